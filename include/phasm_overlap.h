@@ -1,0 +1,127 @@
+/* phasm_overlap.h -- C ABI of libphasm_overlap.so, the MI355X (gfx950) replacement for PHASM's
+ * all-pairs exact read-overlap finder.
+ *
+ * What this boundary replaces.  The reference has no C ABI; its overlapper is a C++ class
+ * exposed to Python through pybind11:
+ *
+ *   class ExactOverlapper                   /root/reference/src/overlapper.h:19-29
+ *     ExactOverlapper()                     src/overlapper.cpp:19      (py::init,  src/phasm.cpp:13)
+ *     addSequence(id, seq)                  src/overlapper.cpp:22-26   ("add_sequence", phasm.cpp:14)
+ *     overlaps(min_length) -> vector<OverlapT>  src/overlapper.cpp:28-150 ("overlaps", phasm.cpp:15)
+ *   OverlapT = tuple<string,string,int,int,int,int>                    src/overlapper.h:17
+ *
+ * Each entry point below names the reference interface it stands in for.  Only plain
+ * pointers and sizes cross the boundary: no C++ types, no exceptions, no torch types.
+ * Every function that can fail returns a po_status; po_last_error() has the message.
+ *
+ * There is no CPU fallback behind this ABI: every overlap is computed by the HIP kernels
+ * in phasm_amd/csrc/.  Without a usable GPU, po_overlaps* fails with PO_ERR_HIP.
+ *
+ * Threading: one handle = one caller at a time (the reference object is not thread-safe
+ * either).  Each handle owns one HIP stream and its device buffers.
+ */
+#ifndef PHASM_OVERLAP_H
+#define PHASM_OVERLAP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PO_ABI_VERSION 1
+
+typedef enum {
+    PO_OK = 0,
+    PO_ERR_INVALID = 1,  /* bad argument (NULL handle, shard >= nshards, ...)            */
+    PO_ERR_NOMEM = 2,    /* host or device allocation failed  -> MemoryError in the shim */
+    PO_ERR_HIP = 3,      /* HIP runtime error / no device     -> RuntimeError            */
+    PO_ERR_CAPACITY = 4  /* candidate or row count exceeds what one call can hold        */
+} po_status;
+
+typedef struct po_handle po_handle;
+typedef struct po_result po_result;
+
+/* One overlap edge.  Same six fields as OverlapT (src/overlapper.h:17) with the two id
+ * strings replaced by read indices (insertion order of po_add_sequence); ids are resolved
+ * with po_get_id.  Coordinates are 0-based half-open on the oriented string as added;
+ * bstart is always 0 (src/overlapper.cpp:81,110).                                         */
+typedef struct {
+    uint32_t a_idx, b_idx;
+    int32_t astart, aend, bstart, bend;
+} po_row;
+
+/* Per-call device timings (HIP events on the handle's stream) and counters of the last
+ * po_overlaps* call on this handle; feeds bench.py's roofline object.                     */
+typedef struct {
+    uint32_t bits_per_base;      /* 2 (pure ACGT) or 8 (raw bytes)                          */
+    uint32_t kmer;               /* anchor length K = min(64/bits, max(min_length,1))       */
+    uint64_t n_reads;            /* reads in the handle                                     */
+    uint64_t n_eligible;         /* reads with length >= min_length (can be a `b`)          */
+    uint64_t total_bases;        /* sum of read lengths (oriented bases B)                  */
+    uint64_t shard_bases;        /* bases of the a-side reads scanned by this call          */
+    uint64_t n_tiles;            /* 64-word scan tiles in this call's shard                 */
+    uint64_t n_candidates;       /* anchor hits (a, p, b) handed to the verify kernel       */
+    uint64_t n_verified;         /* candidates that verified                                */
+    uint64_t n_rows;             /* rows emitted (A + B, duplicates included)               */
+    uint64_t sum_overlap_bases;  /* sum over emitted rows of the overlap length l           */
+    uint64_t verify_bytes_algo;  /* sum over emitted rows of 2*ceil(l*bits/8) (both sides)  */
+    float ms_index;              /* anchor table + chains + Bloom filter build              */
+    float ms_scan_count;         /* position scan, counting pass                            */
+    float ms_scan_fill;          /* position scan, candidate fill pass                      */
+    float ms_verify;             /* packed exact verify of all candidates                   */
+    float ms_select;             /* longest-only selection + row counting                   */
+    float ms_emit;               /* row emission                                            */
+    float ms_total;              /* first kernel start -> last kernel end                   */
+    float ms_upload;             /* H2D of the packed read set if this call uploaded it     */
+} po_stats;
+
+/* ExactOverlapper()  -- src/overlapper.cpp:19, py::init at src/phasm.cpp:13. */
+po_status po_create(po_handle** out);
+void po_destroy(po_handle* h);
+
+/* Choose the HIP device (default 0).  Must precede the first po_overlaps* call. */
+po_status po_set_device(po_handle* h, int device);
+
+/* addSequence(id, seq)  -- src/overlapper.cpp:22-26.  Copies id and seq (the caller may
+ * free them at once).  seq is compared byte-wise, like the reference's CharString: any byte
+ * other than upper-case A/C/G/T switches the handle to the 8-bit representation.           */
+po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const char* seq, size_t seq_len);
+
+uint32_t po_num_sequences(const po_handle* h);
+po_status po_get_id(const po_handle* h, uint32_t idx, const char** id, size_t* id_len);
+uint32_t po_get_length(const po_handle* h, uint32_t idx);
+
+/* Pack (if needed) and copy the read set to the device now instead of at the first
+ * po_overlaps* call.  Idempotent until the next po_add_sequence.                          */
+po_status po_upload(po_handle* h);
+
+/* overlaps(min_length)  -- src/overlapper.cpp:28-150.  Rows stay on the device until
+ * po_result_rows() is called.  Stateless across calls like the reference (index rebuilt per
+ * call, :33-36); min_length 0 behaves as 1 (a suffix array has no empty suffix).          */
+po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out);
+
+/* Multi-GPU form: only the rows whose `a` read lies in shard `shard` of `nshards` (contiguous
+ * read-index ranges balanced by base count) are produced.  The union over all shards is
+ * exactly the po_overlaps() result; the caller merges (RCCL all-gather in phasm_amd/dist.py). */
+po_status po_overlaps_shard(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards,
+                            po_result** out);
+
+uint64_t po_result_count(const po_result* r);
+/* Host pointer to po_result_count() rows (copied device->host on first use); NULL on error. */
+const po_row* po_result_rows(po_result* r);
+/* Device pointer to the same rows (valid until po_result_free). */
+const void* po_result_device_rows(const po_result* r);
+/* Copy the rows device->device into dst (>= count*sizeof(po_row) bytes), e.g. a torch tensor. */
+po_status po_result_copy_to_device(po_result* r, void* dst_device);
+void po_result_free(po_result* r);
+
+po_status po_get_stats(const po_handle* h, po_stats* out);
+const char* po_last_error(const po_handle* h);
+int po_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHASM_OVERLAP_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of libphasm_overlap.so (include/phasm_overlap.h).
+
+There is no fallback: if the shared library is missing this raises ImportError, and the
+library itself fails with PO_ERR_HIP when no GPU is usable.  (``cffi`` is not installed in the
+target image, hence ctypes.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libphasm_overlap.so")
+
+PO_OK, PO_ERR_INVALID, PO_ERR_NOMEM, PO_ERR_HIP, PO_ERR_CAPACITY = range(5)
+
+ROW_DTYPE = np.dtype([("a_idx", "<u4"), ("b_idx", "<u4"), ("astart", "<i4"),
+                      ("aend", "<i4"), ("bstart", "<i4"), ("bend", "<i4")])
+
+
+class PoStats(ctypes.Structure):
+    _fields_ = [
+        ("bits_per_base", ctypes.c_uint32), ("kmer", ctypes.c_uint32),
+        ("n_reads", ctypes.c_uint64), ("n_eligible", ctypes.c_uint64),
+        ("total_bases", ctypes.c_uint64), ("shard_bases", ctypes.c_uint64),
+        ("n_tiles", ctypes.c_uint64), ("n_candidates", ctypes.c_uint64),
+        ("n_verified", ctypes.c_uint64), ("n_rows", ctypes.c_uint64),
+        ("sum_overlap_bases", ctypes.c_uint64), ("verify_bytes_algo", ctypes.c_uint64),
+        ("ms_index", ctypes.c_float), ("ms_scan_count", ctypes.c_float),
+        ("ms_scan_fill", ctypes.c_float), ("ms_verify", ctypes.c_float),
+        ("ms_select", ctypes.c_float), ("ms_emit", ctypes.c_float),
+        ("ms_total", ctypes.c_float), ("ms_upload", ctypes.c_float),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+# every symbol include/phasm_overlap.h declares: (name, restype, argtypes)
+_P = ctypes.c_void_p
+SYMBOLS = [
+    ("po_abi_version", ctypes.c_int, []),
+    ("po_create", ctypes.c_int, [ctypes.POINTER(_P)]),
+    ("po_destroy", None, [_P]),
+    ("po_set_device", ctypes.c_int, [_P, ctypes.c_int]),
+    ("po_add_sequence", ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]),
+    ("po_num_sequences", ctypes.c_uint32, [_P]),
+    ("po_get_id", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]),
+    ("po_get_length", ctypes.c_uint32, [_P, ctypes.c_uint32]),
+    ("po_upload", ctypes.c_int, [_P]),
+    ("po_overlaps", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(_P)]),
+    ("po_overlaps_shard", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),
+    ("po_result_count", ctypes.c_uint64, [_P]),
+    ("po_result_rows", ctypes.c_void_p, [_P]),
+    ("po_result_device_rows", ctypes.c_void_p, [_P]),
+    ("po_result_copy_to_device", ctypes.c_int, [_P, ctypes.c_void_p]),
+    ("po_result_free", None, [_P]),
+    ("po_get_stats", ctypes.c_int, [_P, ctypes.POINTER(PoStats)]),
+    ("po_last_error", ctypes.c_char_p, [_P]),
+]
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: build it with `python -m phasm_amd.build` (hipcc, gfx950). "
+                "phasm_amd has no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, restype, argtypes in SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib

@@ -1,0 +1,37 @@
+"""Build libphasm_overlap.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "c_api.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "kernels.hip.h"), os.path.join(ROOT, "include", "phasm_overlap.h")]
+LIB = os.path.join(HERE, "libphasm_overlap.so")
+ARCH = "gfx950"
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-result", "-o", LIB, SRC]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose="-v" in sys.argv))

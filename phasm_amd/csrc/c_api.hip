@@ -1,0 +1,635 @@
+// Host side of libphasm_overlap.so: the C ABI declared in include/phasm_overlap.h.
+// Holds the read set (2-bit or 8-bit packed 64-bit words), keeps a device-resident copy, and
+// drives the kernels of kernels.hip.h on the handle's own HIP stream.  No CPU compute path.
+#include "../../include/phasm_overlap.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.hip.h"
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+enum { EV_START = 0, EV_INDEX, EV_COUNT, EV_FILL, EV_VERIFY, EV_SELECT, EV_EMIT, EV_N };
+
+}  // namespace
+
+struct po_handle {
+    int device = 0;
+    bool dev_ready = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[EV_N] = {};
+    hipEvent_t ev_up0 = nullptr, ev_up1 = nullptr;
+    uint64_t* pinned = nullptr;  // host-pinned landing zone for device totals/counters (8 x u64)
+    int n_cu = 256;
+    size_t lds_max = 64 * 1024;
+    std::string err;
+
+    // host read store
+    int bits = 2;
+    std::vector<std::string> ids;
+    std::vector<uint32_t> len;
+    std::vector<uint64_t> woff;
+    std::vector<uint64_t> words;
+    uint64_t total_bases = 0;
+    bool dirty = true;
+
+    // device read set + tiling (built at upload)
+    DevBuf d_words, d_woff, d_len, d_tile_read, d_tile_word0, d_read_tile0;
+    std::vector<uint32_t> h_read_tile0;  // n_reads + 1
+    uint32_t n_tiles = 0;
+
+    // per-call workspace (grow-only)
+    DevBuf d_table, d_slot_cnt, d_slot_cur, d_slot_start, d_read_slot, d_chain, d_chain_tmp, d_long_list;
+    DevBuf d_bloom, d_selfrep, d_tile_count, d_tile_off, d_ps_blocks, d_scalars;
+    DevBuf d_cand_a, d_cand_p, d_cand_b, d_type, d_rowcnt, d_row_off;
+    DevBuf spare_rows;
+    int live_results = 0;
+
+    po_stats stats = {};
+};
+
+struct po_result {
+    po_handle* h = nullptr;
+    DevBuf d_rows;
+    uint64_t count = 0;
+    po_row* host = nullptr;
+};
+
+namespace {
+
+po_status fail(po_handle* h, po_status st, const std::string& msg) {
+    if (h) h->err = msg;
+    return st;
+}
+
+#define HIP_TRY(h, expr)                                                                        \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            return fail((h), e_ == hipErrorOutOfMemory ? PO_ERR_NOMEM : PO_ERR_HIP,             \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+        }                                                                                       \
+    } while (0)
+
+po_status ensure(po_handle* h, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return PO_OK;
+    b.release();
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(h, PO_ERR_NOMEM, "hipMalloc(" + std::to_string(want) + " bytes): " + hipGetErrorString(e));
+    }
+    b.cap = want;
+    return PO_OK;
+}
+
+#define PO_TRY(expr)                    \
+    do {                                \
+        po_status s_ = (expr);          \
+        if (s_ != PO_OK) return s_;     \
+    } while (0)
+
+po_status init_device(po_handle* h) {
+    if (h->dev_ready) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        return PO_OK;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(h, PO_ERR_HIP, "no HIP device available (libphasm_overlap has no CPU fallback)");
+    if (h->device < 0 || h->device >= n) return fail(h, PO_ERR_INVALID, "device ordinal out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->lds_max = prop.sharedMemPerBlock;
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (int i = 0; i < EV_N; ++i) HIP_TRY(h, hipEventCreate(&h->ev[i]));
+    HIP_TRY(h, hipEventCreate(&h->ev_up0));
+    HIP_TRY(h, hipEventCreate(&h->ev_up1));
+    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->pinned), 64, hipHostMallocDefault));
+    h->dev_ready = true;
+    return PO_OK;
+}
+
+inline int base_code(unsigned char c) {
+    switch (c) {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T': return 3;
+        default: return -1;
+    }
+}
+
+// Append one read to the packed store.  Layout: every read starts on a 16-byte boundary and is
+// followed by at least one zero guard word (kernels read one word past the last data word).
+void append_packed(po_handle* h, const unsigned char* s, size_t n, int bits) {
+    const size_t per = 64 / bits;
+    size_t off = (h->words.size() + 1) & ~size_t(1);
+    const size_t nw = (n + per - 1) / per;
+    h->words.resize(off + nw + 1, 0);
+    uint64_t* w = h->words.data() + off;
+    if (bits == 2) {
+        for (size_t i = 0; i < n; ++i) w[i >> 5] |= (uint64_t)base_code(s[i]) << ((i & 31) * 2);
+    } else {
+        for (size_t i = 0; i < n; ++i) w[i >> 3] |= (uint64_t)s[i] << ((i & 7) * 8);
+    }
+    h->woff.push_back(off);
+}
+
+// A non-ACGT byte arrived: re-encode everything held so far at 8 bits per base (lossless: all of
+// it was upper-case ACGT).
+void widen_to_bytes(po_handle* h) {
+    std::vector<uint64_t> old_words;
+    std::vector<uint64_t> old_off;
+    old_words.swap(h->words);
+    old_off.swap(h->woff);
+    std::vector<unsigned char> tmp;
+    for (size_t r = 0; r < h->len.size(); ++r) {
+        const uint32_t n = h->len[r];
+        tmp.resize(n);
+        const uint64_t* w = old_words.data() + old_off[r];
+        for (uint32_t i = 0; i < n; ++i) tmp[i] = "ACGT"[(w[i >> 5] >> ((i & 31) * 2)) & 3];
+        append_packed(h, tmp.data(), n, 8);
+    }
+    h->bits = 8;
+}
+
+po_status upload(po_handle* h) {
+    PO_TRY(init_device(h));
+    if (!h->dirty) return PO_OK;
+    const uint32_t n = (uint32_t)h->len.size();
+    const size_t per = 64 / h->bits;
+    // tiles: 64 words each, never spanning reads
+    std::vector<uint32_t> tile_read, tile_word0;
+    h->h_read_tile0.assign((size_t)n + 1, 0);
+    for (uint32_t r = 0; r < n; ++r) {
+        h->h_read_tile0[r] = (uint32_t)tile_read.size();
+        const size_t nw = (h->len[r] + per - 1) / per;
+        for (size_t w0 = 0; w0 < nw; w0 += po::TILE_WORDS) {
+            tile_read.push_back(r);
+            tile_word0.push_back((uint32_t)w0);
+        }
+        if (tile_read.size() > 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "too many scan tiles");
+    }
+    h->h_read_tile0[n] = (uint32_t)tile_read.size();
+    h->n_tiles = (uint32_t)tile_read.size();
+
+    const size_t nwords = h->words.size() + 4;  // trailing zero padding
+    PO_TRY(ensure(h, h->d_words, nwords * 8));
+    PO_TRY(ensure(h, h->d_woff, ((size_t)n + 1) * 8));
+    PO_TRY(ensure(h, h->d_len, ((size_t)n + 1) * 4));
+    PO_TRY(ensure(h, h->d_tile_read, ((size_t)h->n_tiles + 1) * 4));
+    PO_TRY(ensure(h, h->d_tile_word0, ((size_t)h->n_tiles + 1) * 4));
+    PO_TRY(ensure(h, h->d_read_tile0, ((size_t)n + 1) * 4));
+    HIP_TRY(h, hipEventRecord(h->ev_up0, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_words.p, 0, nwords * 8, h->stream));
+    if (!h->words.empty())
+        HIP_TRY(h, hipMemcpyAsync(h->d_words.p, h->words.data(), h->words.size() * 8, hipMemcpyHostToDevice, h->stream));
+    if (n) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_woff.p, h->woff.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_len.p, h->len.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    if (h->n_tiles) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_tile_read.p, tile_read.data(), (size_t)h->n_tiles * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_tile_word0.p, tile_word0.data(), (size_t)h->n_tiles * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_read_tile0.p, h->h_read_tile0.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev_up1, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // host vectors above go out of scope
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, h->ev_up0, h->ev_up1);
+    h->stats.ms_upload = ms;
+    h->dirty = false;
+    return PO_OK;
+}
+
+inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// exclusive scan of n items (u8 or u32) -> u32 offsets; *total_host gets the grand total
+// (a pinned slot: valid after the next hipStreamSynchronize)
+template <typename T>
+po_status prefix_sum(po_handle* h, const T* in, uint64_t n, uint32_t* out, volatile uint64_t* total_host) {
+    *total_host = 0;
+    if (n == 0) return PO_OK;
+    const uint32_t nblocks = cdiv(n, po::PS_TILE);
+    PO_TRY(ensure(h, h->d_ps_blocks, (size_t)nblocks * 8));
+    uint64_t* blocks = h->d_ps_blocks.as<uint64_t>();
+    uint64_t* total_dev = h->d_scalars.as<uint64_t>();
+    hipLaunchKernelGGL(po::k_ps_reduce<T>, dim3(nblocks), dim3(po::PS_BLOCK), 0, h->stream, in, n, blocks);
+    hipLaunchKernelGGL(po::k_ps_spine, dim3(1), dim3(1024), 0, h->stream, blocks, nblocks, total_dev);
+    hipLaunchKernelGGL(po::k_ps_down<T>, dim3(nblocks), dim3(po::PS_BLOCK), 0, h->stream, in, n, blocks, out);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(const_cast<uint64_t*>(total_host), total_dev, 8, hipMemcpyDeviceToHost, h->stream));
+    return PO_OK;
+}
+
+template <int BITS>
+po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, po_result* res) {
+    constexpr uint32_t W = 64 / BITS;
+    const uint32_t n = (uint32_t)h->len.size();
+    const uint32_t m = min_length ? min_length : 1;  // a suffix array has no empty suffix
+    const uint32_t K = m < W ? m : W;
+    const uint64_t kmask = K * BITS >= 64 ? ~0ull : ((1ull << (K * BITS)) - 1ull);
+    hipStream_t st = h->stream;
+    po_stats& S = h->stats;
+    const float keep_upload = S.ms_upload;
+    S = po_stats();
+    S.ms_upload = keep_upload;
+    S.bits_per_base = BITS;
+    S.kmer = K;
+    S.n_reads = n;
+    S.total_bases = h->total_bases;
+
+    // a-side shard: contiguous read ranges balanced by bases
+    uint32_t r_begin = 0, r_end = n;
+    if (nshards > 1) {
+        std::vector<uint64_t> cum((size_t)n + 1, 0);
+        for (uint32_t r = 0; r < n; ++r) cum[r + 1] = cum[r] + h->len[r];
+        auto cut = [&](uint32_t s) -> uint32_t {
+            if (s == 0) return 0;
+            if (s >= nshards) return n;
+            const uint64_t target = (uint64_t)((__uint128_t)cum[n] * s / nshards);
+            return (uint32_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+        };
+        r_begin = cut(shard);
+        r_end = cut(shard + 1);
+        if (r_end < r_begin) r_end = r_begin;
+        S.shard_bases = cum[r_end] - cum[r_begin];
+    } else {
+        S.shard_bases = h->total_bases;
+    }
+    const uint32_t tile_begin = h->h_read_tile0[r_begin], tile_end = h->h_read_tile0[r_end];
+    const uint32_t ntiles = tile_end - tile_begin;
+    S.n_tiles = ntiles;
+
+    uint64_t n_elig = 0;
+    for (uint32_t r = 0; r < n; ++r) n_elig += h->len[r] >= m;
+    S.n_eligible = n_elig;
+    res->count = 0;
+    if (n == 0 || n_elig == 0 || ntiles == 0) return PO_OK;
+
+    // ---- sizes
+    uint32_t tbits = 10;
+    while ((1ull << tbits) < 2 * n_elig) ++tbits;
+    if (tbits > 30) return fail(h, PO_ERR_CAPACITY, "too many reads for the anchor table");
+    const uint32_t nslots = (1u << tbits) + 1;
+    uint32_t bloom_log2 = 13;
+    while (bloom_log2 < 20 && (1ull << bloom_log2) < 16 * n_elig) ++bloom_log2;
+    const size_t bloom_bytes = (size_t)1 << (bloom_log2 - 3);
+
+    PO_TRY(ensure(h, h->d_scalars, 64));
+    PO_TRY(ensure(h, h->d_table, (size_t)nslots * sizeof(po::Slot)));
+    PO_TRY(ensure(h, h->d_slot_cnt, (size_t)nslots * 4));
+    PO_TRY(ensure(h, h->d_slot_cur, (size_t)nslots * 4));
+    PO_TRY(ensure(h, h->d_slot_start, (size_t)nslots * 4));
+    PO_TRY(ensure(h, h->d_read_slot, (size_t)n * 4));
+    PO_TRY(ensure(h, h->d_chain, (size_t)n * 4));
+    PO_TRY(ensure(h, h->d_chain_tmp, (size_t)n * 4));
+    PO_TRY(ensure(h, h->d_long_list, (size_t)nslots * 4));
+    PO_TRY(ensure(h, h->d_bloom, bloom_bytes));
+    PO_TRY(ensure(h, h->d_selfrep, (size_t)n * 4));
+    PO_TRY(ensure(h, h->d_tile_count, ((size_t)h->n_tiles + 1) * 4));
+    PO_TRY(ensure(h, h->d_tile_off, ((size_t)h->n_tiles + 1) * 4));
+
+    const uint64_t* words = h->d_words.as<uint64_t>();
+    const uint64_t* woff = h->d_woff.as<uint64_t>();
+    const uint32_t* len = h->d_len.as<uint32_t>();
+    po::Slot* table = h->d_table.as<po::Slot>();
+    uint32_t* slot_cnt = h->d_slot_cnt.as<uint32_t>();
+    uint32_t* slot_cur = h->d_slot_cur.as<uint32_t>();
+    uint32_t* slot_start = h->d_slot_start.as<uint32_t>();
+    uint32_t* read_slot = h->d_read_slot.as<uint32_t>();
+    uint32_t* chain = h->d_chain.as<uint32_t>();
+    uint32_t* bloom = h->d_bloom.as<uint32_t>();
+    uint32_t* selfrep = h->d_selfrep.as<uint32_t>();
+    unsigned long long* scalars = h->d_scalars.as<unsigned long long>();  // [0] scan total, [1] n_long, [4..6] emit counters
+    uint32_t* n_long = reinterpret_cast<uint32_t*>(scalars + 1);
+
+    // ---- index: anchor table, chains, Bloom filter
+    HIP_TRY(h, hipEventRecord(h->ev[EV_START], st));
+    HIP_TRY(h, hipMemsetAsync(h->d_scalars.p, 0, 64, st));
+    HIP_TRY(h, hipMemsetAsync(bloom, 0, bloom_bytes, st));
+    hipLaunchKernelGGL(po::k_table_init, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt, slot_cur);
+    hipLaunchKernelGGL(po::k_fill_u32, dim3(cdiv(n, 256)), dim3(256), 0, st, selfrep, (uint64_t)n, po::NO_SELFREP);
+    hipLaunchKernelGGL(po::k_table_insert, dim3(cdiv(n, 256)), dim3(256), 0, st, words, woff, len, n, m, kmask, table,
+                       tbits, slot_cnt, read_slot, bloom, bloom_log2);
+    PO_TRY(prefix_sum<uint32_t>(h, slot_cnt, nslots, slot_start, &h->pinned[0]));
+    hipLaunchKernelGGL(po::k_table_finalize, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt, slot_start);
+    hipLaunchKernelGGL(po::k_chain_fill, dim3(cdiv(n, 256)), dim3(256), 0, st, read_slot, n, slot_start, slot_cur, chain);
+    hipLaunchKernelGGL(po::k_chain_sort_short, dim3(cdiv(nslots, 256)), dim3(256), 0, st, slot_cnt, slot_start, nslots,
+                       chain, h->d_long_list.as<uint32_t>(), n_long);
+    hipLaunchKernelGGL(po::k_chain_sort_long, dim3(64), dim3(256), 0, st, slot_cnt, slot_start,
+                       h->d_long_list.as<uint32_t>(), n_long, chain, h->d_chain_tmp.as<uint32_t>());
+    if (nshards > 1) {
+        const uint32_t blocks = std::min<uint32_t>(cdiv((uint64_t)h->n_tiles * 64, 256), (uint32_t)h->n_cu * 8);
+        hipLaunchKernelGGL(po::k_selfrep<BITS>, dim3(blocks), dim3(256), 0, st, words, woff, len,
+                           h->d_tile_read.as<uint32_t>(), h->d_tile_word0.as<uint32_t>(), h->n_tiles, tile_begin,
+                           tile_end, m, kmask, selfrep);
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev[EV_INDEX], st));
+
+    // ---- scan, counting pass
+    po::ScanArgs A = {};
+    A.words = words;
+    A.woff = woff;
+    A.len = len;
+    A.tile_read = h->d_tile_read.as<uint32_t>();
+    A.tile_word0 = h->d_tile_word0.as<uint32_t>();
+    A.tile_begin = tile_begin;
+    A.tile_end = tile_end;
+    A.m = m;
+    A.kmask = kmask;
+    A.bloom = bloom;
+    A.bloom_log2 = bloom_log2;
+    A.table = table;
+    A.tbits = tbits;
+    A.chain = chain;
+    A.selfrep = selfrep;
+    A.tile_count = h->d_tile_count.as<uint32_t>();
+    A.tile_off = h->d_tile_off.as<uint32_t>();
+    const uint32_t scan_waves = po::SCAN_BLOCK / 64;
+    const uint32_t scan_grid = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)h->n_cu, cdiv(ntiles, scan_waves)));
+    const size_t scan_lds = (size_t)scan_waves * 64 * 12 + bloom_bytes;
+    if (scan_lds > h->lds_max) return fail(h, PO_ERR_HIP, "device LDS too small for the scan kernel");
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan<BITS, po::SCAN_COUNT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan<BITS, po::SCAN_FILL>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
+    hipLaunchKernelGGL((po::k_scan<BITS, po::SCAN_COUNT>), dim3(scan_grid), dim3(po::SCAN_BLOCK), scan_lds, st, A);
+    HIP_TRY(h, hipGetLastError());
+    PO_TRY(prefix_sum<uint32_t>(h, A.tile_count + tile_begin, ntiles, h->d_tile_off.as<uint32_t>() + tile_begin, &h->pinned[1]));
+    HIP_TRY(h, hipEventRecord(h->ev[EV_COUNT], st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    const uint64_t n_cand64 = h->pinned[1];
+    S.n_candidates = n_cand64;
+    if (n_cand64 >= 0xFFFFFF00ull)
+        return fail(h, PO_ERR_CAPACITY, "candidate count " + std::to_string(n_cand64) + " exceeds one call's capacity (2^32)");
+    const uint32_t n_cand = (uint32_t)n_cand64;
+
+    uint64_t n_rows64 = 0;
+    if (n_cand) {
+        PO_TRY(ensure(h, h->d_cand_a, (size_t)n_cand * 4));
+        PO_TRY(ensure(h, h->d_cand_p, (size_t)n_cand * 4));
+        PO_TRY(ensure(h, h->d_cand_b, (size_t)n_cand * 4));
+        PO_TRY(ensure(h, h->d_type, (size_t)n_cand));
+        PO_TRY(ensure(h, h->d_rowcnt, (size_t)n_cand));
+        PO_TRY(ensure(h, h->d_row_off, (size_t)n_cand * 4));
+        A.cand_a = h->d_cand_a.as<uint32_t>();
+        A.cand_p = h->d_cand_p.as<uint32_t>();
+        A.cand_b = h->d_cand_b.as<uint32_t>();
+        // ---- scan, fill pass
+        hipLaunchKernelGGL((po::k_scan<BITS, po::SCAN_FILL>), dim3(scan_grid), dim3(po::SCAN_BLOCK), scan_lds, st, A);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(h->ev[EV_FILL], st));
+        // ---- verify
+        hipLaunchKernelGGL(po::k_verify<BITS>, dim3(cdiv((uint64_t)n_cand * po::VER_GROUP, 256)), dim3(256), 0, st, words,
+                           woff, len, A.cand_a, A.cand_p, A.cand_b, n_cand, h->d_type.as<uint8_t>());
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
+        // ---- select + row offsets
+        hipLaunchKernelGGL(po::k_select, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_b,
+                           h->d_type.as<uint8_t>(), n_cand, selfrep, h->d_read_tile0.as<uint32_t>(),
+                           h->d_tile_off.as<uint32_t>(), h->d_rowcnt.as<uint8_t>());
+        HIP_TRY(h, hipGetLastError());
+        PO_TRY(prefix_sum<uint8_t>(h, h->d_rowcnt.as<uint8_t>(), n_cand, h->d_row_off.as<uint32_t>(), &h->pinned[2]));
+        HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        n_rows64 = h->pinned[2];
+        if (n_rows64 >= 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "row count exceeds one call's capacity (2^32)");
+        // ---- emit
+        if (h->spare_rows.cap >= n_rows64 * sizeof(po_row) && h->spare_rows.p) {
+            res->d_rows = h->spare_rows;
+            h->spare_rows = DevBuf();
+        } else {
+            h->spare_rows.release();
+        }
+        PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_rows64 * sizeof(po_row), 256)));
+        hipLaunchKernelGGL(po::k_emit, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_p, A.cand_b,
+                           h->d_type.as<uint8_t>(), h->d_rowcnt.as<uint8_t>(), h->d_row_off.as<uint32_t>(), n_cand, len,
+                           res->d_rows.as<po::Row>(), (uint32_t)BITS, scalars + 4);
+        HIP_TRY(h, hipGetLastError());
+    } else {
+        HIP_TRY(h, hipEventRecord(h->ev[EV_FILL], st));
+        HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
+        HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev[EV_EMIT], st));
+    uint64_t* counters = h->pinned + 4;
+    HIP_TRY(h, hipMemcpyAsync(counters, scalars + 4, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    res->count = n_rows64;
+    S.n_rows = n_rows64;
+    S.n_verified = counters[0];
+    S.sum_overlap_bases = counters[1];
+    S.verify_bytes_algo = counters[2];
+    (void)hipEventElapsedTime(&S.ms_index, h->ev[EV_START], h->ev[EV_INDEX]);
+    (void)hipEventElapsedTime(&S.ms_scan_count, h->ev[EV_INDEX], h->ev[EV_COUNT]);
+    (void)hipEventElapsedTime(&S.ms_scan_fill, h->ev[EV_COUNT], h->ev[EV_FILL]);
+    (void)hipEventElapsedTime(&S.ms_verify, h->ev[EV_FILL], h->ev[EV_VERIFY]);
+    (void)hipEventElapsedTime(&S.ms_select, h->ev[EV_VERIFY], h->ev[EV_SELECT]);
+    (void)hipEventElapsedTime(&S.ms_emit, h->ev[EV_SELECT], h->ev[EV_EMIT]);
+    (void)hipEventElapsedTime(&S.ms_total, h->ev[EV_START], h->ev[EV_EMIT]);
+    return PO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int po_abi_version(void) { return PO_ABI_VERSION; }
+
+po_status po_create(po_handle** out) {
+    if (!out) return PO_ERR_INVALID;
+    po_handle* h = new (std::nothrow) po_handle();
+    if (!h) return PO_ERR_NOMEM;
+    *out = h;
+    return PO_OK;
+}
+
+void po_destroy(po_handle* h) {
+    if (!h) return;
+    if (h->dev_ready) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+        DevBuf* bufs[] = {&h->d_words, &h->d_woff, &h->d_len, &h->d_tile_read, &h->d_tile_word0, &h->d_read_tile0,
+                          &h->d_table, &h->d_slot_cnt, &h->d_slot_cur, &h->d_slot_start, &h->d_read_slot, &h->d_chain,
+                          &h->d_chain_tmp, &h->d_long_list, &h->d_bloom, &h->d_selfrep, &h->d_tile_count, &h->d_tile_off,
+                          &h->d_ps_blocks, &h->d_scalars, &h->d_cand_a, &h->d_cand_p, &h->d_cand_b, &h->d_type,
+                          &h->d_rowcnt, &h->d_row_off, &h->spare_rows};
+        for (DevBuf* b : bufs) b->release();
+        for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(h->ev[i]);
+        (void)hipEventDestroy(h->ev_up0);
+        (void)hipEventDestroy(h->ev_up1);
+        if (h->pinned) (void)hipHostFree(h->pinned);
+        (void)hipStreamDestroy(h->stream);
+    }
+    delete h;
+}
+
+po_status po_set_device(po_handle* h, int device) {
+    if (!h) return PO_ERR_INVALID;
+    if (h->dev_ready && device != h->device) return fail(h, PO_ERR_INVALID, "device already initialised");
+    h->device = device;
+    return PO_OK;
+}
+
+po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const char* seq, size_t seq_len) {
+    if (!h || (!id && id_len) || (!seq && seq_len)) return PO_ERR_INVALID;
+    if (seq_len > 0x7FFFFFF0ull) return fail(h, PO_ERR_CAPACITY, "read longer than 2^31 bases");
+    if (h->len.size() >= 0xFFFFFFF0ull) return fail(h, PO_ERR_CAPACITY, "too many reads");
+    try {
+        const unsigned char* s = reinterpret_cast<const unsigned char*>(seq);
+        if (h->bits == 2) {
+            bool acgt = true;
+            for (size_t i = 0; i < seq_len; ++i) {
+                if (base_code(s[i]) < 0) {
+                    acgt = false;
+                    break;
+                }
+            }
+            if (!acgt) widen_to_bytes(h);
+        }
+        append_packed(h, s, seq_len, h->bits);
+        h->ids.emplace_back(id ? id : "", id_len);
+        h->len.push_back((uint32_t)seq_len);
+        h->total_bases += seq_len;
+        h->dirty = true;
+    } catch (const std::bad_alloc&) {
+        return fail(h, PO_ERR_NOMEM, "out of host memory in po_add_sequence");
+    }
+    return PO_OK;
+}
+
+uint32_t po_num_sequences(const po_handle* h) { return h ? (uint32_t)h->len.size() : 0; }
+
+po_status po_get_id(const po_handle* h, uint32_t idx, const char** id, size_t* id_len) {
+    if (!h || idx >= h->ids.size() || !id || !id_len) return PO_ERR_INVALID;
+    *id = h->ids[idx].data();
+    *id_len = h->ids[idx].size();
+    return PO_OK;
+}
+
+uint32_t po_get_length(const po_handle* h, uint32_t idx) { return (h && idx < h->len.size()) ? h->len[idx] : 0; }
+
+po_status po_upload(po_handle* h) {
+    if (!h) return PO_ERR_INVALID;
+    try {
+        return upload(h);
+    } catch (const std::bad_alloc&) {
+        return fail(h, PO_ERR_NOMEM, "out of host memory in po_upload");
+    }
+}
+
+po_status po_overlaps_shard(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, po_result** out) {
+    if (!h || !out) return PO_ERR_INVALID;
+    *out = nullptr;
+    if (nshards == 0 || shard >= nshards) return fail(h, PO_ERR_INVALID, "shard must be < nshards");
+    po_result* r = new (std::nothrow) po_result();
+    if (!r) return fail(h, PO_ERR_NOMEM, "out of host memory");
+    r->h = h;
+    po_status st;
+    try {
+        st = upload(h);
+        if (st == PO_OK) st = h->bits == 2 ? run_overlaps<2>(h, min_length, shard, nshards, r)
+                                           : run_overlaps<8>(h, min_length, shard, nshards, r);
+    } catch (const std::bad_alloc&) {
+        st = fail(h, PO_ERR_NOMEM, "out of host memory in po_overlaps");
+    }
+    if (st != PO_OK) {
+        if (h->dev_ready) (void)hipStreamSynchronize(h->stream);
+        r->d_rows.release();
+        delete r;
+        return st;
+    }
+    ++h->live_results;
+    *out = r;
+    return PO_OK;
+}
+
+po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out) {
+    return po_overlaps_shard(h, min_length, 0, 1, out);
+}
+
+uint64_t po_result_count(const po_result* r) { return r ? r->count : 0; }
+
+const po_row* po_result_rows(po_result* r) {
+    if (!r) return nullptr;
+    if (r->host || r->count == 0) return r->host;
+    po_handle* h = r->h;
+    r->host = static_cast<po_row*>(std::malloc(r->count * sizeof(po_row)));
+    if (!r->host) {
+        fail(h, PO_ERR_NOMEM, "out of host memory for the row array");
+        return nullptr;
+    }
+    (void)hipSetDevice(h->device);
+    hipError_t e = hipMemcpyAsync(r->host, r->d_rows.p, r->count * sizeof(po_row), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        fail(h, PO_ERR_HIP, std::string("row copy device->host: ") + hipGetErrorString(e));
+        std::free(r->host);
+        r->host = nullptr;
+    }
+    return r->host;
+}
+
+const void* po_result_device_rows(const po_result* r) { return r ? r->d_rows.p : nullptr; }
+
+po_status po_result_copy_to_device(po_result* r, void* dst_device) {
+    if (!r || (!dst_device && r->count)) return PO_ERR_INVALID;
+    if (r->count == 0) return PO_OK;
+    po_handle* h = r->h;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(dst_device, r->d_rows.p, r->count * sizeof(po_row), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PO_OK;
+}
+
+void po_result_free(po_result* r) {
+    if (!r) return;
+    po_handle* h = r->h;
+    std::free(r->host);
+    if (h) {
+        --h->live_results;
+        if (r->d_rows.p && r->d_rows.cap > h->spare_rows.cap) {  // keep the larger buffer for the next call
+            h->spare_rows.release();
+            h->spare_rows = r->d_rows;
+            r->d_rows = DevBuf();
+        }
+    }
+    r->d_rows.release();
+    delete r;
+}
+
+po_status po_get_stats(const po_handle* h, po_stats* out) {
+    if (!h || !out) return PO_ERR_INVALID;
+    *out = h->stats;
+    return PO_OK;
+}
+
+const char* po_last_error(const po_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+"""Drop-in for the reference's ``phasm.overlapper`` extension module.
+
+The reference exposes, through pybind11 (/root/reference/src/phasm.cpp:8-18)::
+
+    class ExactOverlapper:
+        def __init__(self)                       # src/overlapper.cpp:19
+        def add_sequence(self, id: str, seq: str) -> None      # src/overlapper.cpp:22-26
+        def overlaps(self, min_length: int) -> List[Tuple[str, str, int, int, int, int]]
+                                                                # src/overlapper.cpp:28-150
+
+and ``phasm overlap`` is its only caller (phasm/cli/assembler.py:31,39-42).  This class has
+the same three methods with the same argument meaning, return type and error behaviour
+(negative ``min_length`` -> ``TypeError`` like pybind11's unsigned conversion; ``bytes`` ids
+and sequences accepted like pybind11's ``std::string`` caster), and calls the HIP library
+through the C ABI of include/phasm_overlap.h.  Extra, non-reference methods
+(``overlaps_array``, ``overlaps_shard_array``, ``stats``) expose the bulk 24-byte row array
+so callers that want throughput do not have to build millions of Python tuples.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import ROW_DTYPE, PoStats
+
+OverlapT = Tuple[str, str, int, int, int, int]
+
+
+def _to_bytes(x, what: str) -> bytes:
+    if isinstance(x, bytes):
+        return x
+    if isinstance(x, str):
+        return x.encode("utf-8")
+    if isinstance(x, (bytearray, memoryview)):
+        return bytes(x)
+    raise TypeError("%s must be str or bytes, not %s" % (what, type(x).__name__))
+
+
+def _check(handle, status: int):
+    if status == _lib.PO_OK:
+        return
+    msg = _lib.load().po_last_error(handle)
+    msg = msg.decode("utf-8", "replace") if msg else "libphasm_overlap error %d" % status
+    if status == _lib.PO_ERR_NOMEM:
+        raise MemoryError(msg)
+    if status == _lib.PO_ERR_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+class OverlapResult:
+    """Owns one ``po_result``: rows stay on the device until asked for."""
+
+    def __init__(self, owner: "ExactOverlapper", ptr):
+        self._owner = owner
+        self._ptr = ptr
+        self._lib = _lib.load()
+
+    def __len__(self) -> int:
+        return int(self._lib.po_result_count(self._ptr)) if self._ptr else 0
+
+    def rows(self) -> np.ndarray:
+        """Host copy as a structured array (a_idx, b_idx, astart, aend, bstart, bend)."""
+        n = len(self)
+        if n == 0:
+            return np.empty(0, dtype=ROW_DTYPE)
+        p = self._lib.po_result_rows(self._ptr)
+        if not p:
+            _check(self._owner._h, _lib.PO_ERR_HIP)
+        buf = (ctypes.c_char * (n * ROW_DTYPE.itemsize)).from_address(p)
+        return np.frombuffer(buf, dtype=ROW_DTYPE).copy()
+
+    def device_ptr(self) -> int:
+        return int(self._lib.po_result_device_rows(self._ptr) or 0)
+
+    def copy_to_device(self, dst_ptr: int) -> None:
+        _check(self._owner._h, self._lib.po_result_copy_to_device(self._ptr, ctypes.c_void_p(dst_ptr)))
+
+    def free(self) -> None:
+        if self._ptr and self._owner._h:
+            self._lib.po_result_free(self._ptr)
+        self._ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class ExactOverlapper:
+    def __init__(self, device: Optional[int] = None):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        st = self._lib.po_create(ctypes.byref(h))
+        if st != _lib.PO_OK:
+            raise MemoryError("po_create failed")
+        self._h = h
+        self._results: List[OverlapResult] = []
+        if device is not None:
+            _check(self._h, self._lib.po_set_device(self._h, int(device)))
+
+    # ---- the reference API -------------------------------------------------------------
+    def add_sequence(self, id, seq) -> None:
+        bid = _to_bytes(id, "id")
+        bseq = _to_bytes(seq, "seq")
+        _check(self._h, self._lib.po_add_sequence(self._h, bid, len(bid), bseq, len(bseq)))
+
+    def overlaps(self, min_length: int) -> List[OverlapT]:
+        arr = self.overlaps_array(min_length)
+        ids = self.ids()
+        a_ids = [ids[i] for i in arr["a_idx"].tolist()]
+        b_ids = [ids[i] for i in arr["b_idx"].tolist()]
+        return list(zip(a_ids, b_ids, arr["astart"].tolist(), arr["aend"].tolist(),
+                        arr["bstart"].tolist(), arr["bend"].tolist()))
+
+    # ---- bulk / multi-GPU extensions ------------------------------------------------------
+    @staticmethod
+    def _min_length(min_length) -> int:
+        if isinstance(min_length, bool) or not isinstance(min_length, (int, np.integer)):
+            raise TypeError("overlaps(): incompatible function arguments: min_length must be an unsigned int")
+        if min_length < 0 or min_length > 0xFFFFFFFF:
+            raise TypeError("overlaps(): incompatible function arguments: min_length must be an unsigned int")
+        return int(min_length)
+
+    def overlaps_result(self, min_length: int, shard: int = 0, nshards: int = 1) -> OverlapResult:
+        m = self._min_length(min_length)
+        r = ctypes.c_void_p()
+        _check(self._h, self._lib.po_overlaps_shard(self._h, m, int(shard), int(nshards), ctypes.byref(r)))
+        return OverlapResult(self, r)
+
+    def overlaps_array(self, min_length: int) -> np.ndarray:
+        res = self.overlaps_result(min_length)
+        try:
+            return res.rows()
+        finally:
+            res.free()
+
+    def overlaps_shard_array(self, min_length: int, shard: int, nshards: int) -> np.ndarray:
+        res = self.overlaps_result(min_length, shard, nshards)
+        try:
+            return res.rows()
+        finally:
+            res.free()
+
+    def upload(self) -> None:
+        _check(self._h, self._lib.po_upload(self._h))
+
+    def __len__(self) -> int:
+        return int(self._lib.po_num_sequences(self._h))
+
+    def ids(self) -> List[str]:
+        out = []
+        p = ctypes.c_void_p()
+        n = ctypes.c_size_t()
+        for i in range(len(self)):
+            self._lib.po_get_id(self._h, i, ctypes.byref(p), ctypes.byref(n))
+            out.append(ctypes.string_at(p.value, n.value).decode("utf-8", "surrogateescape") if n.value else "")
+        return out
+
+    def lengths(self) -> np.ndarray:
+        return np.array([self._lib.po_get_length(self._h, i) for i in range(len(self))], dtype=np.int64)
+
+    def stats(self) -> dict:
+        s = PoStats()
+        _check(self._h, self._lib.po_get_stats(self._h, ctypes.byref(s)))
+        return s.as_dict()
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.po_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
