@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Benchmark of the overlap hot path on MI355X: overlaps/s (+ read-pairs/s) on BASELINE.json's
+config 2 -- 50k x 15 kb error-free reads from a 5 Mb diploid genome, both strands added as
+`phasm overlap` does (100k oriented reads), min-overlap 1000.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over the whole read set: `po_overlaps` (N=1) or
+`po_overlaps_shard` + RCCL all-gather merge (N>1; fixed total work = strong scaling).  The packed
+reads are resident in HBM before the timed region and the rows stay in HBM (the PCIe-inclusive
+figure is reported separately as `pcie_inclusive`, never as `value`).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel (k_verify): algorithmic bytes of the emitted overlaps
+                (sum 2*ceil(l/4) B, both sides at 2 bit/base) / its HIP-event duration, vs 8 TB/s
+  cpu_baseline  the reference overlapper itself (oracle/_ref, built from /root/reference by
+                `make -C oracle ref`) timed on this host's cores on a bounded, same-density sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from phasm_amd import synth  # noqa: E402
+from phasm_amd.dist import local_shard_rows, merge_row_shards  # noqa: E402
+from phasm_amd.overlapper import ExactOverlapper  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def cpu_baseline(min_length: int, sample_reads: int) -> dict:
+    """Time the CPU baseline on a bounded sample with cfg2's coverage per haplotype (so the same
+    overlaps per read).  This is the only place bench.py touches oracle/ -- as the thing compared
+    against, never as part of the measured GPU path."""
+    from oracle import overlap_oracle as oo
+    cfg = synth.scaled(synth.CONFIGS["cfg2"], sample_reads)
+    seqs = [s for _, s in synth.oriented(synth.generate_reads(cfg))]
+    sample = ("cfg2 density at %d reads: %d oriented x %d b, G=%d diploid snp %.3f seed %d, min_length %d"
+              % (cfg.n_reads, len(seqs), cfg.read_len, cfg.genome_len, cfg.snp, cfg.seed, min_length))
+    if oo.have_reference():
+        _, secs, nrows = oo.reference_overlaps(seqs, min_length, quiet=True)
+        kind = "reference"
+    else:
+        arr, secs = oo.oracle_overlaps_struct(seqs, min_length)
+        nrows = len(arr)
+        kind = "port"
+    n = len(seqs)
+    return {"value": nrows / secs if secs > 0 else None, "unit": "overlaps/s", "cores": 1, "kind": kind,
+            "sample": sample, "seconds": round(secs, 3), "rows": int(nrows),
+            "read_pairs_per_sec": n * (n - 1) / secs if secs > 0 else None,
+            "host_cores_available": os.cpu_count()}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg2", choices=sorted(synth.CONFIGS))
+    ap.add_argument("--reads", type=int, default=0, help="scale the config to this many reads (dev only)")
+    ap.add_argument("--min-length", type=int, default=1000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=800)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the overlap path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = synth.CONFIGS[args.config]
+    if args.reads:
+        cfg = synth.scaled(cfg, args.reads)
+    t_load = time.time()
+    ov = ExactOverlapper(device=local_rank)
+    for name, seq in synth.oriented(synth.generate_reads(cfg)):
+        ov.add_sequence(name, seq)
+    ov.upload()  # packed reads resident in HBM before anything is timed
+    n_oriented = len(ov)
+    t_load = time.time() - t_load
+    m = args.min_length
+
+    stage_keys = ["ms_index", "ms_scan_count", "ms_scan_fill", "ms_verify", "ms_select", "ms_emit", "ms_total"]
+    acc = {k: 0.0 for k in stage_keys}
+    last = {}
+
+    def step(timed: bool) -> int:
+        if world == 1:
+            res = ov.overlaps_result(m)
+            n = len(res)
+            res.free()
+        else:
+            merged = merge_row_shards(local_shard_rows(ov, m, rank, world, device))
+            n = merged.shape[0]
+        st = ov.stats()
+        if timed:
+            for k in stage_keys:
+                acc[k] += st[k]
+        last.update(st)
+        return n
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    n_rows = 0
+    for _ in range(args.steps):
+        n_rows = step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        K = max(args.steps, 1)
+        ms_step = dt / K * 1e3
+        avg = {k: acc[k] / K for k in stage_keys}
+        ver_bytes = last["verify_bytes_algo"]                      # this rank's shard, per launch
+        ver_gbs = ver_bytes / (avg["ms_verify"] * 1e-3) / 1e9 if avg["ms_verify"] > 0 else 0.0
+        job_bytes = last["shard_bases"] * last["bits_per_base"] / 8 + ver_bytes + 24 * last["n_rows"]
+        job_gbs = job_bytes / (avg["ms_total"] * 1e-3) / 1e9 if avg["ms_total"] > 0 else 0.0
+        out = {
+            "metric": "overlaps_per_sec", "value": n_rows / (dt / K), "unit": "overlaps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%s: %d x %d b error-free reads, %d b %d-ploid genome (snp %.3f, seed %d), "
+                                   "both strands = %d oriented reads, min_overlap %d"
+                                   % (args.config, cfg.n_reads, cfg.read_len, cfg.genome_len, cfg.ploidy,
+                                      cfg.snp, cfg.seed, n_oriented, m),
+                       "n_reads": cfg.n_reads, "read_len": cfg.read_len, "min_length": m,
+                       "parallelism": "a-side read shards x%d + RCCL all-gather of rows" % world if world > 1
+                                      else "single GPU"},
+            "rows_per_step": int(n_rows),
+            "read_pairs_per_sec": n_oriented * (n_oriented - 1) / (dt / K),
+            "candidates_per_step": int(last["n_candidates"]),
+            "stage_ms": {k: round(v, 4) for k, v in avg.items()},
+            "load_seconds": round(t_load, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_verify<%d>" % last["bits_per_base"],
+                         "achieved": ver_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ver_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": int(ver_bytes),
+                         "avg_launch_ms": avg["ms_verify"],
+                         "job_achieved": job_gbs, "job_frac": job_gbs / HBM_PEAK_GBS,
+                         "job_algorithmic_bytes": int(job_bytes)},
+        }
+        if world == 1:
+            # PCIe-inclusive rate (rows copied to the host): reported, never `value`
+            t1 = time.perf_counter()
+            res = ov.overlaps_result(m)
+            _ = res.rows()
+            res.free()
+            out["pcie_inclusive"] = {"overlaps_per_sec": n_rows / (time.perf_counter() - t1),
+                                     "note": "one step + D2H of the 24-byte row array to pageable host memory"}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(m, args.cpu_sample_reads)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ov.close()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

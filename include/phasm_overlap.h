@@ -108,6 +108,10 @@ po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out);
 po_status po_overlaps_shard(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards,
                             po_result** out);
 
+/* The read-index range [*r_begin, *r_end) that po_overlaps_shard(shard, nshards) scans on the
+ * a-side.  Pure host logic (no GPU needed). */
+po_status po_shard_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint32_t* r_begin, uint32_t* r_end);
+
 uint64_t po_result_count(const po_result* r);
 /* Host pointer to po_result_count() rows (copied device->host on first use); NULL on error. */
 const po_row* po_result_rows(po_result* r);

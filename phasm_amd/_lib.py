@@ -52,6 +52,7 @@ SYMBOLS = [
     ("po_upload", ctypes.c_int, [_P]),
     ("po_overlaps", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_overlaps_shard", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),
+    ("po_shard_range", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
     ("po_result_count", ctypes.c_uint64, [_P]),
     ("po_result_rows", ctypes.c_void_p, [_P]),
     ("po_result_device_rows", ctypes.c_void_p, [_P]),

@@ -1,0 +1,63 @@
+"""``phasm overlap`` on the MI355X path.
+
+Counterpart of ``overlap(args)`` in the reference CLI (/root/reference/phasm/cli/assembler.py:29-50,
+parser at :436-452): same positional FASTA argument, ``-l/--min-length`` (default 1000),
+``-o/--output`` (default stdout), and byte-identical ``H`` / ``S`` / ``E`` lines for identical
+rows -- all ``S`` lines first, then the ``E`` lines.  Row order differs from the reference
+(whose order is an artefact of ``std::unordered_map`` iteration, overlapper.cpp:30,:68): here
+rows are a-major in FASTA order, then by start position.
+
+    python -m phasm_amd.cli overlap reads.fasta -l 1000 -o overlaps.gfa
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import sys
+
+from .io import gfa
+from .io.fasta import read_fasta, reverse_complement
+from .overlapper import ExactOverlapper
+
+logger = logging.getLogger("phasm_amd")
+
+
+def overlap(args) -> int:
+    args.output.write(gfa.gfa_header())
+    overlapper = ExactOverlapper(device=getattr(args, "device", None))
+    logger.info("Packing reads and searching for pairwise overlaps on the GPU...")
+    for name, seq in read_fasta(args.fasta_input):
+        args.output.write(gfa.gfa_line("S", name, len(seq), "*"))
+        overlapper.add_sequence(name + "+", seq)
+        overlapper.add_sequence(name + "-", reverse_complement(seq))
+    rows = overlapper.overlaps_array(args.min_length)
+    logger.info("Writing %d overlaps to GFA2...", len(rows))
+    gfa.write_edges(args.output, rows, overlapper.ids())
+    logger.info("Done.")
+    return len(rows)
+
+
+def main(argv=None) -> int:
+    parser = argparse.ArgumentParser(prog="phasm-amd", description="MI355X-native PHASM overlap step")
+    parser.add_argument("-v", "--verbose", action="count", default=0)
+    sub = parser.add_subparsers(dest="command")
+    p = sub.add_parser("overlap", help="Find pairwise exact overlaps between reads in a FASTA file.")
+    p.add_argument("-l", "--min-length", type=int, default=1000,
+                   help="Minimum overlap length (default: 1000)")
+    p.add_argument("-o", "--output", type=argparse.FileType("w"), default=sys.stdout,
+                   help="Output file (default: stdout)")
+    p.add_argument("--device", type=int, default=None, help="HIP device ordinal (default 0)")
+    p.add_argument("fasta_input", help="FASTA file with reads")
+    p.set_defaults(func=overlap)
+    args = parser.parse_args(argv)
+    if not getattr(args, "func", None):
+        parser.print_help()
+        return 1
+    logging.basicConfig(level=[logging.WARNING, logging.INFO, logging.DEBUG][min(args.verbose, 2)],
+                        stream=sys.stderr)
+    args.func(args)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -226,6 +226,23 @@ po_status upload(po_handle* h) {
     return PO_OK;
 }
 
+// a-side shard: contiguous read ranges balanced by bases
+void shard_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint32_t* r_begin, uint32_t* r_end, uint64_t* bases) {
+    const uint32_t n = (uint32_t)h->len.size();
+    std::vector<uint64_t> cum((size_t)n + 1, 0);
+    for (uint32_t r = 0; r < n; ++r) cum[r + 1] = cum[r] + h->len[r];
+    auto cut = [&](uint32_t s) -> uint32_t {
+        if (s == 0) return 0;
+        if (s >= nshards) return n;
+        const uint64_t target = (uint64_t)((__uint128_t)cum[n] * s / nshards);
+        return (uint32_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+    };
+    *r_begin = cut(shard);
+    *r_end = cut(shard + 1);
+    if (*r_end < *r_begin) *r_end = *r_begin;
+    if (bases) *bases = cum[*r_end] - cum[*r_begin];
+}
+
 inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // exclusive scan of n items (u8 or u32) -> u32 offsets; *total_host gets the grand total
@@ -263,24 +280,9 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     S.n_reads = n;
     S.total_bases = h->total_bases;
 
-    // a-side shard: contiguous read ranges balanced by bases
     uint32_t r_begin = 0, r_end = n;
-    if (nshards > 1) {
-        std::vector<uint64_t> cum((size_t)n + 1, 0);
-        for (uint32_t r = 0; r < n; ++r) cum[r + 1] = cum[r] + h->len[r];
-        auto cut = [&](uint32_t s) -> uint32_t {
-            if (s == 0) return 0;
-            if (s >= nshards) return n;
-            const uint64_t target = (uint64_t)((__uint128_t)cum[n] * s / nshards);
-            return (uint32_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
-        };
-        r_begin = cut(shard);
-        r_end = cut(shard + 1);
-        if (r_end < r_begin) r_end = r_begin;
-        S.shard_bases = cum[r_end] - cum[r_begin];
-    } else {
-        S.shard_bases = h->total_bases;
-    }
+    S.shard_bases = h->total_bases;
+    if (nshards > 1) shard_range(h, shard, nshards, &r_begin, &r_end, &S.shard_bases);
     const uint32_t tile_begin = h->h_read_tile0[r_begin], tile_end = h->h_read_tile0[r_end];
     const uint32_t ntiles = tile_end - tile_begin;
     S.n_tiles = ntiles;
@@ -428,7 +430,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             h->spare_rows.release();
         }
         PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_rows64 * sizeof(po_row), 256)));
-        hipLaunchKernelGGL(po::k_emit, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_p, A.cand_b,
+        hipLaunchKernelGGL(po::k_emit, dim3(std::min<uint32_t>(cdiv(n_cand, 256), (uint32_t)h->n_cu * 16)), dim3(256), 0, st, A.cand_a, A.cand_p, A.cand_b,
                            h->d_type.as<uint8_t>(), h->d_rowcnt.as<uint8_t>(), h->d_row_off.as<uint32_t>(), n_cand, len,
                            res->d_rows.as<po::Row>(), (uint32_t)BITS, scalars + 4);
         HIP_TRY(h, hipGetLastError());
@@ -572,6 +574,16 @@ po_status po_overlaps_shard(po_handle* h, uint32_t min_length, uint32_t shard, u
 
 po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out) {
     return po_overlaps_shard(h, min_length, 0, 1, out);
+}
+
+po_status po_shard_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint32_t* r_begin, uint32_t* r_end) {
+    if (!h || !r_begin || !r_end || nshards == 0 || shard >= nshards) return PO_ERR_INVALID;
+    try {
+        shard_range(h, shard, nshards, r_begin, r_end, nullptr);
+    } catch (const std::bad_alloc&) {
+        return PO_ERR_NOMEM;
+    }
+    return PO_OK;
 }
 
 uint64_t po_result_count(const po_result* r) { return r ? r->count : 0; }

@@ -481,16 +481,17 @@ __global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __
     rowcnt[i] = (uint8_t)cnt;
 }
 
-__global__ void k_emit(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
-                       const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,
-                       const uint8_t* __restrict__ rowcnt, const uint32_t* __restrict__ row_off, uint32_t n_cand,
-                       const uint32_t* __restrict__ len, Row* __restrict__ rows, uint32_t bits,
-                       unsigned long long* __restrict__ counters /* [0]=verified [1]=sum l [2]=sum 2*ceil(l*bits/8) */) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
+                                              const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,
+                                              const uint8_t* __restrict__ rowcnt, const uint32_t* __restrict__ row_off,
+                                              uint32_t n_cand, const uint32_t* __restrict__ len, Row* __restrict__ rows,
+                                              uint32_t bits,
+                                              unsigned long long* __restrict__ counters /* [0]=verified [1]=sum l [2]=sum 2*ceil(l*bits/8) */) {
+    __shared__ uint64_t s_red[3][256 / WAVE];
     uint64_t nver = 0, suml = 0, sumb = 0;
-    if (i < n_cand) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cand; i += gridDim.x * blockDim.x) {
         const uint32_t t = type[i], rc = rowcnt[i];
-        nver = t != 0;
+        nver += t != 0;
         if (rc) {
             const uint32_t a = cand_a[i], p = cand_p[i], b = cand_b[i];
             const uint32_t la = len[a], lb = len[b];
@@ -513,10 +514,16 @@ __global__ void k_emit(const uint32_t* __restrict__ cand_a, const uint32_t* __re
     nver = wave_sum64(nver);
     suml = wave_sum64(suml);
     sumb = wave_sum64(sumb);
-    if (lane_id() == 0 && (nver | suml)) {
-        atomicAdd(&counters[0], (unsigned long long)nver);
-        atomicAdd(&counters[1], (unsigned long long)suml);
-        atomicAdd(&counters[2], (unsigned long long)sumb);
+    if (lane_id() == 0) {
+        s_red[0][threadIdx.x >> 6] = nver;
+        s_red[1][threadIdx.x >> 6] = suml;
+        s_red[2][threadIdx.x >> 6] = sumb;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {  // one atomic per counter per workgroup
+        uint64_t v = 0;
+        for (int w = 0; w < 256 / WAVE; ++w) v += s_red[threadIdx.x][w];
+        if (v) atomicAdd(&counters[threadIdx.x], (unsigned long long)v);
     }
 }
 

@@ -146,6 +146,12 @@ class ExactOverlapper:
         finally:
             res.free()
 
+    def shard_range(self, shard: int, nshards: int) -> Tuple[int, int]:
+        """Read-index range scanned on the a-side by shard ``shard`` of ``nshards`` (host logic)."""
+        b, e = ctypes.c_uint32(), ctypes.c_uint32()
+        _check(self._h, self._lib.po_shard_range(self._h, int(shard), int(nshards), ctypes.byref(b), ctypes.byref(e)))
+        return b.value, e.value
+
     def upload(self) -> None:
         _check(self._h, self._lib.po_upload(self._h))
 
