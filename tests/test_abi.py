@@ -1,0 +1,83 @@
+"""The C-ABI library loads and exports every symbol include/phasm_overlap.h declares; host-side
+logic that needs no GPU behaves; compute entry points fail loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from phasm_amd import _lib
+from phasm_amd.overlapper import ExactOverlapper
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _have_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "phasm_overlap.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(po_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = header_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(s[0] for s in _lib.SYMBOLS) == names  # the ctypes table binds exactly the header
+    assert lib.po_abi_version() == 1
+
+
+def test_row_struct_is_24_bytes():
+    assert _lib.ROW_DTYPE.itemsize == 24
+    assert ctypes.sizeof(_lib.PoStats) == 2 * 4 + 10 * 8 + 8 * 4
+
+
+def test_host_side_store_and_shard_ranges():
+    ov = ExactOverlapper()
+    seqs = ["ACGT" * k for k in range(1, 11)]
+    for i, s in enumerate(seqs):
+        ov.add_sequence("read%d+" % i, s)
+    ov.add_sequence(b"bytes-id", b"ACGTNNNN")      # bytes accepted like pybind11's std::string caster
+    assert len(ov) == 11
+    assert ov.ids()[3] == "read3+" and ov.ids()[-1] == "bytes-id"
+    assert ov.lengths().tolist() == [4 * k for k in range(1, 11)] + [8]
+    # shards: contiguous, cover everything, balanced by bases
+    for ns in (1, 2, 3, 8, 20):
+        rng = [ov.shard_range(k, ns) for k in range(ns)]
+        assert rng[0][0] == 0 and rng[-1][1] == 11
+        assert all(rng[k][1] == rng[k + 1][0] for k in range(ns - 1))
+    with pytest.raises(ValueError):
+        ov.shard_range(3, 3)
+    with pytest.raises(TypeError):
+        ov.overlaps(-1)
+    with pytest.raises(TypeError):
+        ov.overlaps("10")
+    with pytest.raises(TypeError):
+        ov.add_sequence(5, "ACGT")
+    ov.close()
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU failure mode")
+def test_overlaps_fails_loudly_without_gpu():
+    ov = ExactOverlapper()
+    ov.add_sequence("a", "ACGTACGT")
+    ov.add_sequence("b", "ACGTACGT")
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback|hip"):
+        ov.overlaps(3)
+    ov.close()
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under phasm_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "phasm_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "overlap_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f

@@ -1,0 +1,99 @@
+"""GPU end-to-end: the overlap command's file output, the torch-side merge helper on one GPU, and
+size-independent properties at BASELINE.json's full config-2 size."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_utils as gu
+from oracle import overlap_oracle as oo
+from phasm_amd import cli, synth
+from phasm_amd.io import gfa
+from phasm_amd.overlapper import ExactOverlapper
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cli_overlap_writes_reference_lines(tmp_path):
+    """H line, all S lines, then E lines byte-identical to the reference CLI's formatting
+    (assembler.py:30,38,46-48) for the golden rows."""
+    name, seqs, m, want = gu.ladder_case("ladder_small")
+    cfg = synth.SynthConfig(n_reads=80, read_len=2000, genome_len=10_000, ploidy=2, snp=0.005, seed=11)
+    reads = synth.generate_reads(cfg)
+    fa = tmp_path / "reads.fasta"
+    synth.write_fasta(str(fa), reads, width=70)           # multi-line records
+    out = tmp_path / "out.gfa"
+    assert cli.main(["overlap", str(fa), "-l", str(m), "-o", str(out)]) == 0
+    lines = out.read_text().splitlines(keepends=True)
+    assert lines[0] == "H\tVN:z:2.0\n"
+    s_lines = [l for l in lines if l.startswith("S\t")]
+    e_lines = [l for l in lines if l.startswith("E\t")]
+    assert lines[1:1 + len(s_lines)] == [gfa.gfa_line("S", n, len(s), "*") for n, s in reads]
+    assert len(lines) == 1 + len(s_lines) + len(e_lines)
+    ids = [n for n, _ in synth.oriented(reads)]
+    want_lines = sorted(gfa.gfa_line("E", "*", ids[a], ids[b], s, e, bs, be, "*") for a, b, s, e, bs, be in want.tolist())
+    assert sorted(e_lines) == want_lines
+
+
+def test_merge_helper_single_gpu():
+    from phasm_amd.dist import rows_tensor_to_struct, sharded_overlaps
+    _, seqs, m, want = gu.ladder_case("ladder_varlen")
+    ov = ExactOverlapper(device=0)
+    for i, s in enumerate(seqs):
+        ov.add_sequence("r%d" % i, s)
+    t = sharded_overlaps(ov, m, device=torch.device("cuda", 0))
+    assert t.is_cuda and t.dtype == torch.int32 and t.shape[1] == 6
+    assert np.array_equal(oo.sort_rows(oo.struct_to_rows(rows_tensor_to_struct(t))), want)
+    ov.close()
+
+
+@pytest.mark.skipif(os.environ.get("PHASM_SKIP_FULL") == "1", reason="full-size run disabled")
+def test_full_size_cfg2_properties():
+    """50k x 15 kb (100k oriented reads): too big for the CPU oracle in seconds, so check what must
+    hold at any size: every row is a true match on the original strings (sampled), A rows are unique
+    per (a,b) and reach the end of a, B rows cover the whole of b, the multiset is closed under the
+    strand mirror, and a sampled set of reads agrees with the CPU oracle run on
+    just those reads' neighbourhoods."""
+    cfg = synth.CONFIGS["cfg2"]
+    reads = synth.generate_reads(cfg)
+    oriented = synth.oriented(reads)
+    ov = ExactOverlapper(device=0)
+    for n, s in oriented:
+        ov.add_sequence(n, s)
+    arr = ov.overlaps_array(1000)
+    st = ov.stats()
+    ov.close()
+    lens = np.array([len(s) for _, s in oriented], dtype=np.int64)
+    a, b = arr["a_idx"].astype(np.int64), arr["b_idx"].astype(np.int64)
+    s, e, bs, be = (arr[k].astype(np.int64) for k in ("astart", "aend", "bstart", "bend"))
+    assert len(arr) == st["n_rows"] > 6_000_000
+    assert (a != b).all() and (bs == 0).all() and (be >= 1000).all() and (e - s == be).all()
+    is_a = e == lens[a]
+    is_b = be == lens[b]
+    assert (is_a | is_b).all()
+    # sampled string check on the original bytes
+    rng = np.random.default_rng(0)
+    for i in rng.integers(0, len(arr), size=3000):
+        assert oriented[a[i]][1][s[i]:e[i]] == oriented[b[i]][1][:be[i]]
+    # A rows: one per ordered pair
+    fam_a = arr[is_a & ~is_b]
+    key = fam_a["a_idx"].astype(np.int64) << 32 | fam_a["b_idx"].astype(np.int64)
+    assert len(np.unique(key)) == len(key)
+    # strand-mirror closure of the whole multiset
+    rows = oo.struct_to_rows(arr)
+    both = rows[is_a & is_b]
+    uniq, cnt = np.unique(both, axis=0, return_counts=True)
+    assert (cnt % 2 == 0).all()
+    fa_ = np.concatenate([rows[is_a & ~is_b], uniq.repeat(cnt // 2, axis=0)])
+    fb_ = np.concatenate([rows[is_b & ~is_a], uniq.repeat(cnt // 2, axis=0)])
+    ma = np.stack([fa_[:, 1] ^ 1, fa_[:, 0] ^ 1, lens[fa_[:, 1]] - fa_[:, 5], lens[fa_[:, 1]], fa_[:, 4], fa_[:, 5]], axis=1)
+    mb = np.stack([fb_[:, 0] ^ 1, fb_[:, 1] ^ 1, lens[fb_[:, 0]] - fb_[:, 3], lens[fb_[:, 0]] - fb_[:, 2], fb_[:, 4], fb_[:, 5]], axis=1)
+    assert np.array_equal(oo.sort_rows(np.concatenate([ma, mb])), oo.sort_rows(rows))
+    # oracle on a closed neighbourhood: rows among the first 400 oriented reads must equal the
+    # oracle run on those 400 reads alone (rows only depend on the two reads involved)
+    sub = [s_ for _, s_ in oriented[:400]]
+    want = oo.oracle_overlaps(sub, 1000)
+    got = oo.sort_rows(rows[(rows[:, 0] < 400) & (rows[:, 1] < 400)])
+    assert np.array_equal(got, want)

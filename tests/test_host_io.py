@@ -1,0 +1,57 @@
+"""Host logic around the hot path: FASTA ingest, reverse complement, GFA2 lines, generator."""
+import io
+
+import numpy as np
+
+from phasm_amd import synth
+from phasm_amd._lib import ROW_DTYPE
+from phasm_amd.io import gfa
+from phasm_amd.io.fasta import read_fasta, reverse_complement
+
+
+def test_gfa_lines_match_reference_format():
+    # strings observed from the reference's phasm.io.gfa
+    assert gfa.gfa_header() == "H\tVN:z:2.0\n"
+    assert gfa.gfa_line("E", "*", "read1+", "read2+", 6, 12, 0, 6, "*") == "E\t*\tread1+\tread2+\t6\t12\t0\t6\t*\n"
+    assert gfa.gfa_line("S", "read1", 12, "*") == "S\tread1\t12\t*\n"
+    assert gfa.gfa_header(trace_spacing=100) == "H\tVN:z:2.0\tTS:i:100\n"
+
+
+def test_write_edges_is_byte_identical_to_per_row_gfa_line():
+    rows = np.array([(0, 1, 6, 12, 0, 6), (1, 0, 0, 5, 0, 5), (2, 1, 100000, 115000, 0, 15000)], dtype=ROW_DTYPE)
+    ids = ["r a+", "r a-", "x|y z+"]
+    want = "".join(gfa.gfa_line("E", "*", ids[r["a_idx"]], ids[r["b_idx"]], r["astart"], r["aend"],
+                                r["bstart"], r["bend"], "*") for r in rows)
+    out = io.StringIO()
+    assert gfa.write_edges(out, rows, ids, chunk=2) == 3
+    assert out.getvalue() == want
+
+
+def test_fasta_reader_multiline_blank_lines_and_full_header():
+    txt = b">read1 some description\nACGT\nacgt\n\n>read2\n\nNNNN\nAC\n>empty\n>last\nT\n"
+    recs = list(read_fasta(io.BytesIO(txt)))
+    assert recs == [("read1 some description", b"ACGTacgt"), ("read2", b"NNNNAC"), ("empty", b""), ("last", b"T")]
+
+
+def test_reverse_complement():
+    assert reverse_complement(b"AAACCCGGGTTT") == b"AAACCCGGGTTT"
+    assert reverse_complement(b"GGGTTTACGTAC") == b"GTACGTAAACCC"
+    assert reverse_complement("ACGTN") == "NACGT"
+    assert reverse_complement(b"acgt") == b"acgt"
+    s = synth.codes_to_ascii(np.random.default_rng(0).integers(0, 4, 1000, dtype=np.uint8))
+    assert reverse_complement(reverse_complement(s)) == s
+
+
+def test_generator_is_seeded_and_shaped():
+    cfg = synth.SynthConfig(n_reads=50, read_len=500, genome_len=3000, ploidy=3, seed=9)
+    a = synth.generate_reads(cfg)
+    b = synth.generate_reads(cfg)
+    assert a == b and len(a) == 50 and all(len(s) == 500 for _, s in a)
+    assert a[0][0] == "read0" and set(b"".join(s for _, s in a)) <= set(b"ACGT")
+    o = synth.oriented(a)
+    assert len(o) == 100 and o[0][0] == "read0+" and o[1][0] == "read0-"
+    assert o[1][1] == reverse_complement(o[0][1])
+    c1 = synth.CONFIGS["cfg1"]
+    assert c1.len_sd > 0 and synth.CONFIGS["cfg2"].n_reads == 50_000
+    sc = synth.scaled(synth.CONFIGS["cfg2"], 800)
+    assert sc.genome_len == 80_000 and sc.n_reads == 800
