@@ -23,6 +23,7 @@ ROW_DTYPE = np.dtype([("a_idx", "<u4"), ("b_idx", "<u4"), ("astart", "<i4"),
 class PoStats(ctypes.Structure):
     _fields_ = [
         ("bits_per_base", ctypes.c_uint32), ("kmer", ctypes.c_uint32),
+        ("paired", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
         ("n_reads", ctypes.c_uint64), ("n_eligible", ctypes.c_uint64),
         ("total_bases", ctypes.c_uint64), ("shard_bases", ctypes.c_uint64),
         ("n_tiles", ctypes.c_uint64), ("n_candidates", ctypes.c_uint64),

@@ -53,13 +53,15 @@ struct po_handle {
     bool dirty = true;
 
     // device read set + tiling (built at upload)
-    DevBuf d_words, d_woff, d_len, d_tile_read, d_tile_word0, d_read_tile0;
+    DevBuf d_words, d_woff, d_len, d_tiles, d_read_tile0;
     std::vector<uint32_t> h_read_tile0;  // n_reads + 1
     uint32_t n_tiles = 0;
+    uint32_t max_len = 0;
+    bool paired = false;  // every read 2i+1 is the reverse complement of read 2i (checked on device at upload)
 
     // per-call workspace (grow-only)
     DevBuf d_table, d_slot_cnt, d_slot_cur, d_slot_start, d_read_slot, d_chain, d_chain_tmp, d_long_list;
-    DevBuf d_bloom, d_selfrep, d_tile_count, d_tile_off, d_ps_blocks, d_scalars;
+    DevBuf d_bloom, d_selfrep, d_tile_count, d_tile_off, d_truemask, d_ps_blocks, d_scalars;
     DevBuf d_cand_a, d_cand_p, d_cand_b, d_type, d_rowcnt, d_row_off;
     DevBuf spare_rows;
     int live_results = 0;
@@ -177,32 +179,41 @@ void widen_to_bytes(po_handle* h) {
     h->bits = 8;
 }
 
+inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+
 po_status upload(po_handle* h) {
     PO_TRY(init_device(h));
     if (!h->dirty) return PO_OK;
     const uint32_t n = (uint32_t)h->len.size();
     const size_t per = 64 / h->bits;
     // tiles: 64 words each, never spanning reads
-    std::vector<uint32_t> tile_read, tile_word0;
+    std::vector<po::TileRec> tiles;
     h->h_read_tile0.assign((size_t)n + 1, 0);
+    h->max_len = 0;
     for (uint32_t r = 0; r < n; ++r) {
-        h->h_read_tile0[r] = (uint32_t)tile_read.size();
+        h->h_read_tile0[r] = (uint32_t)tiles.size();
+        h->max_len = std::max(h->max_len, h->len[r]);
         const size_t nw = (h->len[r] + per - 1) / per;
         for (size_t w0 = 0; w0 < nw; w0 += po::TILE_WORDS) {
-            tile_read.push_back(r);
-            tile_word0.push_back((uint32_t)w0);
+            po::TileRec t;
+            t.wabs = h->woff[r] + w0;
+            t.wread = h->woff[r];
+            t.read = r;
+            t.la = h->len[r];
+            t.word0 = (uint32_t)w0;
+            t.pad = 0;
+            tiles.push_back(t);
         }
-        if (tile_read.size() > 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "too many scan tiles");
+        if (tiles.size() > 0x7FFFFF00ull / po::WAVE) return fail(h, PO_ERR_CAPACITY, "too many scan tiles");
     }
-    h->h_read_tile0[n] = (uint32_t)tile_read.size();
-    h->n_tiles = (uint32_t)tile_read.size();
+    h->h_read_tile0[n] = (uint32_t)tiles.size();
+    h->n_tiles = (uint32_t)tiles.size();
 
     const size_t nwords = h->words.size() + 4;  // trailing zero padding
     PO_TRY(ensure(h, h->d_words, nwords * 8));
     PO_TRY(ensure(h, h->d_woff, ((size_t)n + 1) * 8));
     PO_TRY(ensure(h, h->d_len, ((size_t)n + 1) * 4));
-    PO_TRY(ensure(h, h->d_tile_read, ((size_t)h->n_tiles + 1) * 4));
-    PO_TRY(ensure(h, h->d_tile_word0, ((size_t)h->n_tiles + 1) * 4));
+    PO_TRY(ensure(h, h->d_tiles, ((size_t)h->n_tiles + 1) * sizeof(po::TileRec)));
     PO_TRY(ensure(h, h->d_read_tile0, ((size_t)n + 1) * 4));
     HIP_TRY(h, hipEventRecord(h->ev_up0, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_words.p, 0, nwords * 8, h->stream));
@@ -213,12 +224,24 @@ po_status upload(po_handle* h) {
         HIP_TRY(h, hipMemcpyAsync(h->d_len.p, h->len.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     }
     if (h->n_tiles) {
-        HIP_TRY(h, hipMemcpyAsync(h->d_tile_read.p, tile_read.data(), (size_t)h->n_tiles * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->d_tile_word0.p, tile_word0.data(), (size_t)h->n_tiles * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_tiles.p, tiles.data(), (size_t)h->n_tiles * sizeof(po::TileRec), hipMemcpyHostToDevice, h->stream));
     }
     HIP_TRY(h, hipMemcpyAsync(h->d_read_tile0.p, h->h_read_tile0.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, h->stream));
+    // strand pairing: decides whether po_overlaps may compute one member of each mirror pair
+    h->paired = false;
+    const bool try_paired = h->bits == 2 && n >= 2 && (n % 2) == 0 && !getenv("PHASM_NO_MIRROR");
+    if (try_paired) {
+        PO_TRY(ensure(h, h->d_scalars, 64));
+        HIP_TRY(h, hipMemsetAsync(h->d_scalars.p, 0, 64, h->stream));
+        hipLaunchKernelGGL(po::k_paired_check, dim3(cdiv((uint64_t)(n / 2) * 64, 256)), dim3(256), 0, h->stream,
+                           h->d_words.as<uint64_t>(), h->d_woff.as<uint64_t>(), h->d_len.as<uint32_t>(), n / 2,
+                           h->d_scalars.as<uint32_t>());
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(h->pinned, h->d_scalars.p, 8, hipMemcpyDeviceToHost, h->stream));
+    }
     HIP_TRY(h, hipEventRecord(h->ev_up1, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));  // host vectors above go out of scope
+    if (try_paired) h->paired = (uint32_t)h->pinned[0] == 0;
     float ms = 0;
     (void)hipEventElapsedTime(&ms, h->ev_up0, h->ev_up1);
     h->stats.ms_upload = ms;
@@ -242,8 +265,6 @@ void shard_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint32_t*
     if (*r_end < *r_begin) *r_end = *r_begin;
     if (bases) *bases = cum[*r_end] - cum[*r_begin];
 }
-
-inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // exclusive scan of n items (u8 or u32) -> u32 offsets; *total_host gets the grand total
 // (a pinned slot: valid after the next hipStreamSynchronize)
@@ -279,6 +300,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     S.kmer = K;
     S.n_reads = n;
     S.total_bases = h->total_bases;
+    const uint32_t paired = (BITS == 2 && h->paired) ? 1u : 0u;
+    S.paired = paired;
 
     uint32_t r_begin = 0, r_end = n;
     S.shard_bases = h->total_bases;
@@ -306,7 +329,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     PO_TRY(ensure(h, h->d_table, (size_t)nslots * sizeof(po::Slot)));
     PO_TRY(ensure(h, h->d_slot_cnt, (size_t)nslots * 4));
     PO_TRY(ensure(h, h->d_slot_cur, (size_t)nslots * 4));
-    PO_TRY(ensure(h, h->d_slot_start, (size_t)nslots * 4));
+    PO_TRY(ensure(h, h->d_slot_start, ((size_t)nslots + 1) * 4));
     PO_TRY(ensure(h, h->d_read_slot, (size_t)n * 4));
     PO_TRY(ensure(h, h->d_chain, (size_t)n * 4));
     PO_TRY(ensure(h, h->d_chain_tmp, (size_t)n * 4));
@@ -314,7 +337,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     PO_TRY(ensure(h, h->d_bloom, bloom_bytes));
     PO_TRY(ensure(h, h->d_selfrep, (size_t)n * 4));
     PO_TRY(ensure(h, h->d_tile_count, ((size_t)h->n_tiles + 1) * 4));
-    PO_TRY(ensure(h, h->d_tile_off, ((size_t)h->n_tiles + 1) * 4));
+    PO_TRY(ensure(h, h->d_tile_off, ((size_t)h->n_tiles + 2) * 4));
+    PO_TRY(ensure(h, h->d_truemask, ((size_t)h->n_tiles + 1) * po::WAVE * 4));
 
     const uint64_t* words = h->d_words.as<uint64_t>();
     const uint64_t* woff = h->d_woff.as<uint64_t>();
@@ -347,9 +371,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                        h->d_long_list.as<uint32_t>(), n_long, chain, h->d_chain_tmp.as<uint32_t>());
     if (nshards > 1) {
         const uint32_t blocks = std::min<uint32_t>(cdiv((uint64_t)h->n_tiles * 64, 256), (uint32_t)h->n_cu * 8);
-        hipLaunchKernelGGL(po::k_selfrep<BITS>, dim3(blocks), dim3(256), 0, st, words, woff, len,
-                           h->d_tile_read.as<uint32_t>(), h->d_tile_word0.as<uint32_t>(), h->n_tiles, tile_begin,
-                           tile_end, m, kmask, selfrep);
+        hipLaunchKernelGGL(po::k_selfrep<BITS>, dim3(blocks), dim3(256), 0, st, words, h->d_tiles.as<po::TileRec>(),
+                           h->n_tiles, tile_begin, tile_end, m, kmask, selfrep);
     }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev[EV_INDEX], st));
@@ -357,10 +380,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     // ---- scan, counting pass
     po::ScanArgs A = {};
     A.words = words;
-    A.woff = woff;
-    A.len = len;
-    A.tile_read = h->d_tile_read.as<uint32_t>();
-    A.tile_word0 = h->d_tile_word0.as<uint32_t>();
+    A.tiles = h->d_tiles.as<po::TileRec>();
     A.tile_begin = tile_begin;
     A.tile_end = tile_end;
     A.m = m;
@@ -373,15 +393,15 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     A.selfrep = selfrep;
     A.tile_count = h->d_tile_count.as<uint32_t>();
     A.tile_off = h->d_tile_off.as<uint32_t>();
+    A.truemask = h->d_truemask.as<uint32_t>();
     const uint32_t scan_waves = po::SCAN_BLOCK / 64;
     const uint32_t scan_grid = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)h->n_cu, cdiv(ntiles, scan_waves)));
-    const size_t scan_lds = (size_t)scan_waves * 64 * 12 + bloom_bytes;
+    const size_t scan_lds = bloom_bytes;
     if (scan_lds > h->lds_max) return fail(h, PO_ERR_HIP, "device LDS too small for the scan kernel");
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan<BITS, po::SCAN_COUNT>),
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan_filter<BITS>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan<BITS, po::SCAN_FILL>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
-    hipLaunchKernelGGL((po::k_scan<BITS, po::SCAN_COUNT>), dim3(scan_grid), dim3(po::SCAN_BLOCK), scan_lds, st, A);
+    hipLaunchKernelGGL((po::k_scan_filter<BITS>), dim3(scan_grid), dim3(po::SCAN_BLOCK), scan_lds, st, A);
+    hipLaunchKernelGGL((po::k_scan_count<BITS>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, A);
     HIP_TRY(h, hipGetLastError());
     PO_TRY(prefix_sum<uint32_t>(h, A.tile_count + tile_begin, ntiles, h->d_tile_off.as<uint32_t>() + tile_begin, &h->pinned[1]));
     HIP_TRY(h, hipEventRecord(h->ev[EV_COUNT], st));
@@ -399,23 +419,29 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         PO_TRY(ensure(h, h->d_cand_b, (size_t)n_cand * 4));
         PO_TRY(ensure(h, h->d_type, (size_t)n_cand));
         PO_TRY(ensure(h, h->d_rowcnt, (size_t)n_cand));
-        PO_TRY(ensure(h, h->d_row_off, (size_t)n_cand * 4));
+        PO_TRY(ensure(h, h->d_row_off, ((size_t)n_cand + 1) * 4));
         A.cand_a = h->d_cand_a.as<uint32_t>();
         A.cand_p = h->d_cand_p.as<uint32_t>();
         A.cand_b = h->d_cand_b.as<uint32_t>();
         // ---- scan, fill pass
-        hipLaunchKernelGGL((po::k_scan<BITS, po::SCAN_FILL>), dim3(scan_grid), dim3(po::SCAN_BLOCK), scan_lds, st, A);
+        hipLaunchKernelGGL((po::k_scan_fill<BITS>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, A);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(h->ev[EV_FILL], st));
         // ---- verify
-        hipLaunchKernelGGL(po::k_verify<BITS>, dim3(cdiv((uint64_t)n_cand * po::VER_GROUP, 256)), dim3(256), 0, st, words,
-                           woff, len, A.cand_a, A.cand_p, A.cand_b, n_cand, h->d_type.as<uint8_t>());
+        {
+            // a's words live in LDS (read length + 3 guard words); reads too long for 64 KB use the global path
+            const uint64_t need_words = ((uint64_t)h->max_len + W - 1) / W + 3;
+            const uint32_t lds_words = (uint32_t)std::min<uint64_t>(need_words, 8192);
+            hipLaunchKernelGGL(po::k_verify_a<BITS>, dim3(r_end - r_begin), dim3(po::VER_BLOCK), (size_t)lds_words * 8, st,
+                               words, woff, len, h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_p,
+                               A.cand_b, r_begin, lds_words, paired, h->d_type.as<uint8_t>());
+        }
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
         // ---- select + row offsets
         hipLaunchKernelGGL(po::k_select, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_b,
                            h->d_type.as<uint8_t>(), n_cand, selfrep, h->d_read_tile0.as<uint32_t>(),
-                           h->d_tile_off.as<uint32_t>(), h->d_rowcnt.as<uint8_t>());
+                           h->d_tile_off.as<uint32_t>(), paired, h->d_rowcnt.as<uint8_t>());
         HIP_TRY(h, hipGetLastError());
         PO_TRY(prefix_sum<uint8_t>(h, h->d_rowcnt.as<uint8_t>(), n_cand, h->d_row_off.as<uint32_t>(), &h->pinned[2]));
         HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
@@ -431,8 +457,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         }
         PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_rows64 * sizeof(po_row), 256)));
         hipLaunchKernelGGL(po::k_emit, dim3(std::min<uint32_t>(cdiv(n_cand, 256), (uint32_t)h->n_cu * 16)), dim3(256), 0, st, A.cand_a, A.cand_p, A.cand_b,
-                           h->d_type.as<uint8_t>(), h->d_rowcnt.as<uint8_t>(), h->d_row_off.as<uint32_t>(), n_cand, len,
-                           res->d_rows.as<po::Row>(), (uint32_t)BITS, scalars + 4);
+                           h->d_type.as<uint8_t>(), h->d_row_off.as<uint32_t>(), n_cand, len,
+                           res->d_rows.as<po::Row>(), (uint32_t)BITS, paired, scalars + 4);
         HIP_TRY(h, hipGetLastError());
     } else {
         HIP_TRY(h, hipEventRecord(h->ev[EV_FILL], st));
@@ -477,7 +503,7 @@ void po_destroy(po_handle* h) {
     if (h->dev_ready) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
-        DevBuf* bufs[] = {&h->d_words, &h->d_woff, &h->d_len, &h->d_tile_read, &h->d_tile_word0, &h->d_read_tile0,
+        DevBuf* bufs[] = {&h->d_words, &h->d_woff, &h->d_len, &h->d_tiles, &h->d_read_tile0, &h->d_truemask,
                           &h->d_table, &h->d_slot_cnt, &h->d_slot_cur, &h->d_slot_start, &h->d_read_slot, &h->d_chain,
                           &h->d_chain_tmp, &h->d_long_list, &h->d_bloom, &h->d_selfrep, &h->d_tile_count, &h->d_tile_off,
                           &h->d_ps_blocks, &h->d_scalars, &h->d_cand_a, &h->d_cand_p, &h->d_cand_b, &h->d_type,

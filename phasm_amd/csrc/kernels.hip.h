@@ -37,6 +37,17 @@ struct Row {
     int32_t astart, aend, bstart, bend;
 };
 
+// One scan tile = TILE_WORDS consecutive words of one read.  32 bytes, built at upload, read with
+// scalar loads (the tile index is wave-uniform) so a tile's whole geometry costs one round trip.
+struct __attribute__((aligned(32))) TileRec {
+    uint64_t wabs;    // index into words[] of the tile's first word
+    uint64_t wread;   // index into words[] of the read's first word
+    uint32_t read;    // read index
+    uint32_t la;      // read length in bases
+    uint32_t word0;   // tile's first word relative to the read
+    uint32_t pad;
+};
+
 // ----------------------------------------------------------------------------------------
 // small helpers
 // ----------------------------------------------------------------------------------------
@@ -47,15 +58,26 @@ __host__ __device__ inline void kmer_hash(uint64_t k, uint32_t& h1, uint32_t& h2
     h2 = (x ^ (x >> 15) ^ (hi * 5u)) * 0x85EBCA77u;
 }
 
+// Blocked Bloom filter, 32-bit blocks, 3 bits per key, one multiply and ONE LDS read per probe.
+__host__ __device__ inline void bloom_slot(uint64_t k, uint32_t bloom_log2, uint32_t& word, uint32_t& mask) {
+    uint32_t h1, h2;
+    kmer_hash(k, h1, h2);
+    (void)h2;
+    word = h1 >> (32 - (bloom_log2 - 5));
+    mask = (1u << ((h1 >> 7) & 31)) | (1u << ((h1 >> 12) & 31)) | (1u << ((h1 >> 2) & 31));
+}
+
 __device__ inline uint32_t lane_id() { return threadIdx.x & (WAVE - 1); }
 
+// Wave64 inclusive prefix sum in 6 DPP adds (gfx9 row_shr within rows of 16, then row_bcast:15 /
+// row_bcast:31 to carry across rows): no LDS, no ds_bpermute round trips.
 __device__ inline uint32_t wave_incl_scan(uint32_t v) {
-    const uint32_t lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, WAVE);
-        if (lane >= (uint32_t)d) v += t;
-    }
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
     return v;
 }
 
@@ -160,9 +182,9 @@ __global__ void k_table_insert(const uint64_t* __restrict__ words, const uint64_
     }
     atomicAdd(&slot_cnt[i], 1u);
     read_slot[r] = i;
-    const uint32_t i1 = h1 >> (32 - bloom_log2), i2 = h2 >> (32 - bloom_log2);
-    atomicOr(&bloom[i1 >> 5], 1u << (i1 & 31));
-    atomicOr(&bloom[i2 >> 5], 1u << (i2 & 31));
+    uint32_t bword, bmask;
+    bloom_slot(key, bloom_log2, bword, bmask);
+    atomicOr(&bloom[bword], bmask);
 }
 
 __global__ void k_table_finalize(Slot* tab, uint32_t nslots, const uint32_t* __restrict__ slot_cnt,
@@ -234,220 +256,339 @@ __global__ void k_chain_sort_long(const uint32_t* __restrict__ slot_cnt, const u
 // ----------------------------------------------------------------------------------------
 struct ScanArgs {
     const uint64_t* words;
-    const uint64_t* woff;
-    const uint32_t* len;
-    const uint32_t* tile_read;
-    const uint32_t* tile_word0;
+    const TileRec* tiles;
     uint32_t tile_begin, tile_end;
     uint32_t m;       // effective min_length (>= 1)
     uint64_t kmask;   // low K*BITS bits
     const uint32_t* bloom;
-    uint32_t bloom_log2;
+    uint32_t bloom_log2;   // filter bits = 1 << bloom_log2 (32-bit blocks)
     const Slot* table;
     uint32_t tbits;
     const uint32_t* chain;
     uint32_t* selfrep;     // COUNT: min p>0 at which a read's own prefix K-mer recurs
-    uint32_t* tile_count;  // COUNT out
+    uint32_t* tile_count;  // COUNT out: candidates per tile
+    uint32_t* truemask;    // COUNT out / FILL in: per (tile, lane) bit s set = position p0+s has candidates
     const uint32_t* tile_off;  // FILL in
     uint32_t* cand_a;
     uint32_t* cand_p;
     uint32_t* cand_b;
 };
 
-enum { SCAN_COUNT = 0, SCAN_FILL = 1 };
+template <int BITS>
+__device__ inline uint64_t window(uint64_t w0, uint64_t w1, int s) {
+    return s == 0 ? w0 : ((w0 >> (s * BITS)) | (w1 << ((64 - s * BITS) & 63)));
+}
 
-// Persistent workgroups (grid <= #CUs), 16 waves each; the Bloom filter lives in LDS for the whole
-// launch.  One wave per tile = 64 consecutive words of one read = 64*W positions.  Lane l owns word
-// l (+ the next one for windows that straddle) and tests its W positions against the filter; the
-// survivors of the whole wave are compacted through a wave-private LDS queue so that the L2 table
-// probes run with all lanes busy, in ascending p.
-template <int BITS, int MODE>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan(const ScanArgs A) {
+// Scan stage 1 (filter).  Persistent workgroups (grid <= #CUs), 16 waves each; the Bloom filter
+// lives in LDS for the whole launch.  One wave per tile = 64 words = 64*W positions; lane l owns
+// word l (+ the next one for windows that straddle) and tests its W positions against the filter.
+// Pure streaming: the next tile's record and words are fetched while the current tile computes.
+// Out: per (tile, lane) the mask of positions that pass the filter.
+template <int BITS>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_filter(const ScanArgs A) {
     constexpr int W = 64 / BITS;
-    extern __shared__ uint64_t smem[];
+    extern __shared__ uint32_t s_bloom[];
     const uint32_t nwaves = blockDim.x >> 6;
-    uint64_t* q_kmer = smem;                                            // nwaves * 64 * 8 B
-    uint32_t* q_p = reinterpret_cast<uint32_t*>(smem + nwaves * WAVE);  // nwaves * 64 * 4 B
-    uint32_t* s_bloom = q_p + nwaves * WAVE;
     const uint32_t bloom_words = (1u << A.bloom_log2) >> 5;
     for (uint32_t i = threadIdx.x; i < bloom_words; i += blockDim.x) s_bloom[i] = A.bloom[i];
     __syncthreads();
 
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t wshift = 32 - (A.bloom_log2 - 5);
+    const uint32_t stride = gridDim.x * nwaves;
+
+    uint32_t t = __builtin_amdgcn_readfirstlane(A.tile_begin + blockIdx.x * nwaves + wave);
+    TileRec rec = {};
+    uint64_t w0 = 0, w1 = 0;
+    if (t < A.tile_end) {
+        rec = A.tiles[t];
+        if (rec.la >= A.m && (rec.word0 + lane) * W <= rec.la - A.m) {
+            w0 = A.words[rec.wabs + lane];
+            w1 = A.words[rec.wabs + lane + 1];  // guard word after every read keeps this in bounds
+        }
+    }
+    while (t < A.tile_end) {
+        const uint32_t tn = t + stride;
+        TileRec nrec = {};
+        uint64_t nw0 = 0, nw1 = 0;
+        if (tn < A.tile_end) {
+            nrec = A.tiles[tn];
+            if (nrec.la >= A.m && (nrec.word0 + lane) * W <= nrec.la - A.m) {
+                nw0 = A.words[nrec.wabs + lane];
+                nw1 = A.words[nrec.wabs + lane + 1];
+            }
+        }
+        uint32_t hitmask = 0;
+        const uint32_t p0 = (rec.word0 + lane) * W;
+        if (rec.la >= A.m && p0 <= rec.la - A.m) {
+            const uint32_t pmax = rec.la - A.m;  // last position whose suffix/containment can reach min_length
+#pragma unroll
+            for (int s = 0; s < W; ++s) {
+                const uint64_t kmer = window<BITS>(w0, w1, s) & A.kmask;
+                const uint32_t lo = (uint32_t)kmer, hi = (uint32_t)(kmer >> 32);
+                const uint32_t h1 = (lo ^ ((hi << 13) | (hi >> 19))) * 0x9E3779B1u;
+                const uint32_t mask = (1u << ((h1 >> 7) & 31)) | (1u << ((h1 >> 12) & 31)) | (1u << ((h1 >> 2) & 31));
+                const uint32_t bw = s_bloom[h1 >> wshift];
+                hitmask |= ((bw & mask) == mask ? 1u : 0u) << s;
+            }
+            const uint32_t nvalid = pmax - p0 + 1;
+            if (nvalid < (uint32_t)W) hitmask &= (1u << nvalid) - 1u;
+        }
+        A.truemask[(size_t)t * WAVE + lane] = hitmask;
+        t = tn;
+        rec = nrec;
+        w0 = nw0;
+        w1 = nw1;
+    }
+}
+
+// Scan stage 2 (count).  One wave per tile, ordinary grid, high occupancy: the filter survivors of
+// the whole wave are compacted through a wave-private LDS queue so the L2 table probes run with all
+// lanes busy.  Rewrites the (tile, lane) mask in place so that only positions that really have
+// candidates stay set, counts the tile's candidates, and records self-repeats of a's own prefix.
+template <int BITS>
+__global__ __launch_bounds__(256) void k_scan_count(const ScanArgs A) {
+    constexpr int W = 64 / BITS;
+    __shared__ uint64_t q_kmer[4 * WAVE];
+    __shared__ uint32_t q_p[4 * WAVE];
+    __shared__ uint32_t q_tm[4 * WAVE];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     uint64_t* qk = q_kmer + wave * WAVE;
     uint32_t* qp = q_p + wave * WAVE;
-    const uint32_t bshift = 32 - A.bloom_log2;
-
-    for (uint32_t t = A.tile_begin + blockIdx.x * nwaves + wave; t < A.tile_end; t += gridDim.x * nwaves) {
-        const uint32_t a = A.tile_read[t];
-        const uint32_t la = A.len[a];
-        uint32_t tile_total = 0;
-        if (la >= A.m) {  // wave-uniform
-            const uint64_t* __restrict__ rw = A.words + A.woff[a];
-            const uint32_t nw = (la + W - 1) / W;
-            const uint32_t pmax = la - A.m;  // last position whose suffix/containment can reach min_length
-            const uint32_t wi = A.tile_word0[t] + lane;
-            const uint32_t p0 = wi * W;
-            const uint64_t key_a = rw[0] & A.kmask;
-            uint32_t hitmask = 0;
-            uint64_t w0 = 0, w1 = 0;
-            if (wi < nw && p0 <= pmax) {
-                w0 = rw[wi];
-                w1 = rw[wi + 1];  // guard word after every read keeps this in bounds
-#pragma unroll
-                for (int s = 0; s < W; ++s) {
-                    const uint64_t kmer = (s == 0 ? w0 : ((w0 >> (s * BITS)) | (w1 << ((64 - s * BITS) & 63)))) & A.kmask;
-                    uint32_t h1, h2;
-                    kmer_hash(kmer, h1, h2);
-                    const uint32_t i1 = h1 >> bshift, i2 = h2 >> bshift;
-                    const uint32_t b1 = s_bloom[i1 >> 5] >> (i1 & 31);
-                    const uint32_t b2 = s_bloom[i2 >> 5] >> (i2 & 31);
-                    hitmask |= (b1 & b2 & 1u) << s;
-                }
-                const uint32_t nvalid = pmax - p0 + 1;
-                if (nvalid < (uint32_t)W) hitmask &= (1u << nvalid) - 1u;
-            }
-            const uint32_t nh = __popc(hitmask);
-            const uint32_t incl = wave_incl_scan(nh);
-            const uint32_t total = read_last_lane(incl);
-            uint32_t rank = incl - nh;
-            uint32_t base = 0;
-            if (MODE == SCAN_FILL) base = A.tile_off[t];
-            for (uint32_t r0 = 0; r0 < total; r0 += WAVE) {
-                while (hitmask && rank < r0 + WAVE) {
-                    const uint32_t s = __ffs(hitmask) - 1;
-                    hitmask &= hitmask - 1;
-                    qk[rank - r0] = funnel(w0, w1, s * BITS) & A.kmask;
-                    qp[rank - r0] = p0 + s;
-                    ++rank;
-                }
-                wave_lds_fence();
-                const bool has = r0 + lane < total;
-                const uint64_t kmer = qk[lane];
-                const uint32_t p = qp[lane];
-                wave_lds_fence();
-                uint32_t start = 0, cnt = 0;
-                if (has) table_probe(A.table, A.tbits, kmer, start, cnt);
-                const bool self = cnt != 0 && kmer == key_a;  // a's own chain entry is not a candidate
-                const uint32_t ceff = cnt - (self ? 1u : 0u);
-                if (MODE == SCAN_COUNT) {
-                    if (self && p > 0) atomicMin(&A.selfrep[a], p);
-                    tile_total += ceff;
-                } else {
-                    const uint32_t inc = wave_incl_scan(ceff);
-                    uint32_t off = base + inc - ceff;
-                    for (uint32_t j = 0; j < cnt; ++j) {
-                        const uint32_t b = A.chain[start + j];
-                        if (b != a) {
-                            A.cand_a[off] = a;
-                            A.cand_p[off] = p;
-                            A.cand_b[off] = b;
-                            ++off;
-                        }
-                    }
-                    base += read_last_lane(inc);
-                }
-            }
-            if (MODE == SCAN_COUNT) tile_total = wave_sum(tile_total);
+    uint32_t* tm = q_tm + wave * WAVE;
+    const uint32_t t = __builtin_amdgcn_readfirstlane(A.tile_begin + blockIdx.x * 4 + wave);
+    if (t >= A.tile_end) return;
+    uint32_t hitmask = A.truemask[(size_t)t * WAVE + lane];
+    const uint32_t nh = __popc(hitmask);
+    const uint32_t incl = wave_incl_scan(nh);
+    const uint32_t total = read_last_lane(incl);
+    if (total == 0) {
+        if (lane == 0) A.tile_count[t] = 0;
+        return;
+    }
+    const TileRec rec = A.tiles[t];
+    uint64_t w0 = 0, w1 = 0;
+    if (hitmask) {
+        w0 = A.words[rec.wabs + lane];
+        w1 = A.words[rec.wabs + lane + 1];
+    }
+    const uint32_t a = rec.read;
+    const uint64_t key_a = A.words[rec.wread] & A.kmask;
+    uint32_t rank = incl - nh;
+    uint32_t tile_total = 0;
+    tm[lane] = 0;
+    for (uint32_t r0 = 0; r0 < total; r0 += WAVE) {
+        while (hitmask && rank < r0 + WAVE) {
+            const uint32_t s = __ffs(hitmask) - 1;
+            hitmask &= hitmask - 1;
+            qk[rank - r0] = funnel(w0, w1, s * BITS) & A.kmask;
+            qp[rank - r0] = (lane << 8) | s;
+            ++rank;
         }
-        if (MODE == SCAN_COUNT && lane == 0) A.tile_count[t] = tile_total;
+        wave_lds_fence();
+        const bool has = r0 + lane < total;
+        const uint64_t kmer = qk[lane];
+        const uint32_t src = qp[lane];
+        uint32_t start = 0, cnt = 0;
+        if (has) table_probe(A.table, A.tbits, kmer, start, cnt);
+        const bool self = cnt != 0 && kmer == key_a;  // a's own chain entry is not a candidate
+        const uint32_t ceff = cnt - (self ? 1u : 0u);
+        if (self) {
+            const uint32_t p = (rec.word0 + (src >> 8)) * W + (src & 255u);
+            if (p > 0) atomicMin(&A.selfrep[a], p);
+        }
+        if (ceff) atomicOr(&tm[src >> 8], 1u << (src & 255u));
+        tile_total += ceff;
+        wave_lds_fence();
+    }
+    A.truemask[(size_t)t * WAVE + lane] = tm[lane];
+    tile_total = wave_sum(tile_total);
+    if (lane == 0) A.tile_count[t] = tile_total;
+}
+
+// FILL pass: one wave per tile, ordinary grid.  Positions with candidates come from truemask; each
+// is probed again (L2-resident table) for its chain and the (a, p, b) triples are written at
+// tile_off[t] in ascending p, chain order (ascending b).
+template <int BITS>
+__global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
+    constexpr int W = 64 / BITS;
+    __shared__ uint64_t q_kmer[4 * WAVE];
+    __shared__ uint32_t q_p[4 * WAVE];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    uint64_t* qk = q_kmer + wave * WAVE;
+    uint32_t* qp = q_p + wave * WAVE;
+    const uint32_t t = __builtin_amdgcn_readfirstlane(A.tile_begin + blockIdx.x * 4 + wave);
+    if (t >= A.tile_end) return;
+    uint32_t hitmask = A.truemask[(size_t)t * WAVE + lane];
+    const uint32_t nh = __popc(hitmask);
+    const uint32_t incl = wave_incl_scan(nh);
+    const uint32_t total = read_last_lane(incl);
+    if (total == 0) return;
+    const TileRec rec = A.tiles[t];
+    uint64_t w0 = 0, w1 = 0;
+    if (hitmask) {
+        w0 = A.words[rec.wabs + lane];
+        w1 = A.words[rec.wabs + lane + 1];
+    }
+    const uint32_t a = rec.read;
+    const uint32_t p0 = (rec.word0 + lane) * W;
+    uint32_t rank = incl - nh;
+    uint32_t base = A.tile_off[t];
+    for (uint32_t r0 = 0; r0 < total; r0 += WAVE) {
+        while (hitmask && rank < r0 + WAVE) {
+            const uint32_t s = __ffs(hitmask) - 1;
+            hitmask &= hitmask - 1;
+            qk[rank - r0] = funnel(w0, w1, s * BITS) & A.kmask;
+            qp[rank - r0] = p0 + s;
+            ++rank;
+        }
+        wave_lds_fence();
+        const bool has = r0 + lane < total;
+        const uint64_t kmer = qk[lane];
+        const uint32_t p = qp[lane];
+        wave_lds_fence();
+        uint32_t start = 0, cnt = 0;
+        if (has) table_probe(A.table, A.tbits, kmer, start, cnt);
+        uint32_t ceff = 0;
+        for (uint32_t j = 0; j < cnt; ++j) ceff += A.chain[start + j] != a;
+        const uint32_t inc = wave_incl_scan(ceff);
+        uint32_t off = base + inc - ceff;
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint32_t b = A.chain[start + j];
+            if (b != a) {
+                A.cand_a[off] = a;
+                A.cand_p[off] = p;
+                A.cand_b[off] = b;
+                ++off;
+            }
+        }
+        base += read_last_lane(inc);
     }
 }
 
 // selfrep for reads OUTSIDE the a-side shard of this call (multi-GPU / sharded calls): the COUNT
 // pass only visits the shard's reads, but the select step needs selfrep[b] for every b.
 template <int BITS>
-__global__ __launch_bounds__(256) void k_selfrep(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
-                                                 const uint32_t* __restrict__ len, const uint32_t* __restrict__ tile_read,
-                                                 const uint32_t* __restrict__ tile_word0, uint32_t n_tiles,
-                                                 uint32_t skip_begin, uint32_t skip_end, uint32_t m,
+__global__ __launch_bounds__(256) void k_selfrep(const uint64_t* __restrict__ words, const TileRec* __restrict__ tiles,
+                                                 uint32_t n_tiles, uint32_t skip_begin, uint32_t skip_end, uint32_t m,
                                                  uint64_t kmask, uint32_t* selfrep) {
     constexpr int W = 64 / BITS;
     const uint32_t lane = lane_id();
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < n_tiles; t += nwaves) {
         if (t >= skip_begin && t < skip_end) continue;
-        const uint32_t a = tile_read[t];
-        const uint32_t la = len[a];
+        const TileRec rec = tiles[t];
+        const uint32_t la = rec.la;
         if (la < m) continue;
-        const uint64_t* __restrict__ rw = words + woff[a];
-        const uint32_t nw = (la + W - 1) / W, pmax = la - m;
-        const uint32_t wi = tile_word0[t] + lane, p0 = wi * W;
-        const uint64_t key_a = rw[0] & kmask;
+        const uint32_t pmax = la - m;
+        const uint32_t p0 = (rec.word0 + lane) * W;
         uint32_t best = NO_SELFREP;
-        if (wi < nw && p0 <= pmax) {
-            const uint64_t w0 = rw[wi], w1 = rw[wi + 1];
+        if (p0 <= pmax) {
+            const uint64_t key_a = words[rec.wread] & kmask;
+            const uint64_t w0 = words[rec.wabs + lane], w1 = words[rec.wabs + lane + 1];
 #pragma unroll
             for (int s = W - 1; s >= 0; --s) {
-                const uint64_t kmer = (s == 0 ? w0 : ((w0 >> (s * BITS)) | (w1 << ((64 - s * BITS) & 63)))) & kmask;
+                const uint64_t kmer = window<BITS>(w0, w1, s) & kmask;
                 const uint32_t p = p0 + s;
                 if (kmer == key_a && p > 0 && p <= pmax) best = p;
             }
         }
-        if (best != NO_SELFREP) atomicMin(&selfrep[a], best);
+        if (best != NO_SELFREP) atomicMin(&selfrep[rec.read], best);
     }
 }
 
 // ----------------------------------------------------------------------------------------
-// verify: packed exact compare of a[p : p+n) against b[0 : n)
+// verify: packed exact compare of a[p : p+n) against b[0 : n), n = min(la-p, lb)
 // ----------------------------------------------------------------------------------------
-// 16 lanes per candidate, one 64-bit word of b per lane per step (the matching window of a is
-// funnel-shifted out of two words).  type: bit0 = suffix-prefix (A) candidate holds, bit1 = b is
-// wholly contained at p (B).  0 = mismatch.
+// One workgroup per a-side read: a's packed words are staged in LDS once and every candidate of a
+// streams only its b side from global memory, 16 bytes per lane per step (global_load_dwordx4).
+// 16 lanes form a group that walks one candidate in 256-byte steps (1024 bases at 2 bit); the four
+// groups of a wave advance independently through a flattened loop, so a finished or mismatching
+// candidate hands its lanes to the group's next candidate at once.  The window of a that faces b is
+// funnel-shifted out of three LDS words.
+// type: bit0 = suffix-prefix (A) candidate holds, bit1 = b wholly contained at p (B); 0 = mismatch.
 constexpr int VER_GROUP = 16;
+constexpr int VER_BLOCK = 256;
 
 template <int BITS>
-__global__ __launch_bounds__(256) void k_verify(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
-                                                const uint32_t* __restrict__ len, const uint32_t* __restrict__ cand_a,
-                                                const uint32_t* __restrict__ cand_p, const uint32_t* __restrict__ cand_b,
-                                                uint32_t n_cand, uint8_t* __restrict__ type) {
+__global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
+                                                         const uint32_t* __restrict__ len,
+                                                         const uint32_t* __restrict__ read_tile0,
+                                                         const uint32_t* __restrict__ tile_off,
+                                                         const uint32_t* __restrict__ cand_p,
+                                                         const uint32_t* __restrict__ cand_b, uint32_t r_begin,
+                                                         uint32_t lds_words, uint32_t paired,
+                                                         uint8_t* __restrict__ type) {
     constexpr int W = 64 / BITS;
-    const uint32_t gid = (blockIdx.x * blockDim.x + threadIdx.x) / VER_GROUP;
+    extern __shared__ uint64_t s_a[];
+    const uint32_t a = r_begin + blockIdx.x;
+    const uint32_t seg0 = tile_off[read_tile0[a]], seg1 = tile_off[read_tile0[a + 1]];
+    if (seg0 == seg1) return;
+    const uint32_t la = len[a];
+    const uint32_t nwa = (la + W - 1) / W;
+    const uint64_t* __restrict__ ga = words + woff[a];
+    const bool in_lds = nwa + 3 <= lds_words;  // workgroup-uniform
+    if (in_lds) {
+        for (uint32_t i = threadIdx.x; i < nwa + 3; i += VER_BLOCK) s_a[i] = ga[i];
+        __syncthreads();
+    }
     const uint32_t sub = threadIdx.x & (VER_GROUP - 1);
     const uint32_t gshift = (lane_id() / VER_GROUP) * VER_GROUP;
-    bool live = gid < n_cand;
-    uint32_t n = 0, nwords = 0, sh = 0, rem = 0, lb = 0;
-    const uint64_t* A = words;
+    constexpr uint32_t NGROUPS = VER_BLOCK / VER_GROUP;
+
+    uint32_t c = seg0 + threadIdx.x / VER_GROUP;
+    bool have = c < seg1;
+    uint32_t n = 0, nwords = 0, sh = 0, q = 0, w = 0, keep = 0;
     const uint64_t* B = words;
-    if (live) {
-        const uint32_t a = cand_a[gid], p = cand_p[gid], b = cand_b[gid];
-        rem = len[a] - p;
-        lb = len[b];
+    auto init = [&]() {
+        const uint32_t p = cand_p[c], b = cand_b[c];
+        const uint32_t rem = la - p, lb = len[b];
+        // which rows this candidate can give: A (suffix of a = prefix of b) / B (b inside a).
+        // Paired-strand mode: only the canonical member of each strand-mirror pair is verified
+        // (A: a <= flip(b);  B: a on the + strand); k_emit writes the mirrored row too.
+        keep = ((rem <= lb && (!paired || a <= (b ^ 1u))) ? 1u : 0u) |
+               ((rem >= lb && (!paired || (a & 1u) == 0u)) ? 2u : 0u);
+        if (b == a) keep = 0;  // a read never overlaps itself (overlapper.cpp:72)
         n = rem < lb ? rem : lb;
-        nwords = (n + W - 1) / W;
+        nwords = keep ? (n + W - 1) / W : 0;
         const uint64_t bitpos = (uint64_t)p * BITS;
-        A = words + woff[a] + (bitpos >> 6);
+        q = (uint32_t)(bitpos >> 6);
         sh = (uint32_t)(bitpos & 63);
         B = words + woff[b];
-    }
-    bool ok = true;
-    uint32_t c0 = 0;
-    bool active = live && c0 < nwords;
-    while (__any(active)) {
+        w = 2 * sub;  // this lane's first word of b in the current step
+    };
+    if (have) init();
+    while (__any(have)) {
         uint64_t diff = 0;
-        const uint32_t c = c0 + sub;
-        if (active && c < nwords) {
-            const uint64_t bw = B[c];
-            const uint64_t av = funnel(A[c], A[c + 1], sh);
-            const uint32_t valid = n - c * W;  // bases of this word inside the compared range
-            const uint64_t mask = valid >= (uint32_t)W ? ~0ull : ((1ull << (valid * BITS)) - 1ull);
-            diff = (av ^ bw) & mask;
+        if (have && w < nwords) {
+            const uint4 bv = *reinterpret_cast<const uint4*>(B + w);  // b starts 16-byte aligned
+            const uint64_t b0 = ((uint64_t)bv.y << 32) | bv.x, b1 = ((uint64_t)bv.w << 32) | bv.z;
+            uint64_t a0, a1, a2;
+            if (in_lds) {
+                a0 = s_a[q + w];
+                a1 = s_a[q + w + 1];
+                a2 = s_a[q + w + 2];
+            } else {
+                a0 = ga[q + w];
+                a1 = ga[q + w + 1];
+                a2 = ga[q + w + 2];
+            }
+            const uint32_t v0 = n - w * W;  // bases of word w inside the compared range (>= 1)
+            const uint64_t m0 = v0 >= (uint32_t)W ? ~0ull : ((1ull << (v0 * BITS)) - 1ull);
+            const uint64_t m1 = v0 >= 2u * W ? ~0ull : (v0 > (uint32_t)W ? ((1ull << ((v0 - W) * BITS)) - 1ull) : 0ull);
+            diff = ((funnel(a0, a1, sh) ^ b0) & m0) | ((funnel(a1, a2, sh) ^ b1) & m1);
         }
         const uint64_t bal = __ballot(diff != 0);
-        if (active) {
-            if ((bal >> gshift) & ((1ull << VER_GROUP) - 1ull)) {
-                ok = false;
-                active = false;
-            } else {
-                c0 += VER_GROUP;
-                active = c0 < nwords;
+        if (have) {
+            const bool mismatch = ((bal >> gshift) & ((1ull << VER_GROUP) - 1ull)) != 0;
+            w += 2 * VER_GROUP;
+            if (mismatch || w - 2 * sub >= nwords) {  // group-uniform: candidate finished
+                if (sub == 0) type[c] = mismatch ? (uint8_t)0 : (uint8_t)keep;
+                c += NGROUPS;
+                have = c < seg1;
+                if (have) init();
             }
         }
-    }
-    if (live && sub == 0) {
-        uint8_t t = 0;
-        if (ok) t = (uint8_t)((rem <= lb ? 1u : 0u) | (rem >= lb ? 2u : 0u));
-        type[gid] = t;
     }
 }
 
@@ -459,56 +600,75 @@ __global__ __launch_bounds__(256) void k_verify(const uint64_t* __restrict__ wor
 // selfrep[b] set need the look-back.
 // ----------------------------------------------------------------------------------------
 __global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_b,
-                         const uint8_t* __restrict__ type, uint32_t n_cand, const uint32_t* __restrict__ selfrep,
+                         uint8_t* __restrict__ type, uint32_t n_cand, const uint32_t* __restrict__ selfrep,
                          const uint32_t* __restrict__ read_tile0, const uint32_t* __restrict__ tile_off,
-                         uint8_t* __restrict__ rowcnt) {
+                         uint32_t paired, uint8_t* __restrict__ rowcnt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_cand) return;
-    const uint32_t t = type[i];
-    uint32_t cnt = (t & 1u) + ((t >> 1) & 1u);
-    if (t & 1u) {
-        const uint32_t b = cand_b[i];
-        if (selfrep[b] != NO_SELFREP) {
-            const uint32_t seg0 = tile_off[read_tile0[cand_a[i]]];
-            for (uint32_t j = seg0; j < i; ++j) {
-                if (cand_b[j] == b && (type[j] & 1u)) {
-                    --cnt;
-                    break;
-                }
+    uint32_t t = type[i];
+    if (t == 0) {
+        rowcnt[i] = 0;
+        return;
+    }
+    const uint32_t a = cand_a[i], b = cand_b[i];
+    if ((t & 1u) && selfrep[b] != NO_SELFREP) {
+        // An earlier entry that itself lost its A bit still has a winner further back, and the
+        // winner (smallest p) never loses it: concurrent clearing cannot change the outcome.
+        const uint32_t seg0 = tile_off[read_tile0[a]];
+        for (uint32_t j = seg0; j < i; ++j) {
+            if (cand_b[j] == b && (type[j] & 1u)) {
+                t &= ~1u;
+                type[i] = (uint8_t)t;
+                break;
             }
         }
     }
+    // paired-strand mode: every row is written with its strand mirror, except the A row of
+    // (x+, x-) / (x-, x+), which is its own mirror
+    uint32_t cnt = (t & 1u) + ((t >> 1) & 1u);
+    if (paired) cnt = ((t & 1u) ? (a == (b ^ 1u) ? 1u : 2u) : 0u) + ((t & 2u) ? 2u : 0u);
     rowcnt[i] = (uint8_t)cnt;
 }
 
+// Rows of candidate i start at row_off[i]: A row, its mirror, B row, its mirror.  Mirrors
+// (exact when every read 2i+1 is the reverse complement of read 2i):
+//   A (a, b, la-l, la, 0, l)   <->  (b^1, a^1, lb-l, lb, 0, l)
+//   B (a, b, p, p+lb, 0, lb)   <->  (a^1, b^1, la-p-lb, la-p, 0, lb)
 __global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
                                               const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,
-                                              const uint8_t* __restrict__ rowcnt, const uint32_t* __restrict__ row_off,
-                                              uint32_t n_cand, const uint32_t* __restrict__ len, Row* __restrict__ rows,
-                                              uint32_t bits,
+                                              const uint32_t* __restrict__ row_off, uint32_t n_cand,
+                                              const uint32_t* __restrict__ len, Row* __restrict__ rows, uint32_t bits,
+                                              uint32_t paired,
                                               unsigned long long* __restrict__ counters /* [0]=verified [1]=sum l [2]=sum 2*ceil(l*bits/8) */) {
     __shared__ uint64_t s_red[3][256 / WAVE];
     uint64_t nver = 0, suml = 0, sumb = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cand; i += gridDim.x * blockDim.x) {
-        const uint32_t t = type[i], rc = rowcnt[i];
-        nver += t != 0;
-        if (rc) {
-            const uint32_t a = cand_a[i], p = cand_p[i], b = cand_b[i];
-            const uint32_t la = len[a], lb = len[b];
-            uint32_t off = row_off[i];
-            const bool emit_a = (t & 1u) && rc == (t & 1u) + ((t >> 1) & 1u);
-            if (emit_a) {
-                Row r = {a, b, (int32_t)p, (int32_t)la, 0, (int32_t)(la - p)};
-                rows[off++] = r;
-                suml += la - p;
-                sumb += 2ull * (((uint64_t)(la - p) * bits + 7) / 8);
+        const uint32_t t = type[i];
+        if (t == 0) continue;
+        nver += 1;
+        const uint32_t a = cand_a[i], p = cand_p[i], b = cand_b[i];
+        const uint32_t la = len[a], lb = len[b];
+        uint32_t off = row_off[i];
+        if (t & 1u) {
+            const uint32_t l = la - p;
+            uint32_t k = 1;
+            rows[off++] = Row{a, b, (int32_t)p, (int32_t)la, 0, (int32_t)l};
+            if (paired && a != (b ^ 1u)) {
+                rows[off++] = Row{b ^ 1u, a ^ 1u, (int32_t)(lb - l), (int32_t)lb, 0, (int32_t)l};
+                k = 2;
             }
-            if (t & 2u) {
-                Row r = {a, b, (int32_t)p, (int32_t)(p + lb), 0, (int32_t)lb};
-                rows[off] = r;
-                suml += lb;
-                sumb += 2ull * (((uint64_t)lb * bits + 7) / 8);
+            suml += (uint64_t)k * l;
+            sumb += (uint64_t)k * 2ull * (((uint64_t)l * bits + 7) / 8);
+        }
+        if (t & 2u) {
+            uint32_t k = 1;
+            rows[off++] = Row{a, b, (int32_t)p, (int32_t)(p + lb), 0, (int32_t)lb};
+            if (paired) {
+                rows[off++] = Row{a ^ 1u, b ^ 1u, (int32_t)(la - p - lb), (int32_t)(la - p), 0, (int32_t)lb};
+                k = 2;
             }
+            suml += (uint64_t)k * lb;
+            sumb += (uint64_t)k * 2ull * (((uint64_t)lb * bits + 7) / 8);
         }
     }
     nver = wave_sum64(nver);
@@ -525,6 +685,44 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ cand_
         for (int w = 0; w < 256 / WAVE; ++w) v += s_red[threadIdx.x][w];
         if (v) atomicAdd(&counters[threadIdx.x], (unsigned long long)v);
     }
+}
+
+// Paired-strand detection (2-bit reads only): is read 2i+1 exactly the reverse complement of read
+// 2i, for every i?  One wave per pair; lane l checks words l, l+64, ... of the odd read against the
+// matching window of the even read, reversed (bit reverse + swap the two bits of every base) and
+// complemented (~).  Any failure bumps *n_bad.
+__global__ __launch_bounds__(256) void k_paired_check(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
+                                                      const uint32_t* __restrict__ len, uint32_t n_pairs,
+                                                      uint32_t* __restrict__ n_bad) {
+    const uint32_t pair = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (pair >= n_pairs) return;
+    const uint32_t lane = lane_id();
+    const uint32_t L = len[2 * pair];
+    bool bad = false;
+    if (len[2 * pair + 1] != L) {
+        bad = true;
+    } else {
+        const uint64_t* __restrict__ R = words + woff[2 * pair];
+        const uint64_t* __restrict__ S = words + woff[2 * pair + 1];
+        const uint32_t nw = (L + 31) / 32;
+        for (uint32_t w = lane; w < nw && !bad; w += WAVE) {
+            const int64_t o = (int64_t)L - 32 * (int64_t)w - 32;  // first base of R facing this word
+            uint64_t x;
+            uint32_t valid = 32;
+            if (o >= 0) {
+                x = funnel(R[o >> 5], R[(o >> 5) + 1], (uint32_t)(o & 31) * 2);
+            } else {
+                valid = (uint32_t)(32 + o);
+                x = R[0] << ((uint32_t)(-o) * 2);
+            }
+            uint64_t y = __brevll(x);
+            y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+            y = ~y;
+            const uint64_t mask = valid >= 32 ? ~0ull : ((1ull << (valid * 2)) - 1ull);
+            bad = ((y ^ S[w]) & mask) != 0;
+        }
+    }
+    if (__any(bad) && lane == 0) atomicAdd(n_bad, 1u);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -606,6 +804,7 @@ __global__ __launch_bounds__(PS_BLOCK) void k_ps_down(const T* __restrict__ in, 
         const uint64_t i = base + k;
         if (i < n) out[i] = run;
         run += v[k];
+        if (i == n - 1) out[n] = run;  // closing sentinel: out has n+1 entries
     }
 }
 

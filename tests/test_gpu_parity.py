@@ -48,6 +48,37 @@ def test_ladder_goldens(name):
     got, st = hip_rows(seqs, m)
     assert np.array_equal(got, want)
     assert st["n_rows"] == len(want)
+    assert st["paired"] == 1  # both strands were added: the strand-mirror shortcut is active
+
+
+@pytest.mark.parametrize("name", ["ladder_varlen", "ladder_cfg2_mini"])
+def test_mirror_shortcut_off_gives_the_same_rows(name, monkeypatch):
+    _, seqs, m, want = gu.ladder_case(name)
+    monkeypatch.setenv("PHASM_NO_MIRROR", "1")
+    got, st = hip_rows(seqs, m)
+    assert st["paired"] == 0
+    assert np.array_equal(got, want)
+
+
+def test_pairing_is_detected_not_assumed():
+    """An even number of reads that are NOT strand pairs (one base off) must not be mirrored."""
+    _, seqs, m, _ = gu.ladder_case("ladder_small")
+    seqs = list(seqs)
+    s = bytearray(seqs[41])
+    s[7] = ord("A") if s[7] != ord("A") else ord("C")
+    seqs[41] = bytes(s)
+    got, st = hip_rows(seqs, m)
+    assert st["paired"] == 0
+    assert np.array_equal(got, oo.oracle_overlaps(seqs, m))
+    # odd lengths / odd tail words still pair up
+    rng = np.random.default_rng(8)
+    reads = []
+    for ln in (1, 2, 31, 32, 33, 63, 64, 65, 100, 257):
+        r = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=ln))
+        reads += [r, r.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1]]
+    got, st = hip_rows(reads, 1)
+    assert st["paired"] == 1
+    assert np.array_equal(got, oo.oracle_overlaps(reads, 1))
 
 
 @pytest.mark.parametrize("nshards", [2, 3, 8])
