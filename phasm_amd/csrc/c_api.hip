@@ -363,12 +363,13 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     hipLaunchKernelGGL(po::k_table_insert, dim3(cdiv(n, 256)), dim3(256), 0, st, words, woff, len, n, m, kmask, table,
                        tbits, slot_cnt, read_slot, bloom, bloom_log2);
     PO_TRY(prefix_sum<uint32_t>(h, slot_cnt, nslots, slot_start, &h->pinned[0]));
-    hipLaunchKernelGGL(po::k_table_finalize, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt, slot_start);
     hipLaunchKernelGGL(po::k_chain_fill, dim3(cdiv(n, 256)), dim3(256), 0, st, read_slot, n, slot_start, slot_cur, chain);
     hipLaunchKernelGGL(po::k_chain_sort_short, dim3(cdiv(nslots, 256)), dim3(256), 0, st, slot_cnt, slot_start, nslots,
                        chain, h->d_long_list.as<uint32_t>(), n_long);
     hipLaunchKernelGGL(po::k_chain_sort_long, dim3(64), dim3(256), 0, st, slot_cnt, slot_start,
                        h->d_long_list.as<uint32_t>(), n_long, chain, h->d_chain_tmp.as<uint32_t>());
+    hipLaunchKernelGGL(po::k_table_finalize, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt, slot_start,
+                       chain, len);
     if (nshards > 1) {
         const uint32_t blocks = std::min<uint32_t>(cdiv((uint64_t)h->n_tiles * 64, 256), (uint32_t)h->n_cu * 8);
         hipLaunchKernelGGL(po::k_selfrep<BITS>, dim3(blocks), dim3(256), 0, st, words, h->d_tiles.as<po::TileRec>(),
@@ -390,18 +391,19 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     A.table = table;
     A.tbits = tbits;
     A.chain = chain;
+    A.len = len;
+    A.paired = paired;
     A.selfrep = selfrep;
     A.tile_count = h->d_tile_count.as<uint32_t>();
     A.tile_off = h->d_tile_off.as<uint32_t>();
     A.truemask = h->d_truemask.as<uint32_t>();
     const uint32_t scan_waves = po::SCAN_BLOCK / 64;
     const uint32_t scan_grid = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)h->n_cu, cdiv(ntiles, scan_waves)));
-    const size_t scan_lds = bloom_bytes;
+    const size_t scan_lds = (size_t)scan_waves * po::SCAN_LDS_PER_WAVE + bloom_bytes;
     if (scan_lds > h->lds_max) return fail(h, PO_ERR_HIP, "device LDS too small for the scan kernel");
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan_filter<BITS>),
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan_probe<BITS>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
-    hipLaunchKernelGGL((po::k_scan_filter<BITS>), dim3(scan_grid), dim3(po::SCAN_BLOCK), scan_lds, st, A);
-    hipLaunchKernelGGL((po::k_scan_count<BITS>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, A);
+    hipLaunchKernelGGL((po::k_scan_probe<BITS>), dim3(scan_grid), dim3(po::SCAN_BLOCK), scan_lds, st, A);
     HIP_TRY(h, hipGetLastError());
     PO_TRY(prefix_sum<uint32_t>(h, A.tile_count + tile_begin, ntiles, h->d_tile_off.as<uint32_t>() + tile_begin, &h->pinned[1]));
     HIP_TRY(h, hipEventRecord(h->ev[EV_COUNT], st));

@@ -19,18 +19,23 @@
 
 namespace po {
 
+// native 4 x u32 vector (one dwordx4 load; stays in VGPRs, unlike HIP's struct-based uint4 when it is
+// carried across loop iterations)
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
 constexpr uint64_t KEY_EMPTY = ~0ull;          // slot-claim sentinel; a real all-ones K-mer lives
                                                // in the dedicated extra slot at index 1<<tbits
 constexpr uint32_t NO_SELFREP = 0xFFFFFFFFu;
 constexpr int WAVE = 64;
-constexpr int SCAN_BLOCK = 1024;               // 16 waves: one persistent workgroup per CU
+constexpr int SCAN_BLOCK = 768;                // 12 waves: one persistent workgroup per CU
 constexpr int TILE_WORDS = 64;                 // one 64-bit word per lane
 
 struct __attribute__((aligned(16))) Slot {
     uint64_t key;
-    uint32_t start;   // first entry in chain[]
-    uint32_t count;   // 0 = empty slot
+    uint32_t start;   // first entry in chain[]  -- or, for a one-read chain, the read itself
+    uint32_t count;   // 0 = empty slot; bit 31 set = one-read chain, low 31 bits = that read's length
 };
+constexpr uint32_t SLOT_SINGLE = 0x80000000u;
 
 struct Row {
     uint32_t a_idx, b_idx;
@@ -106,13 +111,23 @@ __device__ inline uint64_t funnel(uint64_t lo, uint64_t hi, uint32_t sh) {
     return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
 }
 
+// Which rows can candidate (a, p, b) give, and is it the member of its strand-mirror pair that this
+// library computes?  bit0: A (suffix of a = prefix of b; needs la-p <= lb), bit1: B (b inside a;
+// needs la-p >= lb).  Paired mode keeps A only for a <= flip(b) and B only for a on the + strand;
+// k_emit writes the mirrored rows.  A read never pairs with itself (overlapper.cpp:72,:103).
+__device__ inline uint32_t keep_bits(uint32_t a, uint32_t b, uint32_t rem, uint32_t lb, uint32_t paired) {
+    if (a == b) return 0;
+    return ((rem <= lb && (!paired || a <= (b ^ 1u))) ? 1u : 0u) |
+           ((rem >= lb && (!paired || (a & 1u) == 0u)) ? 2u : 0u);
+}
+
 __device__ inline void table_probe(const Slot* __restrict__ tab, uint32_t tbits, uint64_t kmer,
                                    uint32_t& start, uint32_t& cnt) {
     start = 0;
     cnt = 0;
     const uint32_t tmask = (1u << tbits) - 1u;
     if (kmer == KEY_EMPTY) {
-        const uint4 s = *reinterpret_cast<const uint4*>(&tab[tmask + 1u]);
+        const u32x4 s = *reinterpret_cast<const u32x4*>(&tab[tmask + 1u]);
         start = s.z;
         cnt = s.w;
         return;
@@ -121,7 +136,7 @@ __device__ inline void table_probe(const Slot* __restrict__ tab, uint32_t tbits,
     kmer_hash(kmer, h1, h2);
     uint32_t i = h1 >> (32 - tbits);
     for (;;) {
-        const uint4 s = *reinterpret_cast<const uint4*>(&tab[i]);
+        const u32x4 s = *reinterpret_cast<const u32x4*>(&tab[i]);
         if (s.w == 0) return;
         if ((((uint64_t)s.y << 32) | s.x) == kmer) {
             start = s.z;
@@ -187,12 +202,22 @@ __global__ void k_table_insert(const uint64_t* __restrict__ words, const uint64_
     atomicOr(&bloom[bword], bmask);
 }
 
+// Runs after the chains are filled and sorted.  Most prefixes belong to one read only: that read
+// and its length are stored in the slot itself, so a probe that hits needs no second round trip.
 __global__ void k_table_finalize(Slot* tab, uint32_t nslots, const uint32_t* __restrict__ slot_cnt,
-                                 const uint32_t* __restrict__ slot_start) {
+                                 const uint32_t* __restrict__ slot_start, const uint32_t* __restrict__ chain,
+                                 const uint32_t* __restrict__ len) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nslots) {
-        tab[i].start = slot_start[i];
-        tab[i].count = slot_cnt[i];
+        const uint32_t c = slot_cnt[i];
+        if (c == 1) {
+            const uint32_t b = chain[slot_start[i]];
+            tab[i].start = b;
+            tab[i].count = SLOT_SINGLE | len[b];
+        } else {
+            tab[i].start = slot_start[i];
+            tab[i].count = c;
+        }
     }
 }
 
@@ -265,6 +290,8 @@ struct ScanArgs {
     const Slot* table;
     uint32_t tbits;
     const uint32_t* chain;
+    const uint32_t* len;
+    uint32_t paired;
     uint32_t* selfrep;     // COUNT: min p>0 at which a read's own prefix K-mer recurs
     uint32_t* tile_count;  // COUNT out: candidates per tile
     uint32_t* truemask;    // COUNT out / FILL in: per (tile, lane) bit s set = position p0+s has candidates
@@ -279,135 +306,273 @@ __device__ inline uint64_t window(uint64_t w0, uint64_t w1, int s) {
     return s == 0 ? w0 : ((w0 >> (s * BITS)) | (w1 << ((64 - s * BITS) & 63)));
 }
 
-// Scan stage 1 (filter).  Persistent workgroups (grid <= #CUs), 16 waves each; the Bloom filter
-// lives in LDS for the whole launch.  One wave per tile = 64 words = 64*W positions; lane l owns
-// word l (+ the next one for windows that straddle) and tests its W positions against the filter.
-// Pure streaming: the next tile's record and words are fetched while the current tile computes.
-// Out: per (tile, lane) the mask of positions that pass the filter.
+// Candidates of one position p of read a, given the slot its K-mer found (z = start/read, w = count
+// word).  Calls f(b, lb, keep) for every chain entry that survives keep_bits().
+// (pointers by value: a reference to the kernel-argument struct would force it into scratch)
+template <typename F>
+__device__ inline void for_each_candidate(const uint32_t* __restrict__ chain, const uint32_t* __restrict__ len,
+                                          uint32_t paired, uint32_t z, uint32_t w, uint32_t a, uint32_t rem, F&& f) {
+    if (w & SLOT_SINGLE) {
+        const uint32_t lb = w & ~SLOT_SINGLE;
+        const uint32_t k = keep_bits(a, z, rem, lb, paired);
+        if (k) f(z, lb, k);
+    } else {
+        for (uint32_t j = 0; j < w; ++j) {
+            const uint32_t b = chain[z + j];
+            const uint32_t lb = len[b];
+            const uint32_t k = keep_bits(a, b, rem, lb, paired);
+            if (k) f(b, lb, k);
+        }
+    }
+}
+
+// Scan pass 1 (filter + count), ONE kernel.  Persistent workgroups (grid <= #CUs), 12 waves each;
+// the Bloom filter lives in LDS for the whole launch.  One wave per tile = 64 words = 64*W
+// positions; lane l owns word l (+ the next one for windows that straddle) and tests its W positions
+// against the filter (VALU + one LDS read per position).  Survivors go into a wave-private LDS ring;
+// whenever 64 are waiting, their table slots (two consecutive 16-byte slots each) are requested from
+// L2 and the wave goes straight on to filter the next tile -- the replies are consumed one tile
+// later, so the probe latency hides under the filter arithmetic instead of stalling the wave.
+// Results are gathered per tile in LDS (the wave keeps its last TSLOTS tiles open) and leave with
+// plain coalesced stores: truemask[tile][lane] bit s = position has candidates, tile_count[tile].
+// The only global atomic is the rare selfrep[a] = first recurrence of a's own prefix.
+constexpr int RING = 128;
+constexpr int TSLOTS = 4;
+constexpr int SCAN_LDS_PER_WAVE = RING * 8 + RING * 4 + TSLOTS * WAVE * 4 + TSLOTS * 16;
+
 template <int BITS>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_filter(const ScanArgs A) {
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  // A stays in SGPRs: never take its address
     constexpr int W = 64 / BITS;
-    extern __shared__ uint32_t s_bloom[];
+    extern __shared__ uint64_t smem[];
     const uint32_t nwaves = blockDim.x >> 6;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    uint64_t* r_kmer = smem + wave * RING;                                                   // ring: K-mer
+    uint32_t* r_src = reinterpret_cast<uint32_t*>(smem + nwaves * RING) + wave * RING;       // ring: slot<<16 | lane<<8 | s
+    uint32_t* tmask_all = reinterpret_cast<uint32_t*>(smem + nwaves * RING) + nwaves * RING;
+    uint32_t* tm = tmask_all + wave * (TSLOTS * WAVE);                                       // [TSLOTS][64] result masks
+    uint32_t* meta_all = tmask_all + nwaves * (TSLOTS * WAVE);
+    uint32_t* meta = meta_all + wave * (TSLOTS * 4);                                         // [TSLOTS]{read, la, word0, count}
+    uint32_t* s_bloom = meta_all + nwaves * (TSLOTS * 4);
     const uint32_t bloom_words = (1u << A.bloom_log2) >> 5;
     for (uint32_t i = threadIdx.x; i < bloom_words; i += blockDim.x) s_bloom[i] = A.bloom[i];
     __syncthreads();
 
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t wshift = 32 - (A.bloom_log2 - 5);
     const uint32_t stride = gridDim.x * nwaves;
+    const uint32_t tbits = A.tbits, tmask = (1u << A.tbits) - 1u;
+    const Slot* __restrict__ table = A.table;
+    const uint32_t* __restrict__ chain = A.chain;
+    const uint32_t* __restrict__ len = A.len;
+    const uint64_t* __restrict__ words = A.words;
+    const TileRec* __restrict__ tiles = A.tiles;
+    uint32_t* __restrict__ selfrep = A.selfrep;
+    uint32_t* __restrict__ truemask = A.truemask;
+    uint32_t* __restrict__ tile_count = A.tile_count;
+    const uint32_t paired = A.paired, m = A.m, tile_end = A.tile_end;
+    const uint64_t kmask = A.kmask;
 
+    // wave-uniform state: ring, open tile slots
+    uint32_t r_head = 0, r_cnt = 0;
+    uint32_t slot_tile[TSLOTS], slot_pending[TSLOTS];
+#pragma unroll
+    for (int k = 0; k < TSLOTS; ++k) {
+        slot_tile[k] = 0xFFFFFFFFu;
+        slot_pending[k] = 0;
+    }
+    // the one batch of probes in flight (per lane)
+    bool p_valid = false;
+    uint64_t p_kmer = 0;
+    uint32_t p_src = 0, p_idx = 0;
+    u32x4 p_s0 = {0, 0, 0, 0}, p_s1 = {0, 0, 0, 0};
+
+    // tile stream with one-tile look-ahead
     uint32_t t = __builtin_amdgcn_readfirstlane(A.tile_begin + blockIdx.x * nwaves + wave);
     TileRec rec = {};
     uint64_t w0 = 0, w1 = 0;
-    if (t < A.tile_end) {
-        rec = A.tiles[t];
-        if (rec.la >= A.m && (rec.word0 + lane) * W <= rec.la - A.m) {
-            w0 = A.words[rec.wabs + lane];
-            w1 = A.words[rec.wabs + lane + 1];  // guard word after every read keeps this in bounds
+    if (t < tile_end) {
+        rec = tiles[t];
+        if (rec.la >= m && (rec.word0 + lane) * W <= rec.la - m) {
+            w0 = words[rec.wabs + lane];
+            w1 = words[rec.wabs + lane + 1];  // guard word after every read keeps this in bounds
         }
     }
-    while (t < A.tile_end) {
-        const uint32_t tn = t + stride;
-        TileRec nrec = {};
-        uint64_t nw0 = 0, nw1 = 0;
-        if (tn < A.tile_end) {
-            nrec = A.tiles[tn];
-            if (nrec.la >= A.m && (nrec.word0 + lane) * W <= nrec.la - A.m) {
-                nw0 = A.words[nrec.wabs + lane];
-                nw1 = A.words[nrec.wabs + lane + 1];
-            }
-        }
-        uint32_t hitmask = 0;
-        const uint32_t p0 = (rec.word0 + lane) * W;
-        if (rec.la >= A.m && p0 <= rec.la - A.m) {
-            const uint32_t pmax = rec.la - A.m;  // last position whose suffix/containment can reach min_length
+    // the tile whose survivors are being appended (a tile with > 64 survivors takes several rounds)
+    bool tile_active = false;
+    uint32_t hitmask = 0, rank = 0, r0 = 0, total = 0, ts = 0, iter = 0, p0 = 0;
+    uint64_t cw0 = 0, cw1 = 0;
+
+    // One loop, one copy of each stage (filter / append / consume / issue): everything the stages
+    // share stays in registers.
+    for (;;) {
+        const uint32_t next_slot = iter & (TSLOTS - 1);
+        uint32_t next_slot_pending = 0;
 #pragma unroll
-            for (int s = 0; s < W; ++s) {
-                const uint64_t kmer = window<BITS>(w0, w1, s) & A.kmask;
-                const uint32_t lo = (uint32_t)kmer, hi = (uint32_t)(kmer >> 32);
-                const uint32_t h1 = (lo ^ ((hi << 13) | (hi >> 19))) * 0x9E3779B1u;
-                const uint32_t mask = (1u << ((h1 >> 7) & 31)) | (1u << ((h1 >> 12) & 31)) | (1u << ((h1 >> 2) & 31));
-                const uint32_t bw = s_bloom[h1 >> wshift];
-                hitmask |= ((bw & mask) == mask ? 1u : 0u) << s;
+        for (int k = 0; k < TSLOTS; ++k)
+            if ((uint32_t)k == next_slot) next_slot_pending = slot_pending[k];
+        const bool tiles_left = t < tile_end;
+        const bool can_start = !tile_active && tiles_left && next_slot_pending == 0;
+
+        // ---- stage 1: filter the next tile (VALU + one LDS read per position)
+        if (can_start) {
+            const uint32_t tn = t + stride;
+            TileRec nrec = {};
+            uint64_t nw0 = 0, nw1 = 0;
+            if (tn < tile_end) {  // look-ahead loads: consumed one tile later
+                nrec = tiles[tn];
+                if (nrec.la >= m && (nrec.word0 + lane) * W <= nrec.la - m) {
+                    nw0 = words[nrec.wabs + lane];
+                    nw1 = words[nrec.wabs + lane + 1];
+                }
             }
-            const uint32_t nvalid = pmax - p0 + 1;
-            if (nvalid < (uint32_t)W) hitmask &= (1u << nvalid) - 1u;
+            hitmask = 0;
+            p0 = (rec.word0 + lane) * W;
+            if (rec.la >= m && p0 <= rec.la - m) {
+                const uint32_t pmax = rec.la - m;  // last position whose suffix/containment can reach min_length
+#pragma unroll
+                for (int s = 0; s < W; ++s) {
+                    const uint64_t kmer = window<BITS>(w0, w1, s) & kmask;
+                    const uint32_t lo = (uint32_t)kmer, hi = (uint32_t)(kmer >> 32);
+                    const uint32_t h1 = (lo ^ ((hi << 13) | (hi >> 19))) * 0x9E3779B1u;
+                    const uint32_t bmask = (1u << ((h1 >> 7) & 31)) | (1u << ((h1 >> 12) & 31)) | (1u << ((h1 >> 2) & 31));
+                    const uint32_t bw = s_bloom[h1 >> wshift];
+                    hitmask |= ((bw & bmask) == bmask ? 1u : 0u) << s;
+                }
+                const uint32_t nvalid = pmax - p0 + 1;
+                if (nvalid < (uint32_t)W) hitmask &= (1u << nvalid) - 1u;
+            }
+            const uint32_t nh = __popc(hitmask);
+            const uint32_t incl = wave_incl_scan(nh);
+            total = read_last_lane(incl);
+            rank = incl - nh;
+            r0 = 0;
+            ts = next_slot;
+            // the slot's previous tile is fully probed (pending == 0): its results leave LDS
+#pragma unroll
+            for (int k = 0; k < TSLOTS; ++k) {
+                if ((uint32_t)k == ts) {
+                    if (slot_tile[k] != 0xFFFFFFFFu) {
+                        wave_lds_fence();
+                        truemask[(size_t)slot_tile[k] * WAVE + lane] = tm[k * WAVE + lane];
+                        if (lane == 0) tile_count[slot_tile[k]] = meta[k * 4 + 3];
+                    }
+                    slot_tile[k] = t;
+                    slot_pending[k] = total;
+                }
+            }
+            wave_lds_fence();
+            tm[ts * WAVE + lane] = 0;
+            if (lane == 0) {
+                meta[ts * 4 + 0] = rec.read;
+                meta[ts * 4 + 1] = rec.la;
+                meta[ts * 4 + 2] = rec.word0;
+                meta[ts * 4 + 3] = 0;
+            }
+            cw0 = w0;
+            cw1 = w1;
+            tile_active = total != 0;
+            t = tn;
+            rec = nrec;
+            w0 = nw0;
+            w1 = nw1;
+            ++iter;
         }
-        A.truemask[(size_t)t * WAVE + lane] = hitmask;
-        t = tn;
-        rec = nrec;
-        w0 = nw0;
-        w1 = nw1;
+        // ---- stage 2: append up to 64 survivors to the ring (needs room: r_cnt < 64)
+        if (tile_active && r_cnt < WAVE) {
+            while (hitmask && rank < r0 + WAVE) {
+                const uint32_t s = __ffs(hitmask) - 1;
+                hitmask &= hitmask - 1;
+                const uint32_t e = (r_head + r_cnt + rank - r0) & (RING - 1);
+                r_kmer[e] = funnel(cw0, cw1, s * BITS) & kmask;
+                r_src[e] = (ts << 16) | (lane << 8) | s;
+                ++rank;
+            }
+            r_cnt += (total - r0 < WAVE) ? total - r0 : WAVE;
+            r0 += WAVE;
+            if (r0 >= total) tile_active = false;
+            wave_lds_fence();
+        }
+        // ---- stage 3: consume the batch issued one pass ago
+        if (p_valid) {
+            u32x4 s = p_s0;
+            if (p_kmer != KEY_EMPTY && s.w != 0 && (((uint64_t)s.y << 32) | s.x) != p_kmer) {  // linear probing
+                s = p_s1;
+                uint32_t i = (p_idx + 1u) & tmask;
+                while (s.w != 0 && (((uint64_t)s.y << 32) | s.x) != p_kmer) {
+                    i = (i + 1u) & tmask;
+                    s = *reinterpret_cast<const u32x4*>(&table[i]);
+                }
+            }
+            if (s.w != 0) {
+                const uint32_t es = p_src >> 16;
+                const uint32_t a = meta[es * 4 + 0], la = meta[es * 4 + 1];
+                const uint32_t p = (meta[es * 4 + 2] + ((p_src >> 8) & 255u)) * W + (p_src & 255u);
+                uint32_t n = 0;
+                if (p > 0) {
+                    if (s.w & SLOT_SINGLE) {
+                        if (s.z == a) atomicMin(&selfrep[a], p);
+                    } else {
+                        for (uint32_t j = 0; j < s.w; ++j)
+                            if (chain[s.z + j] == a) atomicMin(&selfrep[a], p);
+                    }
+                }
+                for_each_candidate(chain, len, paired, s.z, s.w, a, la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
+                if (n) {
+                    atomicOr(&tm[es * WAVE + ((p_src >> 8) & 255u)], 1u << (p_src & 255u));
+                    atomicAdd(&meta[es * 4 + 3], n);
+                }
+            }
+        }
+        {
+            const uint32_t es = p_src >> 16;
+#pragma unroll
+            for (int k = 0; k < TSLOTS; ++k)
+                slot_pending[k] -= __popcll(__ballot(p_valid && es == (uint32_t)k));
+            p_valid = false;
+        }
+        // ---- stage 4: request the table slots of the next 64 survivors.  A partial batch goes out
+        // only when the next pass cannot append anything: the stream has ended, or the next tile's
+        // result slot still waits for survivors that sit in the ring.
+        uint32_t npend = 0;
+#pragma unroll
+        for (int k = 0; k < TSLOTS; ++k)
+            if ((uint32_t)k == (iter & (TSLOTS - 1))) npend = slot_pending[k];
+        const bool will_append = tile_active || (t < tile_end && npend == 0);
+        if (r_cnt >= WAVE || (r_cnt > 0 && !will_append)) {
+            const uint32_t n_pop = r_cnt < WAVE ? r_cnt : WAVE;
+            p_valid = lane < n_pop;
+            if (p_valid) {
+                const uint32_t e = (r_head + lane) & (RING - 1);
+                p_kmer = r_kmer[e];
+                p_src = r_src[e];
+                if (p_kmer == KEY_EMPTY) {
+                    p_idx = tmask + 1u;
+                    p_s0 = *reinterpret_cast<const u32x4*>(&table[p_idx]);
+                } else {
+                    const uint32_t lo = (uint32_t)p_kmer, hi = (uint32_t)(p_kmer >> 32);
+                    p_idx = ((lo ^ ((hi << 13) | (hi >> 19))) * 0x9E3779B1u) >> (32 - tbits);
+                    p_s0 = *reinterpret_cast<const u32x4*>(&table[p_idx]);
+                    p_s1 = *reinterpret_cast<const u32x4*>(&table[(p_idx + 1u) & tmask]);
+                }
+            }
+            r_head = (r_head + n_pop) & (RING - 1);
+            r_cnt -= n_pop;
+            wave_lds_fence();  // ring reads done before later appends reuse the entries
+        }
+        if (t >= tile_end && !tile_active && r_cnt == 0 && !__any(p_valid)) break;
+    }
+    // every probe is back: the open tiles' results leave LDS
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < TSLOTS; ++k) {
+        if (slot_tile[k] != 0xFFFFFFFFu) {
+            truemask[(size_t)slot_tile[k] * WAVE + lane] = tm[k * WAVE + lane];
+            if (lane == 0) tile_count[slot_tile[k]] = meta[k * 4 + 3];
+        }
     }
 }
 
-// Scan stage 2 (count).  One wave per tile, ordinary grid, high occupancy: the filter survivors of
-// the whole wave are compacted through a wave-private LDS queue so the L2 table probes run with all
-// lanes busy.  Rewrites the (tile, lane) mask in place so that only positions that really have
-// candidates stay set, counts the tile's candidates, and records self-repeats of a's own prefix.
-template <int BITS>
-__global__ __launch_bounds__(256) void k_scan_count(const ScanArgs A) {
-    constexpr int W = 64 / BITS;
-    __shared__ uint64_t q_kmer[4 * WAVE];
-    __shared__ uint32_t q_p[4 * WAVE];
-    __shared__ uint32_t q_tm[4 * WAVE];
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    uint64_t* qk = q_kmer + wave * WAVE;
-    uint32_t* qp = q_p + wave * WAVE;
-    uint32_t* tm = q_tm + wave * WAVE;
-    const uint32_t t = __builtin_amdgcn_readfirstlane(A.tile_begin + blockIdx.x * 4 + wave);
-    if (t >= A.tile_end) return;
-    uint32_t hitmask = A.truemask[(size_t)t * WAVE + lane];
-    const uint32_t nh = __popc(hitmask);
-    const uint32_t incl = wave_incl_scan(nh);
-    const uint32_t total = read_last_lane(incl);
-    if (total == 0) {
-        if (lane == 0) A.tile_count[t] = 0;
-        return;
-    }
-    const TileRec rec = A.tiles[t];
-    uint64_t w0 = 0, w1 = 0;
-    if (hitmask) {
-        w0 = A.words[rec.wabs + lane];
-        w1 = A.words[rec.wabs + lane + 1];
-    }
-    const uint32_t a = rec.read;
-    const uint64_t key_a = A.words[rec.wread] & A.kmask;
-    uint32_t rank = incl - nh;
-    uint32_t tile_total = 0;
-    tm[lane] = 0;
-    for (uint32_t r0 = 0; r0 < total; r0 += WAVE) {
-        while (hitmask && rank < r0 + WAVE) {
-            const uint32_t s = __ffs(hitmask) - 1;
-            hitmask &= hitmask - 1;
-            qk[rank - r0] = funnel(w0, w1, s * BITS) & A.kmask;
-            qp[rank - r0] = (lane << 8) | s;
-            ++rank;
-        }
-        wave_lds_fence();
-        const bool has = r0 + lane < total;
-        const uint64_t kmer = qk[lane];
-        const uint32_t src = qp[lane];
-        uint32_t start = 0, cnt = 0;
-        if (has) table_probe(A.table, A.tbits, kmer, start, cnt);
-        const bool self = cnt != 0 && kmer == key_a;  // a's own chain entry is not a candidate
-        const uint32_t ceff = cnt - (self ? 1u : 0u);
-        if (self) {
-            const uint32_t p = (rec.word0 + (src >> 8)) * W + (src & 255u);
-            if (p > 0) atomicMin(&A.selfrep[a], p);
-        }
-        if (ceff) atomicOr(&tm[src >> 8], 1u << (src & 255u));
-        tile_total += ceff;
-        wave_lds_fence();
-    }
-    A.truemask[(size_t)t * WAVE + lane] = tm[lane];
-    tile_total = wave_sum(tile_total);
-    if (lane == 0) A.tile_count[t] = tile_total;
-}
-
-// FILL pass: one wave per tile, ordinary grid.  Positions with candidates come from truemask; each
-// is probed again (L2-resident table) for its chain and the (a, p, b) triples are written at
+// Scan pass 2 (fill): one wave per tile, ordinary grid.  Positions with candidates come from
+// truemask; each is probed again (L2-resident table) and its (a, p, b) triples are written at
 // tile_off[t] in ascending p, chain order (ascending b).
 template <int BITS>
 __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
@@ -430,7 +595,7 @@ __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
         w0 = A.words[rec.wabs + lane];
         w1 = A.words[rec.wabs + lane + 1];
     }
-    const uint32_t a = rec.read;
+    const uint32_t a = rec.read, la = rec.la;
     const uint32_t p0 = (rec.word0 + lane) * W;
     uint32_t rank = incl - nh;
     uint32_t base = A.tile_off[t];
@@ -447,20 +612,19 @@ __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
         const uint64_t kmer = qk[lane];
         const uint32_t p = qp[lane];
         wave_lds_fence();
-        uint32_t start = 0, cnt = 0;
-        if (has) table_probe(A.table, A.tbits, kmer, start, cnt);
-        uint32_t ceff = 0;
-        for (uint32_t j = 0; j < cnt; ++j) ceff += A.chain[start + j] != a;
-        const uint32_t inc = wave_incl_scan(ceff);
-        uint32_t off = base + inc - ceff;
-        for (uint32_t j = 0; j < cnt; ++j) {
-            const uint32_t b = A.chain[start + j];
-            if (b != a) {
+        uint32_t z = 0, w = 0;
+        if (has) table_probe(A.table, A.tbits, kmer, z, w);
+        uint32_t n = 0;
+        if (w) for_each_candidate(A.chain, A.len, A.paired, z, w, a, la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
+        const uint32_t inc = wave_incl_scan(n);
+        uint32_t off = base + inc - n;
+        if (n) {
+            for_each_candidate(A.chain, A.len, A.paired, z, w, a, la - p, [&](uint32_t b, uint32_t, uint32_t) {
                 A.cand_a[off] = a;
                 A.cand_p[off] = p;
                 A.cand_b[off] = b;
                 ++off;
-            }
+            });
         }
         base += read_last_lane(inc);
     }
@@ -540,15 +704,10 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
     bool have = c < seg1;
     uint32_t n = 0, nwords = 0, sh = 0, q = 0, w = 0, keep = 0;
     const uint64_t* B = words;
-    auto init = [&]() {
+    auto init = [&]() __attribute__((always_inline)) {
         const uint32_t p = cand_p[c], b = cand_b[c];
         const uint32_t rem = la - p, lb = len[b];
-        // which rows this candidate can give: A (suffix of a = prefix of b) / B (b inside a).
-        // Paired-strand mode: only the canonical member of each strand-mirror pair is verified
-        // (A: a <= flip(b);  B: a on the + strand); k_emit writes the mirrored row too.
-        keep = ((rem <= lb && (!paired || a <= (b ^ 1u))) ? 1u : 0u) |
-               ((rem >= lb && (!paired || (a & 1u) == 0u)) ? 2u : 0u);
-        if (b == a) keep = 0;  // a read never overlaps itself (overlapper.cpp:72)
+        keep = keep_bits(a, b, rem, lb, paired);
         n = rem < lb ? rem : lb;
         nwords = keep ? (n + W - 1) / W : 0;
         const uint64_t bitpos = (uint64_t)p * BITS;
@@ -561,7 +720,7 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
     while (__any(have)) {
         uint64_t diff = 0;
         if (have && w < nwords) {
-            const uint4 bv = *reinterpret_cast<const uint4*>(B + w);  // b starts 16-byte aligned
+            const u32x4 bv = *reinterpret_cast<const u32x4*>(B + w);  // b starts 16-byte aligned
             const uint64_t b0 = ((uint64_t)bv.y << 32) | bv.x, b1 = ((uint64_t)bv.w << 32) | bv.z;
             uint64_t a0, a1, a2;
             if (in_lds) {
