@@ -81,3 +81,20 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "overlap_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_importable_under_the_reference_module_name():
+    """`from phasm.overlapper import ExactOverlapper` (assembler.py:15) works with the overlay."""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "integration"))
+    try:
+        mod = importlib.import_module("phasm.overlapper")
+        assert mod.ExactOverlapper is ExactOverlapper
+        ov = mod.ExactOverlapper()
+        assert {"add_sequence", "overlaps"} <= set(dir(ov))
+        ov.close()
+    finally:
+        sys.path.remove(os.path.join(ROOT, "integration"))
+        sys.modules.pop("phasm.overlapper", None)
+        sys.modules.pop("phasm", None)
