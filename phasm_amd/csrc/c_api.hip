@@ -209,7 +209,7 @@ po_status upload(po_handle* h) {
     h->h_read_tile0[n] = (uint32_t)tiles.size();
     h->n_tiles = (uint32_t)tiles.size();
 
-    const size_t nwords = h->words.size() + 4;  // trailing zero padding
+    const size_t nwords = h->words.size() + 72;  // trailing zero padding: a scan tile may read 64+1 words past a read's start
     PO_TRY(ensure(h, h->d_words, nwords * 8));
     PO_TRY(ensure(h, h->d_woff, ((size_t)n + 1) * 8));
     PO_TRY(ensure(h, h->d_len, ((size_t)n + 1) * 4));
@@ -318,7 +318,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
 
     // ---- sizes
     uint32_t tbits = 10;
-    while ((1ull << tbits) < 2 * n_elig) ++tbits;
+    while ((1ull << tbits) < 4 * n_elig) ++tbits;  // load factor <= 0.25: short probe sequences
     if (tbits > 30) return fail(h, PO_ERR_CAPACITY, "too many reads for the anchor table");
     const uint32_t nslots = (1u << tbits) + 1;
     uint32_t bloom_log2 = 13;
@@ -361,7 +361,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     hipLaunchKernelGGL(po::k_table_init, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt, slot_cur);
     hipLaunchKernelGGL(po::k_fill_u32, dim3(cdiv(n, 256)), dim3(256), 0, st, selfrep, (uint64_t)n, po::NO_SELFREP);
     hipLaunchKernelGGL(po::k_table_insert, dim3(cdiv(n, 256)), dim3(256), 0, st, words, woff, len, n, m, kmask, table,
-                       tbits, slot_cnt, read_slot, bloom, bloom_log2);
+                       tbits, slot_cnt, read_slot, bloom, bloom_log2, (uint32_t)BITS);
     PO_TRY(prefix_sum<uint32_t>(h, slot_cnt, nslots, slot_start, &h->pinned[0]));
     hipLaunchKernelGGL(po::k_chain_fill, dim3(cdiv(n, 256)), dim3(256), 0, st, read_slot, n, slot_start, slot_cur, chain);
     hipLaunchKernelGGL(po::k_chain_sort_short, dim3(cdiv(nslots, 256)), dim3(256), 0, st, slot_cnt, slot_start, nslots,
@@ -397,13 +397,14 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     A.tile_count = h->d_tile_count.as<uint32_t>();
     A.tile_off = h->d_tile_off.as<uint32_t>();
     A.truemask = h->d_truemask.as<uint32_t>();
-    const uint32_t scan_waves = po::SCAN_BLOCK / 64;
+    uint32_t scan_waves = po::SCAN_BLOCK / 64;
+    if (const char* e = getenv("PHASM_SCAN_WAVES")) scan_waves = std::max(1, std::min(16, atoi(e)));
     const uint32_t scan_grid = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)h->n_cu, cdiv(ntiles, scan_waves)));
-    const size_t scan_lds = (size_t)scan_waves * po::SCAN_LDS_PER_WAVE + bloom_bytes;
+    const size_t scan_lds = bloom_bytes;
     if (scan_lds > h->lds_max) return fail(h, PO_ERR_HIP, "device LDS too small for the scan kernel");
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan_probe<BITS>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
-    hipLaunchKernelGGL((po::k_scan_probe<BITS>), dim3(scan_grid), dim3(po::SCAN_BLOCK), scan_lds, st, A);
+    hipLaunchKernelGGL((po::k_scan_probe<BITS>), dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
     HIP_TRY(h, hipGetLastError());
     PO_TRY(prefix_sum<uint32_t>(h, A.tile_count + tile_begin, ntiles, h->d_tile_off.as<uint32_t>() + tile_begin, &h->pinned[1]));
     HIP_TRY(h, hipEventRecord(h->ev[EV_COUNT], st));

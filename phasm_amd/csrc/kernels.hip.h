@@ -27,7 +27,7 @@ constexpr uint64_t KEY_EMPTY = ~0ull;          // slot-claim sentinel; a real al
                                                // in the dedicated extra slot at index 1<<tbits
 constexpr uint32_t NO_SELFREP = 0xFFFFFFFFu;
 constexpr int WAVE = 64;
-constexpr int SCAN_BLOCK = 768;                // 12 waves: one persistent workgroup per CU
+constexpr int SCAN_BLOCK = 1024;               // 16 waves: one persistent workgroup per CU (<= 128 VGPRs)
 constexpr int TILE_WORDS = 64;                 // one 64-bit word per lane
 
 struct __attribute__((aligned(16))) Slot {
@@ -172,7 +172,7 @@ __global__ void k_fill_u32(uint32_t* p, uint64_t n, uint32_t v) {
 __global__ void k_table_insert(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
                                const uint32_t* __restrict__ len, uint32_t n_reads, uint32_t m,
                                uint64_t kmask, Slot* tab, uint32_t tbits, uint32_t* slot_cnt,
-                               uint32_t* read_slot, uint32_t* bloom, uint32_t bloom_log2) {
+                               uint32_t* read_slot, uint32_t* bloom, uint32_t bloom_log2, uint32_t bits) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     if (len[r] < m) {
@@ -197,9 +197,19 @@ __global__ void k_table_insert(const uint64_t* __restrict__ words, const uint64_
     }
     atomicAdd(&slot_cnt[i], 1u);
     read_slot[r] = i;
-    uint32_t bword, bmask;
-    bloom_slot(key, bloom_log2, bword, bmask);
-    atomicOr(&bloom[bword], bmask);
+    if (bits == 2) {
+        // 2-bit reads: 64-bit blocks addressed by sequence bits themselves (uniform for DNA, no
+        // multiply): block = bits 5.. of the first 16 bases, one bit in the block's low word from
+        // bases 0-2, one in its high word from bases 16-18.  See filter_tile<2>.
+        const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+        const uint32_t blk = (lo >> 5) & ((1u << (bloom_log2 - 6)) - 1u);
+        atomicOr(&bloom[2 * blk], 1u << (lo & 31));
+        atomicOr(&bloom[2 * blk + 1], 1u << (hi & 31));
+    } else {
+        uint32_t bword, bmask;
+        bloom_slot(key, bloom_log2, bword, bmask);
+        atomicOr(&bloom[bword], bmask);
+    }
 }
 
 // Runs after the chains are filled and sorted.  Most prefixes belong to one read only: that read
@@ -306,6 +316,50 @@ __device__ inline uint64_t window(uint64_t w0, uint64_t w1, int s) {
     return s == 0 ? w0 : ((w0 >> (s * BITS)) | (w1 << ((64 - s * BITS) & 63)));
 }
 
+// Filter one lane's W positions (K-mers starting in word w0, spilling into w1) against the LDS
+// filter; bit s of the result = position s passes.
+//  BITS == 8: hashed blocked Bloom filter, 32-bit blocks, 3 bits per key (bloom_slot).
+//  BITS == 2: the packed bases are already uniform bits, so no hash: T[s] = the 32 bits of the read
+//  starting at base s; a K-mer's block is T[s] bits 5.., its two bits are T[s] & 31 in the block's
+//  low word and T[s+16] & 31 (bases 16-18) in its high word.  One ds_read_b64 and ~10 VALU ops per
+//  position; T[s+16] is shared between positions s and s+16.
+template <int BITS>
+__device__ inline uint32_t filter_tile(const uint32_t* __restrict__ s_bloom, uint32_t bloom_log2, uint64_t w0,
+                                       uint64_t w1, uint64_t kmask) {
+    constexpr int W = 64 / BITS;
+    uint32_t hitmask = 0;
+    if constexpr (BITS == 2) {
+        const uint32_t x[4] = {(uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32)};
+        const uint32_t klo = (uint32_t)kmask, khi = (uint32_t)(kmask >> 32);
+        const uint32_t bmask = (1u << (bloom_log2 - 6)) - 1u;
+        const uint2* __restrict__ blocks = reinterpret_cast<const uint2*>(s_bloom);
+        uint32_t T[48];
+#pragma unroll
+        for (int s = 0; s < 48; ++s) {
+            const int j = (2 * s) >> 5, sh = (2 * s) & 31;
+            T[s] = sh ? __builtin_amdgcn_alignbit(x[j + 1], x[j], sh) : x[j];
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const uint32_t t1 = T[s] & klo, t2 = T[s + 16] & khi;
+            const uint2 blk = blocks[(t1 >> 5) & bmask];
+            hitmask |= ((blk.x >> (t1 & 31)) & (blk.y >> (t2 & 31)) & 1u) << s;
+        }
+    } else {
+        const uint32_t wshift = 32 - (bloom_log2 - 5);
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+            const uint64_t kmer = window<BITS>(w0, w1, s) & kmask;
+            const uint32_t lo = (uint32_t)kmer, hi = (uint32_t)(kmer >> 32);
+            const uint32_t h1 = (lo ^ ((hi << 13) | (hi >> 19))) * 0x9E3779B1u;
+            const uint32_t bm = (1u << ((h1 >> 7) & 31)) | (1u << ((h1 >> 12) & 31)) | (1u << ((h1 >> 2) & 31));
+            const uint32_t bw = s_bloom[h1 >> wshift];
+            hitmask |= ((bw & bm) == bm ? 1u : 0u) << s;
+        }
+    }
+    return hitmask;
+}
+
 // Candidates of one position p of read a, given the slot its K-mer found (z = start/read, w = count
 // word).  Calls f(b, lb, keep) for every chain entry that survives keep_bits().
 // (pointers by value: a reference to the kernel-argument struct would force it into scratch)
@@ -326,38 +380,28 @@ __device__ inline void for_each_candidate(const uint32_t* __restrict__ chain, co
     }
 }
 
-// Scan pass 1 (filter + count), ONE kernel.  Persistent workgroups (grid <= #CUs), 12 waves each;
-// the Bloom filter lives in LDS for the whole launch.  One wave per tile = 64 words = 64*W
-// positions; lane l owns word l (+ the next one for windows that straddle) and tests its W positions
-// against the filter (VALU + one LDS read per position).  Survivors go into a wave-private LDS ring;
-// whenever 64 are waiting, their table slots (two consecutive 16-byte slots each) are requested from
-// L2 and the wave goes straight on to filter the next tile -- the replies are consumed one tile
-// later, so the probe latency hides under the filter arithmetic instead of stalling the wave.
-// Results are gathered per tile in LDS (the wave keeps its last TSLOTS tiles open) and leave with
-// plain coalesced stores: truemask[tile][lane] bit s = position has candidates, tile_count[tile].
-// The only global atomic is the rare selfrep[a] = first recurrence of a's own prefix.
-constexpr int RING = 128;
-constexpr int TSLOTS = 4;
-constexpr int SCAN_LDS_PER_WAVE = RING * 8 + RING * 4 + TSLOTS * WAVE * 4 + TSLOTS * 16;
+// Scan pass 1 (filter + count), ONE kernel.  Persistent workgroups (grid <= #CUs); the filter
+// lives in LDS for the whole launch.  One wave per tile = 64 words = 64*W positions; lane l owns
+// word l (+ the next one for windows that straddle) and tests its W positions against the filter
+// (filter_tile: VALU + one LDS read per position).  Each lane then requests the table slots of its
+// OWN survivors (up to NPEND of them; two consecutive 16-byte slots each) from L2 and goes straight
+// on to filter the next tile -- the replies are consumed one tile later, so the probe latency hides
+// under the filter arithmetic.  Everything a lane needs to finish a position stays in its
+// registers: no compaction, no LDS traffic besides the filter, no atomics except the rare
+// selfrep[a] = first recurrence of a's own prefix.
+// Out: truemask[tile][lane] bit s = position has candidates; tile_count[tile] = their number.
+constexpr int NPEND = 4;
 
 template <int BITS>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  // A stays in SGPRs: never take its address
     constexpr int W = 64 / BITS;
-    extern __shared__ uint64_t smem[];
+    extern __shared__ uint32_t s_bloom[];
     const uint32_t nwaves = blockDim.x >> 6;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    uint64_t* r_kmer = smem + wave * RING;                                                   // ring: K-mer
-    uint32_t* r_src = reinterpret_cast<uint32_t*>(smem + nwaves * RING) + wave * RING;       // ring: slot<<16 | lane<<8 | s
-    uint32_t* tmask_all = reinterpret_cast<uint32_t*>(smem + nwaves * RING) + nwaves * RING;
-    uint32_t* tm = tmask_all + wave * (TSLOTS * WAVE);                                       // [TSLOTS][64] result masks
-    uint32_t* meta_all = tmask_all + nwaves * (TSLOTS * WAVE);
-    uint32_t* meta = meta_all + wave * (TSLOTS * 4);                                         // [TSLOTS]{read, la, word0, count}
-    uint32_t* s_bloom = meta_all + nwaves * (TSLOTS * 4);
     const uint32_t bloom_words = (1u << A.bloom_log2) >> 5;
     for (uint32_t i = threadIdx.x; i < bloom_words; i += blockDim.x) s_bloom[i] = A.bloom[i];
     __syncthreads();
 
-    const uint32_t wshift = 32 - (A.bloom_log2 - 5);
     const uint32_t stride = gridDim.x * nwaves;
     const uint32_t tbits = A.tbits, tmask = (1u << A.tbits) - 1u;
     const Slot* __restrict__ table = A.table;
@@ -371,204 +415,181 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
     const uint32_t paired = A.paired, m = A.m, tile_end = A.tile_end;
     const uint64_t kmask = A.kmask;
 
-    // wave-uniform state: ring, open tile slots
-    uint32_t r_head = 0, r_cnt = 0;
-    uint32_t slot_tile[TSLOTS], slot_pending[TSLOTS];
+    // probes in flight: they belong to the PREVIOUS tile of this wave
+    uint64_t pk[NPEND];
+    u32x4 ps0[NPEND], ps1[NPEND];
+    uint32_t pidx[NPEND], psh[NPEND];
+    uint32_t pvalid = 0;
+    uint32_t prev_t = 0xFFFFFFFFu, prev_a = 0, prev_la = 0, prev_p0 = 0;
+    uint32_t prev_mask = 0, prev_cnt = 0;  // results of survivors beyond NPEND, resolved at issue time
 #pragma unroll
-    for (int k = 0; k < TSLOTS; ++k) {
-        slot_tile[k] = 0xFFFFFFFFu;
-        slot_pending[k] = 0;
+    for (int i = 0; i < NPEND; ++i) {
+        pk[i] = 0;
+        ps0[i] = u32x4{0, 0, 0, 0};
+        ps1[i] = u32x4{0, 0, 0, 0};
+        pidx[i] = 0;
+        psh[i] = 0;
     }
-    // the one batch of probes in flight (per lane)
-    bool p_valid = false;
-    uint64_t p_kmer = 0;
-    uint32_t p_src = 0, p_idx = 0;
-    u32x4 p_s0 = {0, 0, 0, 0}, p_s1 = {0, 0, 0, 0};
 
-    // tile stream with one-tile look-ahead
+    // a found slot -> number of candidates of position p of read a (and the selfrep side effect)
+    auto count_slot = [&](u32x4 s, uint32_t a, uint32_t la, uint32_t p) __attribute__((always_inline)) -> uint32_t {
+        uint32_t n = 0;
+        if (p > 0) {
+            if (s.w & SLOT_SINGLE) {
+                if (s.z == a) atomicMin(&selfrep[a], p);
+            } else {
+                for (uint32_t j = 0; j < s.w; ++j)
+                    if (chain[s.z + j] == a) atomicMin(&selfrep[a], p);
+            }
+        }
+        for_each_candidate(chain, len, paired, s.z, s.w, a, la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
+        return n;
+    };
+
+    // Hand-scheduled software pipeline over this wave's tiles k = t, t+stride, ...  The three load
+    // streams of the steady state are issued with inline asm so that the waits can be COUNTED
+    // (hipcc falls back to vmcnt(0) at every use here, which would serialise the probes):
+    //   R(k+2)  record of tile k+2     2 x dwordx4   issued in pass k, used from pass k+1
+    //   W(k+1)  words of tile k+1      1 x dwordx4   issued in pass k, used in pass k+1
+    //   P(k)    table slots of tile k  2*NPEND x dwordx4, issued at the end of pass k, used in pass k+1
+    // vm ops complete in issue order, and vmcnt(N) waits until at most N are outstanding, so a wait
+    // needs N <= (ops issued after the one wanted).  Stores and the rare compiler-tracked loads only
+    // add younger ops, so the counts below are lower bounds: safe.  Every steady-state load is
+    // unconditional (clamped tile index / slot 0 for "no survivor"), which keeps the counts exact.
+    const uint32_t t_last = tile_end - 1;  // launch guarantees tile_end > tile_begin
     uint32_t t = __builtin_amdgcn_readfirstlane(A.tile_begin + blockIdx.x * nwaves + wave);
-    TileRec rec = {};
-    uint64_t w0 = 0, w1 = 0;
-    if (t < tile_end) {
-        rec = tiles[t];
-        if (rec.la >= m && (rec.word0 + lane) * W <= rec.la - m) {
-            w0 = words[rec.wabs + lane];
-            w1 = words[rec.wabs + lane + 1];  // guard word after every read keeps this in bounds
+    if (t >= tile_end) return;
+    auto ld16 = [](const void* ptr) __attribute__((always_inline)) -> u32x4 {
+        u32x4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+        return v;
+    };
+    TileRec rec = tiles[t];  // tile k (ordinary load)
+    // in flight: R = record of the next tile; W = words of the tile to filter next.  W has two
+    // landing register sets used alternately (the pass body is instantiated twice): the words of
+    // tile k stay live in their landing registers through the whole pass while W(k+1) lands in the
+    // other set, so no register whose load is still in flight ever has to be copied.
+    u32x4 r_lo, r_hi, wa, wb = {0, 0, 0, 0};
+    {
+        const TileRec* rp = &tiles[__builtin_amdgcn_readfirstlane(min(t + stride, t_last))];
+        r_lo = ld16(rp);
+        r_hi = ld16(reinterpret_cast<const char*>(rp) + 16);
+        wa = ld16(&words[rec.wabs + lane]);  // (tail padding keeps every lane in bounds)
+#pragma unroll
+        for (int i = 0; i < NPEND; ++i) {  // dummy probes: same queue shape as the steady state
+            ps0[i] = ld16(&table[0]);
+            ps1[i] = ld16(&table[1]);
         }
     }
-    // the tile whose survivors are being appended (a tile with > 64 survivors takes several rounds)
-    bool tile_active = false;
-    uint32_t hitmask = 0, rank = 0, r0 = 0, total = 0, ts = 0, iter = 0, p0 = 0;
-    uint64_t cw0 = 0, cw1 = 0;
-
-    // One loop, one copy of each stage (filter / append / consume / issue): everything the stages
-    // share stays in registers.
-    for (;;) {
-        const uint32_t next_slot = iter & (TSLOTS - 1);
-        uint32_t next_slot_pending = 0;
-#pragma unroll
-        for (int k = 0; k < TSLOTS; ++k)
-            if ((uint32_t)k == next_slot) next_slot_pending = slot_pending[k];
-        const bool tiles_left = t < tile_end;
-        const bool can_start = !tile_active && tiles_left && next_slot_pending == 0;
-
-        // ---- stage 1: filter the next tile (VALU + one LDS read per position)
-        if (can_start) {
-            const uint32_t tn = t + stride;
-            TileRec nrec = {};
-            uint64_t nw0 = 0, nw1 = 0;
-            if (tn < tile_end) {  // look-ahead loads: consumed one tile later
-                nrec = tiles[tn];
-                if (nrec.la >= m && (nrec.word0 + lane) * W <= nrec.la - m) {
-                    nw0 = words[nrec.wabs + lane];
-                    nw1 = words[nrec.wabs + lane + 1];
-                }
-            }
-            hitmask = 0;
-            p0 = (rec.word0 + lane) * W;
-            if (rec.la >= m && p0 <= rec.la - m) {
-                const uint32_t pmax = rec.la - m;  // last position whose suffix/containment can reach min_length
-#pragma unroll
-                for (int s = 0; s < W; ++s) {
-                    const uint64_t kmer = window<BITS>(w0, w1, s) & kmask;
-                    const uint32_t lo = (uint32_t)kmer, hi = (uint32_t)(kmer >> 32);
-                    const uint32_t h1 = (lo ^ ((hi << 13) | (hi >> 19))) * 0x9E3779B1u;
-                    const uint32_t bmask = (1u << ((h1 >> 7) & 31)) | (1u << ((h1 >> 12) & 31)) | (1u << ((h1 >> 2) & 31));
-                    const uint32_t bw = s_bloom[h1 >> wshift];
-                    hitmask |= ((bw & bmask) == bmask ? 1u : 0u) << s;
-                }
-                const uint32_t nvalid = pmax - p0 + 1;
-                if (nvalid < (uint32_t)W) hitmask &= (1u << nvalid) - 1u;
-            }
-            const uint32_t nh = __popc(hitmask);
-            const uint32_t incl = wave_incl_scan(nh);
-            total = read_last_lane(incl);
-            rank = incl - nh;
-            r0 = 0;
-            ts = next_slot;
-            // the slot's previous tile is fully probed (pending == 0): its results leave LDS
-#pragma unroll
-            for (int k = 0; k < TSLOTS; ++k) {
-                if ((uint32_t)k == ts) {
-                    if (slot_tile[k] != 0xFFFFFFFFu) {
-                        wave_lds_fence();
-                        truemask[(size_t)slot_tile[k] * WAVE + lane] = tm[k * WAVE + lane];
-                        if (lane == 0) tile_count[slot_tile[k]] = meta[k * 4 + 3];
-                    }
-                    slot_tile[k] = t;
-                    slot_pending[k] = total;
-                }
-            }
-            wave_lds_fence();
-            tm[ts * WAVE + lane] = 0;
-            if (lane == 0) {
-                meta[ts * 4 + 0] = rec.read;
-                meta[ts * 4 + 1] = rec.la;
-                meta[ts * 4 + 2] = rec.word0;
-                meta[ts * 4 + 3] = 0;
-            }
-            cw0 = w0;
-            cw1 = w1;
-            tile_active = total != 0;
-            t = tn;
-            rec = nrec;
-            w0 = nw0;
-            w1 = nw1;
-            ++iter;
-        }
-        // ---- stage 2: append up to 64 survivors to the ring (needs room: r_cnt < 64)
-        if (tile_active && r_cnt < WAVE) {
-            while (hitmask && rank < r0 + WAVE) {
-                const uint32_t s = __ffs(hitmask) - 1;
-                hitmask &= hitmask - 1;
-                const uint32_t e = (r_head + r_cnt + rank - r0) & (RING - 1);
-                r_kmer[e] = funnel(cw0, cw1, s * BITS) & kmask;
-                r_src[e] = (ts << 16) | (lane << 8) | s;
-                ++rank;
-            }
-            r_cnt += (total - r0 < WAVE) ? total - r0 : WAVE;
-            r0 += WAVE;
-            if (r0 >= total) tile_active = false;
-            wave_lds_fence();
-        }
-        // ---- stage 3: consume the batch issued one pass ago
-        if (p_valid) {
-            u32x4 s = p_s0;
-            if (p_kmer != KEY_EMPTY && s.w != 0 && (((uint64_t)s.y << 32) | s.x) != p_kmer) {  // linear probing
-                s = p_s1;
-                uint32_t i = (p_idx + 1u) & tmask;
-                while (s.w != 0 && (((uint64_t)s.y << 32) | s.x) != p_kmer) {
-                    i = (i + 1u) & tmask;
-                    s = *reinterpret_cast<const u32x4*>(&table[i]);
-                }
-            }
-            if (s.w != 0) {
-                const uint32_t es = p_src >> 16;
-                const uint32_t a = meta[es * 4 + 0], la = meta[es * 4 + 1];
-                const uint32_t p = (meta[es * 4 + 2] + ((p_src >> 8) & 255u)) * W + (p_src & 255u);
-                uint32_t n = 0;
-                if (p > 0) {
-                    if (s.w & SLOT_SINGLE) {
-                        if (s.z == a) atomicMin(&selfrep[a], p);
-                    } else {
-                        for (uint32_t j = 0; j < s.w; ++j)
-                            if (chain[s.z + j] == a) atomicMin(&selfrep[a], p);
-                    }
-                }
-                for_each_candidate(chain, len, paired, s.z, s.w, a, la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
-                if (n) {
-                    atomicOr(&tm[es * WAVE + ((p_src >> 8) & 255u)], 1u << (p_src & 255u));
-                    atomicAdd(&meta[es * 4 + 3], n);
-                }
-            }
-        }
+    // one pass; returns false after the last tile has been retired
+    auto pass = [&](u32x4& wcur, u32x4& wnext) __attribute__((always_inline)) -> bool {
+        const bool have_tile = t < tile_end;  // wave-uniform
+        const uint32_t tn = t + stride;
+        // ---- R and W of the previous pass have 2*NPEND probe loads behind them
+        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r_lo), "+v"(r_hi), "+v"(wcur) : "n"(2 * NPEND) : "memory");
+        TileRec rec1;  // tile k+1
+        rec1.wabs = ((uint64_t)__builtin_amdgcn_readfirstlane(r_lo.y) << 32) | __builtin_amdgcn_readfirstlane(r_lo.x);
+        rec1.wread = ((uint64_t)__builtin_amdgcn_readfirstlane(r_lo.w) << 32) | __builtin_amdgcn_readfirstlane(r_lo.z);
+        rec1.read = __builtin_amdgcn_readfirstlane(r_hi.x);
+        rec1.la = __builtin_amdgcn_readfirstlane(r_hi.y);
+        rec1.word0 = __builtin_amdgcn_readfirstlane(r_hi.z);
+        rec1.pad = 0;
         {
-            const uint32_t es = p_src >> 16;
-#pragma unroll
-            for (int k = 0; k < TSLOTS; ++k)
-                slot_pending[k] -= __popcll(__ballot(p_valid && es == (uint32_t)k));
-            p_valid = false;
+            const TileRec* rp = &tiles[__builtin_amdgcn_readfirstlane(min(tn + stride, t_last))];
+            r_lo = ld16(rp);
+            r_hi = ld16(reinterpret_cast<const char*>(rp) + 16);
+            wnext = ld16(&words[rec1.wabs + lane]);
         }
-        // ---- stage 4: request the table slots of the next 64 survivors.  A partial batch goes out
-        // only when the next pass cannot append anything: the stream has ended, or the next tile's
-        // result slot still waits for survivors that sit in the ring.
-        uint32_t npend = 0;
+        const uint64_t w0 = ((uint64_t)wcur.y << 32) | wcur.x, w1 = ((uint64_t)wcur.w << 32) | wcur.z;
+        // ---- filter this tile
+        uint32_t hitmask = 0;
+        const uint32_t p0 = (rec.word0 + lane) * W;
+        if (have_tile && rec.la >= m && p0 <= rec.la - m) {
+            hitmask = filter_tile<BITS>(s_bloom, A.bloom_log2, w0, w1, kmask);
+            const uint32_t nvalid = rec.la - m - p0 + 1;  // positions whose suffix/containment can reach min_length
+            if (nvalid < (uint32_t)W) hitmask &= (1u << nvalid) - 1u;
+        }
+        // ---- the previous tile's probes have only this pass's R and W (3 loads) behind them
+        asm volatile("s_waitcnt vmcnt(3)" : "+v"(ps0[0]), "+v"(ps0[1]), "+v"(ps0[2]), "+v"(ps0[3]), "+v"(ps1[0]),
+                     "+v"(ps1[1]), "+v"(ps1[2]), "+v"(ps1[3])
+                     :
+                     : "memory");
+        static_assert(NPEND == 4, "the wait above names NPEND probe registers");
+        if (prev_t != 0xFFFFFFFFu) {
+            uint32_t tmk = prev_mask, cnt = prev_cnt;
 #pragma unroll
-        for (int k = 0; k < TSLOTS; ++k)
-            if ((uint32_t)k == (iter & (TSLOTS - 1))) npend = slot_pending[k];
-        const bool will_append = tile_active || (t < tile_end && npend == 0);
-        if (r_cnt >= WAVE || (r_cnt > 0 && !will_append)) {
-            const uint32_t n_pop = r_cnt < WAVE ? r_cnt : WAVE;
-            p_valid = lane < n_pop;
-            if (p_valid) {
-                const uint32_t e = (r_head + lane) & (RING - 1);
-                p_kmer = r_kmer[e];
-                p_src = r_src[e];
-                if (p_kmer == KEY_EMPTY) {
-                    p_idx = tmask + 1u;
-                    p_s0 = *reinterpret_cast<const u32x4*>(&table[p_idx]);
-                } else {
-                    const uint32_t lo = (uint32_t)p_kmer, hi = (uint32_t)(p_kmer >> 32);
-                    p_idx = ((lo ^ ((hi << 13) | (hi >> 19))) * 0x9E3779B1u) >> (32 - tbits);
-                    p_s0 = *reinterpret_cast<const u32x4*>(&table[p_idx]);
-                    p_s1 = *reinterpret_cast<const u32x4*>(&table[(p_idx + 1u) & tmask]);
+            for (int i = 0; i < NPEND; ++i) {
+                if (pvalid & (1u << i)) {
+                    u32x4 s = ps0[i];
+                    if (pk[i] != KEY_EMPTY && s.w != 0 && (((uint64_t)s.y << 32) | s.x) != pk[i]) {  // linear probing
+                        s = ps1[i];
+                        uint32_t j = (pidx[i] + 1u) & tmask;
+                        while (s.w != 0 && (((uint64_t)s.y << 32) | s.x) != pk[i]) {
+                            j = (j + 1u) & tmask;
+                            s = *reinterpret_cast<const u32x4*>(&table[j]);
+                        }
+                    }
+                    if (s.w != 0) {
+                        const uint32_t n = count_slot(s, prev_a, prev_la, prev_p0 + psh[i]);
+                        if (n) {
+                            tmk |= 1u << psh[i];
+                            cnt += n;
+                        }
+                    }
                 }
             }
-            r_head = (r_head + n_pop) & (RING - 1);
-            r_cnt -= n_pop;
-            wave_lds_fence();  // ring reads done before later appends reuse the entries
+            truemask[(size_t)prev_t * WAVE + lane] = tmk;
+            cnt = wave_sum(cnt);
+            if (lane == 0) tile_count[prev_t] = cnt;
         }
-        if (t >= tile_end && !tile_active && r_cnt == 0 && !__any(p_valid)) break;
-    }
-    // every probe is back: the open tiles' results leave LDS
-    wave_lds_fence();
+        if (!have_tile) return false;
+        // ---- request the table slots of this tile's survivors: always 2*NPEND loads per lane
+        // (entries without a survivor read slot 0)
+        pvalid = 0;
+        prev_mask = 0;
+        prev_cnt = 0;
 #pragma unroll
-    for (int k = 0; k < TSLOTS; ++k) {
-        if (slot_tile[k] != 0xFFFFFFFFu) {
-            truemask[(size_t)slot_tile[k] * WAVE + lane] = tm[k * WAVE + lane];
-            if (lane == 0) tile_count[slot_tile[k]] = meta[k * 4 + 3];
+        for (int i = 0; i < NPEND; ++i) {
+            const bool on = hitmask != 0;
+            const uint32_t sft = on ? __ffs(hitmask) - 1 : 0;
+            hitmask &= hitmask - 1;  // (0 stays 0)
+            const uint64_t kmer = funnel(w0, w1, sft * BITS) & kmask;
+            const uint32_t lo = (uint32_t)kmer, hi = (uint32_t)(kmer >> 32);
+            uint32_t idx = ((lo ^ ((hi << 13) | (hi >> 19))) * 0x9E3779B1u) >> (32 - tbits);
+            if (kmer == KEY_EMPTY) idx = tmask + 1u;  // the all-ones key lives in the extra slot
+            if (!on) idx = 0;
+            pk[i] = kmer;
+            psh[i] = sft;
+            pidx[i] = idx;
+            ps0[i] = ld16(&table[idx]);
+            ps1[i] = ld16(&table[(idx + 1u) & tmask]);
+            pvalid |= (on ? 1u : 0u) << i;
         }
+        while (hitmask) {  // rare: more than NPEND survivors in one lane -> resolve them now
+            const uint32_t sft = __ffs(hitmask) - 1;
+            hitmask &= hitmask - 1;
+            const uint64_t kmer = funnel(w0, w1, sft * BITS) & kmask;
+            uint32_t z = 0, w = 0;
+            table_probe(table, tbits, kmer, z, w);
+            if (w) {
+                const uint32_t n = count_slot(u32x4{0, 0, z, w}, rec.read, rec.la, p0 + sft);
+                if (n) {
+                    prev_mask |= 1u << sft;
+                    prev_cnt += n;
+                }
+            }
+        }
+        prev_t = t;
+        prev_a = rec.read;
+        prev_la = rec.la;
+        prev_p0 = p0;
+        t = tn;
+        rec = rec1;
+        return true;
+    };
+    while (pass(wa, wb) && pass(wb, wa)) {
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead loads of the last pass
 }
 
 // Scan pass 2 (fill): one wave per tile, ordinary grid.  Positions with candidates come from
