@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libphasm_overlap.so")
+LIB_PATH = os.environ.get("PHASM_LIB") or os.path.join(HERE, "libphasm_overlap.so")  # PHASM_LIB: dev override
 
 PO_OK, PO_ERR_INVALID, PO_ERR_NOMEM, PO_ERR_HIP, PO_ERR_CAPACITY = range(5)
 

@@ -694,6 +694,10 @@ __global__ __launch_bounds__(256) void k_selfrep(const uint64_t* __restrict__ wo
 // type: bit0 = suffix-prefix (A) candidate holds, bit1 = b wholly contained at p (B); 0 = mismatch.
 constexpr int VER_GROUP = 16;
 constexpr int VER_BLOCK = 256;
+#ifndef PO_VER_BLOCKS
+#define PO_VER_BLOCKS 3
+#endif
+constexpr int VER_BLOCKS = PO_VER_BLOCKS;  // 256-byte blocks per group per step after the first step
 
 template <int BITS>
 __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
                                                          uint32_t lds_words, uint32_t paired,
                                                          uint8_t* __restrict__ type) {
     constexpr int W = 64 / BITS;
-    extern __shared__ uint64_t s_a[];
+    extern __shared__ uint64_t s_a64[];
     const uint32_t a = r_begin + blockIdx.x;
     const uint32_t seg0 = tile_off[read_tile0[a]], seg1 = tile_off[read_tile0[a + 1]];
     if (seg0 == seg1) return;
@@ -714,55 +718,109 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
     const uint64_t* __restrict__ ga = words + woff[a];
     const bool in_lds = nwa + 3 <= lds_words;  // workgroup-uniform
     if (in_lds) {
-        for (uint32_t i = threadIdx.x; i < nwa + 3; i += VER_BLOCK) s_a[i] = ga[i];
+        for (uint32_t i = threadIdx.x; i < nwa + 3; i += VER_BLOCK) s_a64[i] = ga[i];
         __syncthreads();
     }
+    // a is addressed as 32-bit words from here on: the window of a that faces b starts at an
+    // arbitrary bit, and v_alignbit_b32 extracts 32 bits at any offset from two adjacent dwords
+    const uint32_t* __restrict__ s_a = reinterpret_cast<const uint32_t*>(s_a64);
+    const uint32_t* __restrict__ ga32 = reinterpret_cast<const uint32_t*>(ga);
     const uint32_t sub = threadIdx.x & (VER_GROUP - 1);
     const uint32_t gshift = (lane_id() / VER_GROUP) * VER_GROUP;
     constexpr uint32_t NGROUPS = VER_BLOCK / VER_GROUP;
 
     uint32_t c = seg0 + threadIdx.x / VER_GROUP;
     bool have = c < seg1;
-    uint32_t n = 0, nwords = 0, sh = 0, q = 0, w = 0, keep = 0;
-    const uint64_t* B = words;
+    // per candidate: nbits = compared bits, q = first dword of a's window, sh = its bit offset,
+    // d = this lane's first dword of b in the current step, keep = rows it can give
+    uint32_t nbits = 0, sh = 0, q = 0, d = 0, keep = 0, nblk = 1;
+    const uint32_t* B = reinterpret_cast<const uint32_t*>(words);
+    // Candidate metadata runs two candidates ahead of the compare loop, so that a group starting a
+    // new candidate has (p, b, len[b], woff[b]) in registers already: m0 = the next candidate to
+    // start (complete), m1 = the one after (p, b only; its len/woff are requested when it moves up).
+    const uint32_t c_last = seg1 - 1;
+    uint32_t m0p, m0b, m0l, m1p, m1b;
+    uint64_t m0w;
+    {
+        const uint32_t c0 = min(c, c_last), c1 = min(c + NGROUPS, c_last);
+        m0p = cand_p[c0];
+        m0b = cand_b[c0];
+        m1p = cand_p[c1];
+        m1b = cand_b[c1];
+        m0l = len[m0b];
+        m0w = woff[m0b];
+    }
     auto init = [&]() __attribute__((always_inline)) {
-        const uint32_t p = cand_p[c], b = cand_b[c];
-        const uint32_t rem = la - p, lb = len[b];
+        const uint32_t p = m0p, b = m0b, lb = m0l;
+        const uint64_t wo = m0w;
+        // advance the look-ahead: requests only, nothing here is needed before the next candidate
+        m0p = m1p;
+        m0b = m1b;
+        m0l = len[m1b];
+        m0w = woff[m1b];
+        const uint32_t c2 = min(c + 2 * NGROUPS, c_last);
+        m1p = cand_p[c2];
+        m1b = cand_b[c2];
+        const uint32_t rem = la - p;
         keep = keep_bits(a, b, rem, lb, paired);
-        n = rem < lb ? rem : lb;
-        nwords = keep ? (n + W - 1) / W : 0;
+        const uint32_t n = rem < lb ? rem : lb;
+        nbits = keep ? n * BITS : 0;
         const uint64_t bitpos = (uint64_t)p * BITS;
-        q = (uint32_t)(bitpos >> 6);
-        sh = (uint32_t)(bitpos & 63);
-        B = words + woff[b];
-        w = 2 * sub;  // this lane's first word of b in the current step
+        q = (uint32_t)(bitpos >> 5);
+        sh = (uint32_t)(bitpos & 31);
+        B = reinterpret_cast<const uint32_t*>(words + wo);
+        d = 4 * sub;
+        nblk = 1;  // first step: one 256-byte block (a wrong-haplotype candidate dies here);
+                   // later steps: VER_BLOCKS blocks, all loads issued before the first compare
     };
+    // compare this lane's 16 bytes of b at dword dd with the facing window of a
+    auto cmp16 = [&](uint32_t dd, u32x4 bv) __attribute__((always_inline)) -> uint32_t {
+        uint32_t a0, a1, a2, a3, a4;
+        if (in_lds) {
+            a0 = s_a[q + dd];
+            a1 = s_a[q + dd + 1];
+            a2 = s_a[q + dd + 2];
+            a3 = s_a[q + dd + 3];
+            a4 = s_a[q + dd + 4];
+        } else {
+            a0 = ga32[q + dd];
+            a1 = ga32[q + dd + 1];
+            a2 = ga32[q + dd + 2];
+            a3 = ga32[q + dd + 3];
+            a4 = ga32[q + dd + 4];
+        }
+        uint32_t x0 = __builtin_amdgcn_alignbit(a1, a0, sh) ^ bv.x;
+        uint32_t x1 = __builtin_amdgcn_alignbit(a2, a1, sh) ^ bv.y;
+        uint32_t x2 = __builtin_amdgcn_alignbit(a3, a2, sh) ^ bv.z;
+        uint32_t x3 = __builtin_amdgcn_alignbit(a4, a3, sh) ^ bv.w;
+        const uint32_t left = nbits - dd * 32;  // compared bits from this lane's first dword on (>= 1)
+        if (left < 128) {                       // the range ends inside these 16 bytes: mask the tail
+            x0 &= left >= 32 ? ~0u : ((1u << left) - 1u);
+            x1 &= left >= 64 ? ~0u : (left > 32 ? ((1u << (left - 32)) - 1u) : 0u);
+            x2 &= left >= 96 ? ~0u : (left > 64 ? ((1u << (left - 64)) - 1u) : 0u);
+            x3 &= left > 96 ? ((1u << (left - 96)) - 1u) : 0u;
+        }
+        return x0 | x1 | x2 | x3;
+    };
+    constexpr uint32_t BLK = 4 * VER_GROUP;  // dwords per 256-byte block
     if (have) init();
     while (__any(have)) {
-        uint64_t diff = 0;
-        if (have && w < nwords) {
-            const u32x4 bv = *reinterpret_cast<const u32x4*>(B + w);  // b starts 16-byte aligned
-            const uint64_t b0 = ((uint64_t)bv.y << 32) | bv.x, b1 = ((uint64_t)bv.w << 32) | bv.z;
-            uint64_t a0, a1, a2;
-            if (in_lds) {
-                a0 = s_a[q + w];
-                a1 = s_a[q + w + 1];
-                a2 = s_a[q + w + 2];
-            } else {
-                a0 = ga[q + w];
-                a1 = ga[q + w + 1];
-                a2 = ga[q + w + 2];
-            }
-            const uint32_t v0 = n - w * W;  // bases of word w inside the compared range (>= 1)
-            const uint64_t m0 = v0 >= (uint32_t)W ? ~0ull : ((1ull << (v0 * BITS)) - 1ull);
-            const uint64_t m1 = v0 >= 2u * W ? ~0ull : (v0 > (uint32_t)W ? ((1ull << ((v0 - W) * BITS)) - 1ull) : 0ull);
-            diff = ((funnel(a0, a1, sh) ^ b0) & m0) | ((funnel(a1, a2, sh) ^ b1) & m1);
+        uint32_t diff = 0;
+        if (have) {
+            u32x4 bv[VER_BLOCKS];
+#pragma unroll
+            for (int j = 0; j < VER_BLOCKS; ++j)  // b starts 16-byte aligned
+                if ((uint32_t)j < nblk && (d + j * BLK) * 32 < nbits) bv[j] = *reinterpret_cast<const u32x4*>(B + d + j * BLK);
+#pragma unroll
+            for (int j = 0; j < VER_BLOCKS; ++j)
+                if ((uint32_t)j < nblk && (d + j * BLK) * 32 < nbits) diff |= cmp16(d + j * BLK, bv[j]);
         }
         const uint64_t bal = __ballot(diff != 0);
         if (have) {
             const bool mismatch = ((bal >> gshift) & ((1ull << VER_GROUP) - 1ull)) != 0;
-            w += 2 * VER_GROUP;
-            if (mismatch || w - 2 * sub >= nwords) {  // group-uniform: candidate finished
+            d += nblk * BLK;
+            nblk = VER_BLOCKS;
+            if (mismatch || (d - 4 * sub) * 32 >= nbits) {  // group-uniform: candidate finished
                 if (sub == 0) type[c] = mismatch ? (uint8_t)0 : (uint8_t)keep;
                 c += NGROUPS;
                 have = c < seg1;
