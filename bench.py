@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from phasm_amd import synth  # noqa: E402
-from phasm_amd.dist import local_shard_rows, merge_row_shards  # noqa: E402
+from phasm_amd.dist import expand_candidates, local_shard_candidates, merge_row_shards  # noqa: E402
 from phasm_amd.overlapper import ExactOverlapper  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
@@ -73,6 +73,8 @@ def main() -> int:
     ap.add_argument("--min-length", type=int, default=1000)
     ap.add_argument("--cpu-sample-reads", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearse the N>1 path with several ranks on one GPU (rows merged on the host)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -82,16 +84,22 @@ def main() -> int:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the overlap path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_idx = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_idx)
+    device = torch.device("cuda", dev_idx)
+    merge_device = device if args.dist_backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     cfg = synth.CONFIGS[args.config]
     if args.reads:
         cfg = synth.scaled(cfg, args.reads)
     t_load = time.time()
-    ov = ExactOverlapper(device=local_rank)
+    ov = ExactOverlapper(device=dev_idx)
     for name, seq in synth.oriented(synth.generate_reads(cfg)):
         ov.add_sequence(name, seq)
     ov.upload()  # packed reads resident in HBM before anything is timed
@@ -109,8 +117,11 @@ def main() -> int:
             n = len(res)
             res.free()
         else:
-            merged = merge_row_shards(local_shard_rows(ov, m, rank, world, device))
-            n = merged.shape[0]
+            # exchange the compact form (verified candidates, 16 B), expand to rows on every rank
+            merged = merge_row_shards(local_shard_candidates(ov, m, rank, world, merge_device))
+            res = expand_candidates(ov, merged)
+            n = len(res)
+            res.free()
         st = ov.stats()
         if timed:
             for k in stage_keys:
@@ -134,7 +145,7 @@ def main() -> int:
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=merge_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -157,14 +168,14 @@ def main() -> int:
                                    % (args.config, cfg.n_reads, cfg.read_len, cfg.genome_len, cfg.ploidy,
                                       cfg.snp, cfg.seed, n_oriented, m),
                        "n_reads": cfg.n_reads, "read_len": cfg.read_len, "min_length": m,
-                       "parallelism": "a-side read shards x%d + RCCL all-gather of rows" % world if world > 1
+                       "parallelism": "a-side read shards x%d + RCCL all-gather of verified candidates (16 B) + local row expansion" % world if world > 1
                                       else "single GPU"},
             "rows_per_step": int(n_rows),
             "read_pairs_per_sec": n_oriented * (n_oriented - 1) / (dt / K),
             "candidates_per_step": int(last["n_candidates"]),
             "stage_ms": {k: round(v, 4) for k, v in avg.items()},
             "load_seconds": round(t_load, 1),
-            "roofline": {"bound": "hbm", "kernel": "k_verify<%d>" % last["bits_per_base"],
+            "roofline": {"bound": "hbm", "kernel": "k_verify_a<%d>" % last["bits_per_base"],
                          "achieved": ver_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ver_gbs / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": int(ver_bytes),
@@ -172,6 +183,14 @@ def main() -> int:
                          "job_achieved": job_gbs, "job_frac": job_gbs / HBM_PEAK_GBS,
                          "job_algorithmic_bytes": int(job_bytes)},
         }
+        # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes on the same
+        # workload (profiles/r01_v2_pmc.md); it cannot be read from inside this process
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                tr = json.load(f).get(args.config, {}) if not args.reads and world == 1 else {}
+            out["roofline"]["traffic"] = tr.get("k_verify_a<%d>" % last["bits_per_base"])
+        except (OSError, ValueError):
+            pass
         if world == 1:
             # PCIe-inclusive rate (rows copied to the host): reported, never `value`
             t1 = time.perf_counter()

@@ -110,6 +110,18 @@ po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out);
 po_status po_overlaps_shard(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards,
                             po_result** out);
 
+/* Multi-GPU exchange in compact form.  po_candidates_shard: like po_overlaps_shard, but the result
+ * holds the shard's VERIFIED CANDIDATES as po_cand[po_result_count] (16 B each; in paired-strand mode
+ * one per strand-mirror pair) instead of rows (24 B each, both members): 3-4x fewer bytes over xGMI.
+ * Read it with po_result_device_rows / po_result_copy_to_device (or po_result_rows cast to po_cand*).
+ * po_expand: turn a candidate array on this handle's device -- normally the rank-order concatenation
+ * of every shard's candidates -- into rows, exactly the po_overlaps() result in the same order. */
+typedef struct {
+    uint32_t a_idx, p, b_idx, type; /* type bit0: A row (suffix of a = prefix of b), bit1: B row (b inside a) */
+} po_cand;
+po_status po_candidates_shard(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, po_result** out);
+po_status po_expand(po_handle* h, const void* candidates_device, uint64_t n_candidates, po_result** out);
+
 /* The read-index range [*r_begin, *r_end) that po_overlaps_shard(shard, nshards) scans on the
  * a-side.  Pure host logic (no GPU needed). */
 po_status po_shard_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint32_t* r_begin, uint32_t* r_end);

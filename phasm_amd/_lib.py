@@ -20,6 +20,9 @@ ROW_DTYPE = np.dtype([("a_idx", "<u4"), ("b_idx", "<u4"), ("astart", "<i4"),
                       ("aend", "<i4"), ("bstart", "<i4"), ("bend", "<i4")])
 
 
+CAND_DTYPE = np.dtype([("a_idx", "<u4"), ("p", "<u4"), ("b_idx", "<u4"), ("type", "<u4")])
+
+
 class PoStats(ctypes.Structure):
     _fields_ = [
         ("bits_per_base", ctypes.c_uint32), ("kmer", ctypes.c_uint32),
@@ -53,6 +56,8 @@ SYMBOLS = [
     ("po_upload", ctypes.c_int, [_P]),
     ("po_overlaps", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_overlaps_shard", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),
+    ("po_candidates_shard", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),
+    ("po_expand", ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(_P)]),
     ("po_shard_range", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
     ("po_result_count", ctypes.c_uint64, [_P]),
     ("po_result_rows", ctypes.c_void_p, [_P]),

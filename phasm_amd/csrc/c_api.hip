@@ -62,7 +62,7 @@ struct po_handle {
     // per-call workspace (grow-only)
     DevBuf d_table, d_slot_cnt, d_slot_cur, d_slot_start, d_read_slot, d_chain, d_chain_tmp, d_long_list;
     DevBuf d_bloom, d_selfrep, d_tile_count, d_tile_off, d_truemask, d_ps_blocks, d_scalars;
-    DevBuf d_cand_a, d_cand_p, d_cand_b, d_type, d_rowcnt, d_row_off;
+    DevBuf d_cand_a, d_cand_p, d_cand_b, d_type, d_rowcnt, d_row_off, d_flag;
     DevBuf spare_rows;
     int live_results = 0;
 
@@ -71,9 +71,10 @@ struct po_handle {
 
 struct po_result {
     po_handle* h = nullptr;
-    DevBuf d_rows;
+    DevBuf d_rows;          // po_row[count] (elem 24) or po_cand[count] (elem 16)
     uint64_t count = 0;
-    po_row* host = nullptr;
+    size_t elem = sizeof(po_row);
+    void* host = nullptr;
 };
 
 namespace {
@@ -135,30 +136,61 @@ po_status init_device(po_handle* h) {
     return PO_OK;
 }
 
-inline int base_code(unsigned char c) {
-    switch (c) {
-        case 'A': return 0;
-        case 'C': return 1;
-        case 'G': return 2;
-        case 'T': return 3;
-        default: return -1;
+// 2-bit code per byte; 0x80 = not one of upper-case A/C/G/T
+struct BaseLut {
+    uint8_t v[256];
+    BaseLut() {
+        std::memset(v, 0x80, sizeof(v));
+        v[(unsigned char)'A'] = 0;
+        v[(unsigned char)'C'] = 1;
+        v[(unsigned char)'G'] = 2;
+        v[(unsigned char)'T'] = 3;
     }
-}
+};
+const BaseLut g_lut;
 
 // Append one read to the packed store.  Layout: every read starts on a 16-byte boundary and is
 // followed by at least one zero guard word (kernels read one word past the last data word).
-void append_packed(po_handle* h, const unsigned char* s, size_t n, int bits) {
+// bits == 2: returns false (and appends nothing) if a byte is not upper-case A/C/G/T.
+bool append_packed(po_handle* h, const unsigned char* s, size_t n, int bits) {
     const size_t per = 64 / bits;
-    size_t off = (h->words.size() + 1) & ~size_t(1);
+    const size_t old_size = h->words.size();
+    const size_t off = (old_size + 1) & ~size_t(1);
     const size_t nw = (n + per - 1) / per;
     h->words.resize(off + nw + 1, 0);
     uint64_t* w = h->words.data() + off;
     if (bits == 2) {
-        for (size_t i = 0; i < n; ++i) w[i >> 5] |= (uint64_t)base_code(s[i]) << ((i & 31) * 2);
+        const uint8_t* lut = g_lut.v;
+        uint8_t bad = 0;
+        const size_t full = n / 32;
+        for (size_t k = 0; k < full; ++k) {
+            const unsigned char* q = s + k * 32;
+            uint64_t acc = 0;
+            for (int j = 0; j < 32; ++j) {
+                const uint8_t c = lut[q[j]];
+                bad |= c;
+                acc |= (uint64_t)(c & 3) << (2 * j);
+            }
+            w[k] = acc;
+        }
+        if (full * 32 < n) {
+            uint64_t acc = 0;
+            for (size_t i = full * 32; i < n; ++i) {
+                const uint8_t c = lut[s[i]];
+                bad |= c;
+                acc |= (uint64_t)(c & 3) << (2 * (i & 31));
+            }
+            w[full] = acc;
+        }
+        if (bad & 0x80) {
+            h->words.resize(old_size);
+            return false;
+        }
     } else {
         for (size_t i = 0; i < n; ++i) w[i >> 3] |= (uint64_t)s[i] << ((i & 7) * 8);
     }
     h->woff.push_back(off);
+    return true;
 }
 
 // A non-ACGT byte arrived: re-encode everything held so far at 8 bits per base (lossless: all of
@@ -285,7 +317,8 @@ po_status prefix_sum(po_handle* h, const T* in, uint64_t n, uint32_t* out, volat
 }
 
 template <int BITS>
-po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, po_result* res) {
+po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, bool want_cands,
+                       po_result* res) {
     constexpr uint32_t W = 64 / BITS;
     const uint32_t n = (uint32_t)h->len.size();
     const uint32_t m = min_length ? min_length : 1;  // a suffix array has no empty suffix
@@ -451,18 +484,35 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         HIP_TRY(h, hipStreamSynchronize(st));
         n_rows64 = h->pinned[2];
         if (n_rows64 >= 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "row count exceeds one call's capacity (2^32)");
-        // ---- emit
-        if (h->spare_rows.cap >= n_rows64 * sizeof(po_row) && h->spare_rows.p) {
-            res->d_rows = h->spare_rows;
-            h->spare_rows = DevBuf();
+        if (want_cands) {
+            // ---- multi-GPU form: hand out the verified candidates (one per strand-mirror pair), compacted
+            PO_TRY(ensure(h, h->d_flag, (size_t)n_cand));
+            hipLaunchKernelGGL(po::k_flag, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, h->d_rowcnt.as<uint8_t>(), n_cand,
+                               h->d_flag.as<uint8_t>());
+            PO_TRY(prefix_sum<uint8_t>(h, h->d_flag.as<uint8_t>(), n_cand, h->d_row_off.as<uint32_t>(), &h->pinned[3]));
+            HIP_TRY(h, hipStreamSynchronize(st));
+            const uint64_t n_ver = h->pinned[3];
+            PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_ver * sizeof(po::Cand), 256)));
+            hipLaunchKernelGGL(po::k_compact, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_p, A.cand_b,
+                               h->d_type.as<uint8_t>(), h->d_flag.as<uint8_t>(), h->d_row_off.as<uint32_t>(), n_cand,
+                               res->d_rows.as<po::Cand>());
+            HIP_TRY(h, hipGetLastError());
+            res->elem = sizeof(po::Cand);
+            n_rows64 = n_ver;
         } else {
-            h->spare_rows.release();
+            // ---- emit
+            if (h->spare_rows.cap >= n_rows64 * sizeof(po_row) && h->spare_rows.p) {
+                res->d_rows = h->spare_rows;
+                h->spare_rows = DevBuf();
+            } else {
+                h->spare_rows.release();
+            }
+            PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_rows64 * sizeof(po_row), 256)));
+            hipLaunchKernelGGL(po::k_emit, dim3(std::min<uint32_t>(cdiv(n_cand, 256), (uint32_t)h->n_cu * 16)), dim3(256), 0,
+                               st, A.cand_a, A.cand_p, A.cand_b, h->d_type.as<uint8_t>(), h->d_row_off.as<uint32_t>(),
+                               n_cand, len, res->d_rows.as<po::Row>(), (uint32_t)BITS, paired, scalars + 4);
+            HIP_TRY(h, hipGetLastError());
         }
-        PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_rows64 * sizeof(po_row), 256)));
-        hipLaunchKernelGGL(po::k_emit, dim3(std::min<uint32_t>(cdiv(n_cand, 256), (uint32_t)h->n_cu * 16)), dim3(256), 0, st, A.cand_a, A.cand_p, A.cand_b,
-                           h->d_type.as<uint8_t>(), h->d_row_off.as<uint32_t>(), n_cand, len,
-                           res->d_rows.as<po::Row>(), (uint32_t)BITS, paired, scalars + 4);
-        HIP_TRY(h, hipGetLastError());
     } else {
         HIP_TRY(h, hipEventRecord(h->ev[EV_FILL], st));
         HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
@@ -473,8 +523,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     HIP_TRY(h, hipMemcpyAsync(counters, scalars + 4, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
     res->count = n_rows64;
-    S.n_rows = n_rows64;
-    S.n_verified = counters[0];
+    S.n_rows = want_cands ? 0 : n_rows64;
+    S.n_verified = want_cands ? n_rows64 : counters[0];
     S.sum_overlap_bases = counters[1];
     S.verify_bytes_algo = counters[2];
     (void)hipEventElapsedTime(&S.ms_index, h->ev[EV_START], h->ev[EV_INDEX]);
@@ -484,6 +534,54 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     (void)hipEventElapsedTime(&S.ms_select, h->ev[EV_VERIFY], h->ev[EV_SELECT]);
     (void)hipEventElapsedTime(&S.ms_emit, h->ev[EV_SELECT], h->ev[EV_EMIT]);
     (void)hipEventElapsedTime(&S.ms_total, h->ev[EV_START], h->ev[EV_EMIT]);
+    return PO_OK;
+}
+
+// rows from a (merged) verified-candidate array that lives on this device
+po_status run_expand(po_handle* h, const void* d_cands, uint64_t n, po_result* res) {
+    hipStream_t st = h->stream;
+    po_stats& S = h->stats;
+    res->count = 0;
+    if (n == 0) return PO_OK;
+    if (n >= 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "candidate count exceeds one call's capacity (2^32)");
+    const uint32_t nc = (uint32_t)n;
+    const uint32_t paired = (h->bits == 2 && h->paired) ? 1u : 0u;
+    PO_TRY(ensure(h, h->d_scalars, 64));
+    PO_TRY(ensure(h, h->d_rowcnt, (size_t)nc));
+    PO_TRY(ensure(h, h->d_row_off, ((size_t)nc + 1) * 4));
+    unsigned long long* scalars = h->d_scalars.as<unsigned long long>();
+    const po::Cand* cands = static_cast<const po::Cand*>(d_cands);
+    HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
+    HIP_TRY(h, hipMemsetAsync(h->d_scalars.p, 0, 64, st));
+    hipLaunchKernelGGL(po::k_cand_rowcnt, dim3(cdiv(nc, 256)), dim3(256), 0, st, cands, nc, (uint32_t)h->len.size(), paired,
+                       h->d_rowcnt.as<uint8_t>(), reinterpret_cast<uint32_t*>(scalars + 3));  // [0] is the prefix-sum total
+    HIP_TRY(h, hipGetLastError());
+    PO_TRY(prefix_sum<uint8_t>(h, h->d_rowcnt.as<uint8_t>(), nc, h->d_row_off.as<uint32_t>(), &h->pinned[2]));
+    HIP_TRY(h, hipMemcpyAsync(h->pinned + 3, scalars + 3, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    if ((uint32_t)h->pinned[3] != 0) return fail(h, PO_ERR_INVALID, "po_expand: candidate array holds invalid entries");
+    const uint64_t n_rows = h->pinned[2];
+    if (n_rows >= 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "row count exceeds one call's capacity (2^32)");
+    if (h->spare_rows.cap >= n_rows * sizeof(po_row) && h->spare_rows.p) {
+        res->d_rows = h->spare_rows;
+        h->spare_rows = DevBuf();
+    } else {
+        h->spare_rows.release();
+    }
+    PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_rows * sizeof(po_row), 256)));
+    HIP_TRY(h, hipMemsetAsync(h->d_scalars.p, 0, 64, st));
+    hipLaunchKernelGGL(po::k_emit_cands, dim3(std::min<uint32_t>(cdiv(nc, 256), (uint32_t)h->n_cu * 16)), dim3(256), 0, st,
+                       cands, h->d_rowcnt.as<uint8_t>(), h->d_row_off.as<uint32_t>(), nc, h->d_len.as<uint32_t>(),
+                       res->d_rows.as<po::Row>(), (uint32_t)h->bits, paired, scalars + 4);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev[EV_EMIT], st));
+    HIP_TRY(h, hipMemcpyAsync(h->pinned + 4, scalars + 4, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    res->count = n_rows;
+    S.n_rows = n_rows;
+    S.sum_overlap_bases = h->pinned[5];
+    S.verify_bytes_algo = h->pinned[6];
+    (void)hipEventElapsedTime(&S.ms_emit, h->ev[EV_SELECT], h->ev[EV_EMIT]);
     return PO_OK;
 }
 
@@ -510,7 +608,7 @@ void po_destroy(po_handle* h) {
                           &h->d_table, &h->d_slot_cnt, &h->d_slot_cur, &h->d_slot_start, &h->d_read_slot, &h->d_chain,
                           &h->d_chain_tmp, &h->d_long_list, &h->d_bloom, &h->d_selfrep, &h->d_tile_count, &h->d_tile_off,
                           &h->d_ps_blocks, &h->d_scalars, &h->d_cand_a, &h->d_cand_p, &h->d_cand_b, &h->d_type,
-                          &h->d_rowcnt, &h->d_row_off, &h->spare_rows};
+                          &h->d_rowcnt, &h->d_row_off, &h->d_flag, &h->spare_rows};
         for (DevBuf* b : bufs) b->release();
         for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(h->ev[i]);
         (void)hipEventDestroy(h->ev_up0);
@@ -534,17 +632,10 @@ po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const cha
     if (h->len.size() >= 0xFFFFFFF0ull) return fail(h, PO_ERR_CAPACITY, "too many reads");
     try {
         const unsigned char* s = reinterpret_cast<const unsigned char*>(seq);
-        if (h->bits == 2) {
-            bool acgt = true;
-            for (size_t i = 0; i < seq_len; ++i) {
-                if (base_code(s[i]) < 0) {
-                    acgt = false;
-                    break;
-                }
-            }
-            if (!acgt) widen_to_bytes(h);
+        if (h->bits != 2 || !append_packed(h, s, seq_len, 2)) {
+            if (h->bits == 2) widen_to_bytes(h);  // first non-ACGT byte: everything moves to 8 bits/base
+            append_packed(h, s, seq_len, 8);
         }
-        append_packed(h, s, seq_len, h->bits);
         h->ids.emplace_back(id ? id : "", id_len);
         h->len.push_back((uint32_t)seq_len);
         h->total_bases += seq_len;
@@ -575,7 +666,8 @@ po_status po_upload(po_handle* h) {
     }
 }
 
-po_status po_overlaps_shard(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, po_result** out) {
+static po_status overlaps_common(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, bool want_cands,
+                                 po_result** out) {
     if (!h || !out) return PO_ERR_INVALID;
     *out = nullptr;
     if (nshards == 0 || shard >= nshards) return fail(h, PO_ERR_INVALID, "shard must be < nshards");
@@ -585,10 +677,42 @@ po_status po_overlaps_shard(po_handle* h, uint32_t min_length, uint32_t shard, u
     po_status st;
     try {
         st = upload(h);
-        if (st == PO_OK) st = h->bits == 2 ? run_overlaps<2>(h, min_length, shard, nshards, r)
-                                           : run_overlaps<8>(h, min_length, shard, nshards, r);
+        if (st == PO_OK) st = h->bits == 2 ? run_overlaps<2>(h, min_length, shard, nshards, want_cands, r)
+                                           : run_overlaps<8>(h, min_length, shard, nshards, want_cands, r);
     } catch (const std::bad_alloc&) {
         st = fail(h, PO_ERR_NOMEM, "out of host memory in po_overlaps");
+    }
+    if (st != PO_OK) {
+        if (h->dev_ready) (void)hipStreamSynchronize(h->stream);
+        r->d_rows.release();
+        delete r;
+        return st;
+    }
+    ++h->live_results;
+    *out = r;
+    return PO_OK;
+}
+
+po_status po_overlaps_shard(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, po_result** out) {
+    return overlaps_common(h, min_length, shard, nshards, false, out);
+}
+
+po_status po_candidates_shard(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, po_result** out) {
+    return overlaps_common(h, min_length, shard, nshards, true, out);
+}
+
+po_status po_expand(po_handle* h, const void* candidates_device, uint64_t n_candidates, po_result** out) {
+    if (!h || !out || (!candidates_device && n_candidates)) return PO_ERR_INVALID;
+    *out = nullptr;
+    po_result* r = new (std::nothrow) po_result();
+    if (!r) return fail(h, PO_ERR_NOMEM, "out of host memory");
+    r->h = h;
+    po_status st;
+    try {
+        st = upload(h);
+        if (st == PO_OK) st = run_expand(h, candidates_device, n_candidates, r);
+    } catch (const std::bad_alloc&) {
+        st = fail(h, PO_ERR_NOMEM, "out of host memory in po_expand");
     }
     if (st != PO_OK) {
         if (h->dev_ready) (void)hipStreamSynchronize(h->stream);
@@ -619,22 +743,22 @@ uint64_t po_result_count(const po_result* r) { return r ? r->count : 0; }
 
 const po_row* po_result_rows(po_result* r) {
     if (!r) return nullptr;
-    if (r->host || r->count == 0) return r->host;
+    if (r->host || r->count == 0) return static_cast<const po_row*>(r->host);
     po_handle* h = r->h;
-    r->host = static_cast<po_row*>(std::malloc(r->count * sizeof(po_row)));
+    r->host = std::malloc(r->count * r->elem);
     if (!r->host) {
         fail(h, PO_ERR_NOMEM, "out of host memory for the row array");
         return nullptr;
     }
     (void)hipSetDevice(h->device);
-    hipError_t e = hipMemcpyAsync(r->host, r->d_rows.p, r->count * sizeof(po_row), hipMemcpyDeviceToHost, h->stream);
+    hipError_t e = hipMemcpyAsync(r->host, r->d_rows.p, r->count * r->elem, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         fail(h, PO_ERR_HIP, std::string("row copy device->host: ") + hipGetErrorString(e));
         std::free(r->host);
         r->host = nullptr;
     }
-    return r->host;
+    return static_cast<const po_row*>(r->host);
 }
 
 const void* po_result_device_rows(const po_result* r) { return r ? r->d_rows.p : nullptr; }
@@ -644,7 +768,7 @@ po_status po_result_copy_to_device(po_result* r, void* dst_device) {
     if (r->count == 0) return PO_OK;
     po_handle* h = r->h;
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpyAsync(dst_device, r->d_rows.p, r->count * sizeof(po_row), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(dst_device, r->d_rows.p, r->count * r->elem, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return PO_OK;
 }
@@ -655,7 +779,7 @@ void po_result_free(po_result* r) {
     std::free(r->host);
     if (h) {
         --h->live_results;
-        if (r->d_rows.p && r->d_rows.cap > h->spare_rows.cap) {  // keep the larger buffer for the next call
+        if (r->elem == sizeof(po_row) && r->d_rows.p && r->d_rows.cap > h->spare_rows.cap) {  // keep the larger buffer for the next call
             h->spare_rows.release();
             h->spare_rows = r->d_rows;
             r->d_rows = DevBuf();

@@ -837,6 +837,12 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
 // for one (a,b) force b's prefix K-mer to recur inside b (period p-p'), so only reads with
 // selfrep[b] set need the look-back.
 // ----------------------------------------------------------------------------------------
+// Rows per verified candidate in emission order: A row, [its mirror], B row, [its mirror].
+__device__ inline uint32_t rows_of(uint32_t t, uint32_t a, uint32_t b, uint32_t paired) {
+    if (!paired) return (t & 1u) + ((t >> 1) & 1u);
+    return ((t & 1u) ? (a == (b ^ 1u) ? 1u : 2u) : 0u) + ((t & 2u) ? 2u : 0u);
+}
+
 __global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_b,
                          uint8_t* __restrict__ type, uint32_t n_cand, const uint32_t* __restrict__ selfrep,
                          const uint32_t* __restrict__ read_tile0, const uint32_t* __restrict__ tile_off,
@@ -845,7 +851,7 @@ __global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __
     if (i >= n_cand) return;
     uint32_t t = type[i];
     if (t == 0) {
-        rowcnt[i] = 0;
+        rowcnt[i] = 0;  // (candidates-only callers read this as "verified" flag: rows > 0 <=> type != 0)
         return;
     }
     const uint32_t a = cand_a[i], b = cand_b[i];
@@ -863,52 +869,42 @@ __global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __
     }
     // paired-strand mode: every row is written with its strand mirror, except the A row of
     // (x+, x-) / (x-, x+), which is its own mirror
-    uint32_t cnt = (t & 1u) + ((t >> 1) & 1u);
-    if (paired) cnt = ((t & 1u) ? (a == (b ^ 1u) ? 1u : 2u) : 0u) + ((t & 2u) ? 2u : 0u);
-    rowcnt[i] = (uint8_t)cnt;
+    rowcnt[i] = (uint8_t)rows_of(t, a, b, paired);
 }
 
-// Rows of candidate i start at row_off[i]: A row, its mirror, B row, its mirror.  Mirrors
-// (exact when every read 2i+1 is the reverse complement of read 2i):
+// Write the rows of one verified candidate at rows[off...].  Mirrors (exact
+// when every read 2i+1 is the reverse complement of read 2i):
 //   A (a, b, la-l, la, 0, l)   <->  (b^1, a^1, lb-l, lb, 0, l)
 //   B (a, b, p, p+lb, 0, lb)   <->  (a^1, b^1, la-p-lb, la-p, 0, lb)
-__global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
-                                              const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,
-                                              const uint32_t* __restrict__ row_off, uint32_t n_cand,
-                                              const uint32_t* __restrict__ len, Row* __restrict__ rows, uint32_t bits,
-                                              uint32_t paired,
-                                              unsigned long long* __restrict__ counters /* [0]=verified [1]=sum l [2]=sum 2*ceil(l*bits/8) */) {
-    __shared__ uint64_t s_red[3][256 / WAVE];
-    uint64_t nver = 0, suml = 0, sumb = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cand; i += gridDim.x * blockDim.x) {
-        const uint32_t t = type[i];
-        if (t == 0) continue;
-        nver += 1;
-        const uint32_t a = cand_a[i], p = cand_p[i], b = cand_b[i];
-        const uint32_t la = len[a], lb = len[b];
-        uint32_t off = row_off[i];
-        if (t & 1u) {
-            const uint32_t l = la - p;
-            uint32_t k = 1;
-            rows[off++] = Row{a, b, (int32_t)p, (int32_t)la, 0, (int32_t)l};
-            if (paired && a != (b ^ 1u)) {
-                rows[off++] = Row{b ^ 1u, a ^ 1u, (int32_t)(lb - l), (int32_t)lb, 0, (int32_t)l};
-                k = 2;
-            }
-            suml += (uint64_t)k * l;
-            sumb += (uint64_t)k * 2ull * (((uint64_t)l * bits + 7) / 8);
+__device__ inline void write_rows(Row* __restrict__ rows, uint32_t off, uint32_t t, uint32_t a, uint32_t p, uint32_t b,
+                                  uint32_t la, uint32_t lb, uint32_t bits, uint32_t paired, uint64_t& suml,
+                                  uint64_t& sumb) {
+    if (t & 1u) {
+        const uint32_t l = la - p;
+        uint32_t k = 1;
+        rows[off++] = Row{a, b, (int32_t)p, (int32_t)la, 0, (int32_t)l};
+        if (paired && a != (b ^ 1u)) {
+            rows[off++] = Row{b ^ 1u, a ^ 1u, (int32_t)(lb - l), (int32_t)lb, 0, (int32_t)l};
+            k = 2;
         }
-        if (t & 2u) {
-            uint32_t k = 1;
-            rows[off++] = Row{a, b, (int32_t)p, (int32_t)(p + lb), 0, (int32_t)lb};
-            if (paired) {
-                rows[off++] = Row{a ^ 1u, b ^ 1u, (int32_t)(la - p - lb), (int32_t)(la - p), 0, (int32_t)lb};
-                k = 2;
-            }
-            suml += (uint64_t)k * lb;
-            sumb += (uint64_t)k * 2ull * (((uint64_t)lb * bits + 7) / 8);
-        }
+        suml += (uint64_t)k * l;
+        sumb += (uint64_t)k * 2ull * (((uint64_t)l * bits + 7) / 8);
     }
+    if (t & 2u) {
+        uint32_t k = 1;
+        rows[off++] = Row{a, b, (int32_t)p, (int32_t)(p + lb), 0, (int32_t)lb};
+        if (paired) {
+            rows[off++] = Row{a ^ 1u, b ^ 1u, (int32_t)(la - p - lb), (int32_t)(la - p), 0, (int32_t)lb};
+            k = 2;
+        }
+        suml += (uint64_t)k * lb;
+        sumb += (uint64_t)k * 2ull * (((uint64_t)lb * bits + 7) / 8);
+    }
+}
+
+// one atomic per counter per workgroup: [0]=verified candidates [1]=sum l [2]=sum 2*ceil(l*bits/8)
+__device__ inline void flush_counters(uint64_t nver, uint64_t suml, uint64_t sumb, unsigned long long* __restrict__ counters) {
+    __shared__ uint64_t s_red[3][256 / WAVE];
     nver = wave_sum64(nver);
     suml = wave_sum64(suml);
     sumb = wave_sum64(sumb);
@@ -918,11 +914,76 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ cand_
         s_red[2][threadIdx.x >> 6] = sumb;
     }
     __syncthreads();
-    if (threadIdx.x < 3) {  // one atomic per counter per workgroup
+    if (threadIdx.x < 3) {
         uint64_t v = 0;
         for (int w = 0; w < 256 / WAVE; ++w) v += s_red[threadIdx.x][w];
         if (v) atomicAdd(&counters[threadIdx.x], (unsigned long long)v);
     }
+}
+
+// Rows of candidate i start at row_off[i].
+__global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
+                                              const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,
+                                              const uint32_t* __restrict__ row_off, uint32_t n_cand,
+                                              const uint32_t* __restrict__ len, Row* __restrict__ rows, uint32_t bits,
+                                              uint32_t paired, unsigned long long* __restrict__ counters) {
+    uint64_t nver = 0, suml = 0, sumb = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cand; i += gridDim.x * blockDim.x) {
+        const uint32_t t = type[i];
+        if (t == 0) continue;
+        nver += 1;
+        const uint32_t a = cand_a[i], p = cand_p[i], b = cand_b[i];
+        write_rows(rows, row_off[i], t, a, p, b, len[a], len[b], bits, paired, suml, sumb);
+    }
+    flush_counters(nver, suml, sumb, counters);
+}
+
+// ---- multi-GPU form: verified candidates travel (16 B each, one per strand-mirror pair) instead of
+// rows (24 B each, both members): compact on the producer, all-gather, expand on every rank.
+struct Cand {
+    uint32_t a, p, b, type;
+};
+
+__global__ void k_compact(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
+                          const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,
+                          const uint8_t* __restrict__ flag, const uint32_t* __restrict__ flag_off, uint32_t n_cand,
+                          Cand* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cand || flag[i] == 0) return;
+    out[flag_off[i]] = Cand{cand_a[i], cand_p[i], cand_b[i], type[i]};
+}
+
+__global__ void k_flag(const uint8_t* __restrict__ rowcnt, uint32_t n, uint8_t* __restrict__ flag) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = rowcnt[i] != 0;
+}
+
+__global__ void k_cand_rowcnt(const Cand* __restrict__ cands, uint32_t n, uint32_t n_reads, uint32_t paired,
+                              uint8_t* __restrict__ rowcnt, uint32_t* __restrict__ n_bad) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Cand c = cands[i];
+    if (c.a >= n_reads || c.b >= n_reads || c.type == 0 || c.type > 3) {  // not produced by this library
+        rowcnt[i] = 0;
+        atomicAdd(n_bad, 1u);
+        return;
+    }
+    rowcnt[i] = (uint8_t)rows_of(c.type, c.a, c.b, paired);
+}
+
+__global__ __launch_bounds__(256) void k_emit_cands(const Cand* __restrict__ cands, const uint8_t* __restrict__ rowcnt,
+                                                    const uint32_t* __restrict__ row_off, uint32_t n,
+                                                    const uint32_t* __restrict__ len, Row* __restrict__ rows,
+                                                    uint32_t bits, uint32_t paired,
+                                                    unsigned long long* __restrict__ counters) {
+    uint64_t nver = 0, suml = 0, sumb = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (rowcnt[i] == 0) continue;
+        const Cand c = cands[i];
+        nver += 1;
+        write_rows(rows, row_off[i], c.type, c.a, c.p, c.b, len[c.a], len[c.b], bits, paired, suml, sumb);
+    }
+    flush_counters(nver, suml, sumb, counters);
 }
 
 // Paired-strand detection (2-bit reads only): is read 2i+1 exactly the reverse complement of read

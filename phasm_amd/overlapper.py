@@ -24,7 +24,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import ROW_DTYPE, PoStats
+from ._lib import CAND_DTYPE, ROW_DTYPE, PoStats
 
 OverlapT = Tuple[str, str, int, int, int, int]
 
@@ -54,9 +54,10 @@ def _check(handle, status: int):
 class OverlapResult:
     """Owns one ``po_result``: rows stay on the device until asked for."""
 
-    def __init__(self, owner: "ExactOverlapper", ptr):
+    def __init__(self, owner: "ExactOverlapper", ptr, dtype=ROW_DTYPE):
         self._owner = owner
         self._ptr = ptr
+        self._dtype = dtype  # ROW_DTYPE (24-byte rows) or CAND_DTYPE (16-byte verified candidates)
         self._lib = _lib.load()
 
     def __len__(self) -> int:
@@ -66,12 +67,12 @@ class OverlapResult:
         """Host copy as a structured array (a_idx, b_idx, astart, aend, bstart, bend)."""
         n = len(self)
         if n == 0:
-            return np.empty(0, dtype=ROW_DTYPE)
+            return np.empty(0, dtype=self._dtype)
         p = self._lib.po_result_rows(self._ptr)
         if not p:
             _check(self._owner._h, _lib.PO_ERR_HIP)
-        buf = (ctypes.c_char * (n * ROW_DTYPE.itemsize)).from_address(p)
-        return np.frombuffer(buf, dtype=ROW_DTYPE).copy()
+        buf = (ctypes.c_char * (n * self._dtype.itemsize)).from_address(p)
+        return np.frombuffer(buf, dtype=self._dtype).copy()
 
     def device_ptr(self) -> int:
         return int(self._lib.po_result_device_rows(self._ptr) or 0)
@@ -130,6 +131,20 @@ class ExactOverlapper:
         m = self._min_length(min_length)
         r = ctypes.c_void_p()
         _check(self._h, self._lib.po_overlaps_shard(self._h, m, int(shard), int(nshards), ctypes.byref(r)))
+        return OverlapResult(self, r)
+
+    def candidates_result(self, min_length: int, shard: int = 0, nshards: int = 1) -> OverlapResult:
+        """Verified candidates of one a-side shard (``po_candidates_shard``): the compact form that
+        travels between GPUs; ``expand_result`` turns the merged array into rows."""
+        m = self._min_length(min_length)
+        r = ctypes.c_void_p()
+        _check(self._h, self._lib.po_candidates_shard(self._h, m, int(shard), int(nshards), ctypes.byref(r)))
+        return OverlapResult(self, r, CAND_DTYPE)
+
+    def expand_result(self, cand_device_ptr: int, n_candidates: int) -> OverlapResult:
+        """Rows from a candidate array resident on this handle's device (``po_expand``)."""
+        r = ctypes.c_void_p()
+        _check(self._h, self._lib.po_expand(self._h, ctypes.c_void_p(cand_device_ptr), int(n_candidates), ctypes.byref(r)))
         return OverlapResult(self, r)
 
     def overlaps_array(self, min_length: int) -> np.ndarray:

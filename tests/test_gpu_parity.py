@@ -157,3 +157,36 @@ def test_long_chain_many_identical_reads():
     seqs = [base] * 40 + [base[50:] + b"ACGTACGT", b"TTTT" + base[:200]]
     got, _ = hip_rows(seqs, 100)
     assert np.array_equal(got, oo.oracle_overlaps(seqs, 100))
+
+
+@pytest.mark.parametrize("nshards", [1, 2, 5])
+def test_compact_candidates_then_expand_equals_rows(nshards):
+    """The multi-GPU exchange form: per-shard verified candidates (16 B), concatenated in shard
+    order, expanded by po_expand -> exactly the po_overlaps rows, in the same order."""
+    import torch
+    from phasm_amd.dist import _result_to_tensor
+    for case in ("ladder_varlen", "ladder_cfg2_mini"):
+        _, seqs, m, want = gu.ladder_case(case)
+        ov = ExactOverlapper()
+        for i, s in enumerate(seqs):
+            ov.add_sequence("r%d" % i, s)
+        whole = ov.overlaps_array(m)
+        dev = torch.device("cuda", 0)
+        parts = []
+        for k in range(nshards):
+            res = ov.candidates_result(m, k, nshards)
+            parts.append(_result_to_tensor(res, 4, dev))
+            res.free()
+        merged = torch.cat(parts, dim=0).contiguous()
+        assert merged.shape[0] < len(whole)          # paired mode: one candidate per mirror pair
+        res = ov.expand_result(merged.data_ptr(), merged.shape[0])
+        got = res.rows()
+        res.free()
+        assert np.array_equal(got, whole)
+        assert np.array_equal(oo.sort_rows(oo.struct_to_rows(got)), want)
+        # garbage in -> loud failure, not garbage rows
+        bad = merged.clone()
+        bad[0, 0] = 10 ** 9
+        with pytest.raises(ValueError):
+            ov.expand_result(bad.data_ptr(), bad.shape[0])
+        ov.close()
