@@ -58,7 +58,9 @@ typedef struct {
     uint32_t bits_per_base;      /* 2 (pure ACGT) or 8 (raw bytes)                          */
     uint32_t kmer;               /* anchor length K = min(64/bits, max(min_length,1))       */
     uint32_t paired;             /* 1: reads are (x, revcomp x) pairs -> one member of each  */
-    uint32_t reserved;           /*    strand-mirror pair verified, the other row mirrored   */
+    uint32_t wide_index;         /*    strand-mirror pair verified, the other row mirrored.  */
+                                 /* wide_index 1: W K-mers per read indexed, word-aligned      */
+                                 /*    probes only (large read sets); 0: prefix + LDS filter  */
     uint64_t n_reads;            /* reads in the handle                                     */
     uint64_t n_eligible;         /* reads with length >= min_length (can be a `b`)          */
     uint64_t total_bases;        /* sum of read lengths (oriented bases B)                  */

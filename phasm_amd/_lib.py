@@ -26,7 +26,7 @@ CAND_DTYPE = np.dtype([("a_idx", "<u4"), ("p", "<u4"), ("b_idx", "<u4"), ("type"
 class PoStats(ctypes.Structure):
     _fields_ = [
         ("bits_per_base", ctypes.c_uint32), ("kmer", ctypes.c_uint32),
-        ("paired", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+        ("paired", ctypes.c_uint32), ("wide_index", ctypes.c_uint32),
         ("n_reads", ctypes.c_uint64), ("n_eligible", ctypes.c_uint64),
         ("total_bases", ctypes.c_uint64), ("shard_bases", ctypes.c_uint64),
         ("n_tiles", ctypes.c_uint64), ("n_candidates", ctypes.c_uint64),

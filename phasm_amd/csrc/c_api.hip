@@ -349,9 +349,19 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     res->count = 0;
     if (n == 0 || n_elig == 0 || ntiles == 0) return PO_OK;
 
+    // ---- index flavour.  narrow: prefix K-mer per read + LDS filter + every position probed (best up
+    // to ~150 k reads: the filter needs ~10 bits per read in 128 KB of LDS).  wide: W K-mers per read,
+    // only word-aligned K-mers of a probed, no filter (linear in the input; needs min_length >= 2W-1).
+    bool wide = n_elig > 160000 && m >= 2 * W - 1;
+    if (const char* e = getenv("PHASM_INDEX")) {
+        if (!strcmp(e, "wide")) wide = m >= 2 * W - 1;
+        if (!strcmp(e, "narrow")) wide = false;
+    }
+    S.wide_index = wide ? 1u : 0u;
+    const uint64_t n_keys = wide ? n_elig * W : n_elig;
     // ---- sizes
     uint32_t tbits = 10;
-    while ((1ull << tbits) < 4 * n_elig) ++tbits;  // load factor <= 0.25: short probe sequences
+    while ((1ull << tbits) < (wide ? 2 : 4) * n_keys) ++tbits;  // narrow: load factor <= 0.25 (short probe sequences)
     if (tbits > 30) return fail(h, PO_ERR_CAPACITY, "too many reads for the anchor table");
     const uint32_t nslots = (1u << tbits) + 1;
     uint32_t bloom_log2 = 13;
@@ -363,9 +373,11 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     PO_TRY(ensure(h, h->d_slot_cnt, (size_t)nslots * 4));
     PO_TRY(ensure(h, h->d_slot_cur, (size_t)nslots * 4));
     PO_TRY(ensure(h, h->d_slot_start, ((size_t)nslots + 1) * 4));
-    PO_TRY(ensure(h, h->d_read_slot, (size_t)n * 4));
-    PO_TRY(ensure(h, h->d_chain, (size_t)n * 4));
-    PO_TRY(ensure(h, h->d_chain_tmp, (size_t)n * 4));
+    const size_t n_entries = wide ? (size_t)n * W : (size_t)n;     // index entries (slots of read_slot / chain)
+    const size_t chain_elem = wide ? 8 : 4;
+    PO_TRY(ensure(h, h->d_read_slot, n_entries * 4));
+    PO_TRY(ensure(h, h->d_chain, n_entries * chain_elem));
+    PO_TRY(ensure(h, h->d_chain_tmp, n_entries * chain_elem));
     PO_TRY(ensure(h, h->d_long_list, (size_t)nslots * 4));
     PO_TRY(ensure(h, h->d_bloom, bloom_bytes));
     PO_TRY(ensure(h, h->d_selfrep, (size_t)n * 4));
@@ -393,20 +405,37 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     HIP_TRY(h, hipMemsetAsync(bloom, 0, bloom_bytes, st));
     hipLaunchKernelGGL(po::k_table_init, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt, slot_cur);
     hipLaunchKernelGGL(po::k_fill_u32, dim3(cdiv(n, 256)), dim3(256), 0, st, selfrep, (uint64_t)n, po::NO_SELFREP);
-    hipLaunchKernelGGL(po::k_table_insert, dim3(cdiv(n, 256)), dim3(256), 0, st, words, woff, len, n, m, kmask, table,
-                       tbits, slot_cnt, read_slot, bloom, bloom_log2, (uint32_t)BITS);
-    PO_TRY(prefix_sum<uint32_t>(h, slot_cnt, nslots, slot_start, &h->pinned[0]));
-    hipLaunchKernelGGL(po::k_chain_fill, dim3(cdiv(n, 256)), dim3(256), 0, st, read_slot, n, slot_start, slot_cur, chain);
-    hipLaunchKernelGGL(po::k_chain_sort_short, dim3(cdiv(nslots, 256)), dim3(256), 0, st, slot_cnt, slot_start, nslots,
-                       chain, h->d_long_list.as<uint32_t>(), n_long);
-    hipLaunchKernelGGL(po::k_chain_sort_long, dim3(64), dim3(256), 0, st, slot_cnt, slot_start,
-                       h->d_long_list.as<uint32_t>(), n_long, chain, h->d_chain_tmp.as<uint32_t>());
-    hipLaunchKernelGGL(po::k_table_finalize, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt, slot_start,
-                       chain, len);
-    if (nshards > 1) {
+    if (!wide) {
+        hipLaunchKernelGGL(po::k_table_insert, dim3(cdiv(n, 256)), dim3(256), 0, st, words, woff, len, n, m, kmask, table,
+                           tbits, slot_cnt, read_slot, bloom, bloom_log2, (uint32_t)BITS);
+        PO_TRY(prefix_sum<uint32_t>(h, slot_cnt, nslots, slot_start, &h->pinned[0]));
+        hipLaunchKernelGGL(po::k_chain_fill, dim3(cdiv(n, 256)), dim3(256), 0, st, read_slot, n, slot_start, slot_cur, chain);
+        hipLaunchKernelGGL(po::k_chain_sort_short<uint32_t>, dim3(cdiv(nslots, 256)), dim3(256), 0, st, slot_cnt, slot_start,
+                           nslots, chain, h->d_long_list.as<uint32_t>(), n_long);
+        hipLaunchKernelGGL(po::k_chain_sort_long<uint32_t>, dim3(64), dim3(256), 0, st, slot_cnt, slot_start,
+                           h->d_long_list.as<uint32_t>(), n_long, chain, h->d_chain_tmp.as<uint32_t>());
+        hipLaunchKernelGGL(po::k_table_finalize, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt,
+                           slot_start, chain, len);
+    } else {
+        uint64_t* chain64 = h->d_chain.as<uint64_t>();
+        hipLaunchKernelGGL(po::k_wide_insert<BITS>, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, words, woff, len, n, m,
+                           table, tbits, slot_cnt, read_slot);
+        PO_TRY(prefix_sum<uint32_t>(h, slot_cnt, nslots, slot_start, &h->pinned[0]));
+        hipLaunchKernelGGL(po::k_wide_chain_fill<BITS>, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, read_slot,
+                           (uint64_t)n_entries, slot_start, slot_cur, chain64);
+        hipLaunchKernelGGL(po::k_chain_sort_short<uint64_t>, dim3(cdiv(nslots, 256)), dim3(256), 0, st, slot_cnt, slot_start,
+                           nslots, chain64, h->d_long_list.as<uint32_t>(), n_long);
+        hipLaunchKernelGGL(po::k_chain_sort_long<uint64_t>, dim3(64), dim3(256), 0, st, slot_cnt, slot_start,
+                           h->d_long_list.as<uint32_t>(), n_long, chain64, h->d_chain_tmp.as<uint64_t>());
+        hipLaunchKernelGGL(po::k_wide_finalize<BITS>, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt,
+                           slot_start, chain64, len);
+    }
+    if (nshards > 1 || wide) {
+        // selfrep of the reads the narrow scan of this call does not visit (sharded call), or of all
+        // reads (wide index: its scan does not look for prefix recurrences)
         const uint32_t blocks = std::min<uint32_t>(cdiv((uint64_t)h->n_tiles * 64, 256), (uint32_t)h->n_cu * 8);
         hipLaunchKernelGGL(po::k_selfrep<BITS>, dim3(blocks), dim3(256), 0, st, words, h->d_tiles.as<po::TileRec>(),
-                           h->n_tiles, tile_begin, tile_end, m, kmask, selfrep);
+                           h->n_tiles, wide ? 0u : tile_begin, wide ? 0u : tile_end, m, kmask, selfrep);
     }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev[EV_INDEX], st));
@@ -433,11 +462,29 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     uint32_t scan_waves = po::SCAN_BLOCK / 64;
     if (const char* e = getenv("PHASM_SCAN_WAVES")) scan_waves = std::max(1, std::min(16, atoi(e)));
     const uint32_t scan_grid = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)h->n_cu, cdiv(ntiles, scan_waves)));
-    const size_t scan_lds = bloom_bytes;
-    if (scan_lds > h->lds_max) return fail(h, PO_ERR_HIP, "device LDS too small for the scan kernel");
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan_probe<BITS>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
-    hipLaunchKernelGGL((po::k_scan_probe<BITS>), dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
+    po::WideArgs WA = {};
+    WA.words = words;
+    WA.tiles = A.tiles;
+    WA.tile_begin = tile_begin;
+    WA.tile_end = tile_end;
+    WA.m = m;
+    WA.table = table;
+    WA.tbits = tbits;
+    WA.chain = h->d_chain.as<uint64_t>();
+    WA.len = len;
+    WA.paired = paired;
+    WA.tile_count = A.tile_count;
+    WA.lane_slot = A.truemask;
+    WA.tile_off = A.tile_off;
+    if (wide) {
+        hipLaunchKernelGGL((po::k_wide_scan<BITS, false>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA);
+    } else {
+        const size_t scan_lds = bloom_bytes;
+        if (scan_lds > h->lds_max) return fail(h, PO_ERR_HIP, "device LDS too small for the scan kernel");
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan_probe<BITS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
+        hipLaunchKernelGGL((po::k_scan_probe<BITS>), dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
+    }
     HIP_TRY(h, hipGetLastError());
     PO_TRY(prefix_sum<uint32_t>(h, A.tile_count + tile_begin, ntiles, h->d_tile_off.as<uint32_t>() + tile_begin, &h->pinned[1]));
     HIP_TRY(h, hipEventRecord(h->ev[EV_COUNT], st));
@@ -460,7 +507,14 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         A.cand_p = h->d_cand_p.as<uint32_t>();
         A.cand_b = h->d_cand_b.as<uint32_t>();
         // ---- scan, fill pass
-        hipLaunchKernelGGL((po::k_scan_fill<BITS>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, A);
+        if (wide) {
+            WA.cand_a = A.cand_a;
+            WA.cand_p = A.cand_p;
+            WA.cand_b = A.cand_b;
+            hipLaunchKernelGGL((po::k_wide_scan<BITS, true>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA);
+        } else {
+            hipLaunchKernelGGL((po::k_scan_fill<BITS>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, A);
+        }
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(h->ev[EV_FILL], st));
         // ---- verify

@@ -245,8 +245,9 @@ __global__ void k_chain_fill(const uint32_t* __restrict__ read_slot, uint32_t n_
 // reads with one prefix) are queued for k_chain_sort_long.
 constexpr uint32_t CHAIN_SHORT = 16;
 
+template <typename E>
 __global__ void k_chain_sort_short(const uint32_t* __restrict__ slot_cnt, const uint32_t* __restrict__ slot_start,
-                                   uint32_t nslots, uint32_t* chain, uint32_t* long_list, uint32_t* n_long) {
+                                   uint32_t nslots, E* chain, uint32_t* long_list, uint32_t* n_long) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nslots) return;
     const uint32_t c = slot_cnt[i];
@@ -255,9 +256,9 @@ __global__ void k_chain_sort_short(const uint32_t* __restrict__ slot_cnt, const 
         long_list[atomicAdd(n_long, 1u)] = i;
         return;
     }
-    uint32_t* v = chain + slot_start[i];
+    E* v = chain + slot_start[i];
     for (uint32_t x = 1; x < c; ++x) {
-        uint32_t key = v[x];
+        E key = v[x];
         uint32_t y = x;
         while (y > 0 && v[y - 1] > key) {
             v[y] = v[y - 1];
@@ -268,21 +269,219 @@ __global__ void k_chain_sort_short(const uint32_t* __restrict__ slot_cnt, const 
 }
 
 // One workgroup per long chain: rank sort through a scratch copy (read indices are distinct).
+template <typename E>
 __global__ void k_chain_sort_long(const uint32_t* __restrict__ slot_cnt, const uint32_t* __restrict__ slot_start,
                                   const uint32_t* __restrict__ long_list, const uint32_t* __restrict__ n_long,
-                                  uint32_t* chain, uint32_t* scratch) {
+                                  E* chain, E* scratch) {
     for (uint32_t li = blockIdx.x; li < *n_long; li += gridDim.x) {
         const uint32_t s = long_list[li];
         const uint32_t c = slot_cnt[s], st = slot_start[s];
         for (uint32_t x = threadIdx.x; x < c; x += blockDim.x) scratch[st + x] = chain[st + x];
         __syncthreads();
         for (uint32_t x = threadIdx.x; x < c; x += blockDim.x) {
-            const uint32_t v = scratch[st + x];
+            const E v = scratch[st + x];
             uint32_t rank = 0;
             for (uint32_t y = 0; y < c; ++y) rank += scratch[st + y] < v;
             chain[st + rank] = v;
         }
         __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// wide index (large read sets)
+// ----------------------------------------------------------------------------------------
+// The LDS filter of the position scan holds ~10 bits per read prefix at up to ~150 k reads; beyond
+// that it stops filtering and every position would reach the table.  For large read sets the roles
+// are swapped: index the K-mers at the first W offsets j = 0..W-1 of every read b (W = bases per
+// word, K = W) and probe only the WORD-ALIGNED K-mers of a -- the packed words themselves, no
+// shifts, no filter.  An overlap (a, p, b) of length >= 2W-1 is found exactly once: at the word of a
+// that starts at p + j with j = (-p) mod W.  Work is one table probe per word of a (1/W of the
+// positions) against a table of W entries per read: linear in the input, at the price of random
+// access into a table that lives in HBM.  Needs min_length >= 2W-1 (63 bases at 2 bit).
+//
+// Slot: {key, start, count} as in the narrow index.  Chain entries are 64-bit (W-1-j) << 32 | b, so
+// that ascending order = ascending candidate position p = W*word - j, then ascending b.  One-entry
+// chains are embedded: start = b, count = SLOT_SINGLE | j << 26 | len[b]  (len < 2^26).
+constexpr uint32_t WIDE_LEN_BITS = 26;
+
+template <int BITS>
+__global__ void k_wide_insert(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
+                              const uint32_t* __restrict__ len, uint32_t n_reads, uint32_t m, Slot* tab,
+                              uint32_t tbits, uint32_t* slot_cnt, uint32_t* entry_slot) {
+    constexpr uint32_t W = 64 / BITS;
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)n_reads * W) return;
+    const uint32_t r = (uint32_t)(e / W), j = (uint32_t)(e % W);
+    if (len[r] < m) {
+        entry_slot[e] = 0xFFFFFFFFu;
+        return;
+    }
+    const uint64_t* __restrict__ rw = words + woff[r];
+    const uint64_t key = funnel(rw[0], rw[1], j * BITS);  // m >= 2W-1: the K-mer at offset j is inside the read
+    const uint32_t tmask = (1u << tbits) - 1u;
+    uint32_t h1, h2;
+    kmer_hash(key, h1, h2);
+    uint32_t i;
+    if (key == KEY_EMPTY) {
+        i = tmask + 1u;
+    } else {
+        i = h1 >> (32 - tbits);
+        for (;;) {
+            unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[i].key),
+                                                (unsigned long long)KEY_EMPTY, (unsigned long long)key);
+            if (prev == KEY_EMPTY || prev == key) break;
+            i = (i + 1u) & tmask;
+        }
+    }
+    atomicAdd(&slot_cnt[i], 1u);
+    entry_slot[e] = i;
+}
+
+template <int BITS>
+__global__ void k_wide_chain_fill(const uint32_t* __restrict__ entry_slot, uint64_t n_entries,
+                                  const uint32_t* __restrict__ slot_start, uint32_t* slot_cur, uint64_t* chain) {
+    constexpr uint32_t W = 64 / BITS;
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_entries) return;
+    const uint32_t s = entry_slot[e];
+    if (s == 0xFFFFFFFFu) return;
+    const uint32_t r = (uint32_t)(e / W), j = (uint32_t)(e % W);
+    chain[slot_start[s] + atomicAdd(&slot_cur[s], 1u)] = ((uint64_t)(W - 1 - j) << 32) | r;
+}
+
+template <int BITS>
+__global__ void k_wide_finalize(Slot* tab, uint32_t nslots, const uint32_t* __restrict__ slot_cnt,
+                                const uint32_t* __restrict__ slot_start, const uint64_t* __restrict__ chain,
+                                const uint32_t* __restrict__ len) {
+    constexpr uint32_t W = 64 / BITS;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nslots) return;
+    const uint32_t c = slot_cnt[i];
+    tab[i].start = slot_start[i];
+    tab[i].count = c;
+    if (c == 1) {
+        const uint64_t e = chain[slot_start[i]];
+        const uint32_t b = (uint32_t)e, j = W - 1 - (uint32_t)(e >> 32);
+        const uint32_t lb = len[b];
+        if (lb < (1u << WIDE_LEN_BITS)) {
+            tab[i].start = b;
+            tab[i].count = SLOT_SINGLE | (j << WIDE_LEN_BITS) | lb;
+        }
+    }
+}
+
+// candidates of the word-aligned K-mer at base offset pw of read a, given the slot it found
+template <int BITS, typename F>
+__device__ inline void for_each_candidate_wide(const uint64_t* __restrict__ chain, const uint32_t* __restrict__ len,
+                                               uint32_t paired, uint32_t z, uint32_t w, uint32_t a, uint32_t la,
+                                               uint32_t pw, uint32_t m, F&& f) {
+    constexpr uint32_t W = 64 / BITS;
+    auto one = [&](uint32_t b, uint32_t j, uint32_t lb) __attribute__((always_inline)) {
+        if (j > pw) return;            // p = pw - j would be negative
+        const uint32_t p = pw - j;
+        if (p + m > la) return;        // too close to the end of a to reach min_length
+        const uint32_t k = keep_bits(a, b, la - p, lb, paired);
+        if (k) f(b, p, k);
+    };
+    if (w & SLOT_SINGLE) {
+        one(z, (w >> WIDE_LEN_BITS) & (W - 1), w & ((1u << WIDE_LEN_BITS) - 1u));
+    } else {
+        for (uint32_t i = 0; i < w; ++i) {
+            const uint64_t e = chain[z + i];
+            const uint32_t b = (uint32_t)e;
+            one(b, W - 1 - (uint32_t)(e >> 32), len[b]);
+        }
+    }
+}
+
+struct WideArgs {
+    const uint64_t* words;
+    const TileRec* tiles;
+    uint32_t tile_begin, tile_end;
+    uint32_t m;
+    const Slot* table;
+    uint32_t tbits;
+    const uint64_t* chain;
+    const uint32_t* len;
+    uint32_t paired;
+    uint32_t* tile_count;
+    uint32_t* lane_slot;   // per (tile, lane): slot index + 1 of the word's K-mer, 0 = no candidates
+    const uint32_t* tile_off;
+    uint32_t* cand_a;
+    uint32_t* cand_p;
+    uint32_t* cand_b;
+};
+
+// One wave per tile, one word per lane: probe the table with the word itself.  FILL = false: count
+// candidates per tile and remember the slot per lane; FILL = true: write the candidates.
+template <int BITS, bool FILL>
+__global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A) {
+    constexpr uint32_t W = 64 / BITS;
+    const uint32_t lane = lane_id();
+    const uint32_t t = __builtin_amdgcn_readfirstlane(A.tile_begin + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (t >= A.tile_end) return;
+    const TileRec rec = A.tiles[t];
+    const uint32_t a = rec.read, la = rec.la;
+    const uint32_t wi = rec.word0 + lane;
+    const uint32_t pw = wi * W;
+    const size_t li = (size_t)t * WAVE + lane;
+    uint32_t n = 0, z = 0, w = 0, slot1 = 0;
+    const bool live = la >= A.m && pw + W <= la;  // the word lies wholly inside the read
+    if (!FILL) {
+        if (live) {
+            const uint64_t kmer = A.words[rec.wabs + lane];
+            const uint32_t tmask = (1u << A.tbits) - 1u;
+            uint32_t i;
+            if (kmer == KEY_EMPTY) {
+                i = tmask + 1u;
+                const u32x4 s = *reinterpret_cast<const u32x4*>(&A.table[i]);
+                z = s.z;
+                w = s.w;
+            } else {
+                uint32_t h1, h2;
+                kmer_hash(kmer, h1, h2);
+                i = h1 >> (32 - A.tbits);
+                for (;;) {
+                    const u32x4 s = *reinterpret_cast<const u32x4*>(&A.table[i]);
+                    if (s.w == 0) break;
+                    if ((((uint64_t)s.y << 32) | s.x) == kmer) {
+                        z = s.z;
+                        w = s.w;
+                        break;
+                    }
+                    i = (i + 1u) & tmask;
+                }
+            }
+            if (w) {
+                for_each_candidate_wide<BITS>(A.chain, A.len, A.paired, z, w, a, la, pw, A.m,
+                                              [&](uint32_t, uint32_t, uint32_t) { ++n; });
+                if (n) slot1 = i + 1u;
+            }
+        }
+        A.lane_slot[li] = slot1;
+        const uint32_t tot = wave_sum(n);
+        if (lane == 0) A.tile_count[t] = tot;
+    } else {
+        slot1 = A.lane_slot[li];
+        if (slot1) {
+            const u32x4 s = *reinterpret_cast<const u32x4*>(&A.table[slot1 - 1u]);
+            z = s.z;
+            w = s.w;
+            for_each_candidate_wide<BITS>(A.chain, A.len, A.paired, z, w, a, la, pw, A.m,
+                                          [&](uint32_t, uint32_t, uint32_t) { ++n; });
+        }
+        const uint32_t inc = wave_incl_scan(n);
+        uint32_t off = A.tile_off[t] + inc - n;
+        if (n) {
+            for_each_candidate_wide<BITS>(A.chain, A.len, A.paired, z, w, a, la, pw, A.m,
+                                          [&](uint32_t b, uint32_t p, uint32_t) {
+                                              A.cand_a[off] = a;
+                                              A.cand_p[off] = p;
+                                              A.cand_b[off] = b;
+                                              ++off;
+                                          });
+        }
     }
 }
 

@@ -190,3 +190,75 @@ def test_compact_candidates_then_expand_equals_rows(nshards):
         with pytest.raises(ValueError):
             ov.expand_result(bad.data_ptr(), bad.shape[0])
         ov.close()
+
+
+@pytest.mark.parametrize("waves", ["1", "3", "16"])
+def test_scan_pipeline_many_tiles_per_wave(waves, monkeypatch):
+    """The scan kernel is a hand-scheduled load pipeline (counted s_waitcnt, in-flight landing
+    registers).  Few waves per workgroup = many tiles per wave = the steady state of that pipeline;
+    a mis-counted wait shows up as run-to-run differences, so run it repeatedly."""
+    monkeypatch.setenv("PHASM_SCAN_WAVES", waves)
+    _, seqs, m, want = gu.ladder_case("ladder_cfg2_mini")
+    for _ in range(3):
+        got, _ = hip_rows(seqs, m)
+        assert np.array_equal(got, want)
+    monkeypatch.setenv("PHASM_NO_MIRROR", "1")
+    got, _ = hip_rows(seqs, m)
+    assert np.array_equal(got, want)
+
+
+def test_long_reads_take_the_global_verify_path():
+    """Reads longer than the 64 KB LDS staging limit (262 144 bases at 2 bit) are compared straight
+    from global memory."""
+    rng = np.random.default_rng(21)
+    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=700_000)].tobytes()
+    reads = [genome[0:400_000], genome[150_000:600_000], genome[390_000:700_000], genome[100_000:130_000],
+             genome[399_000:400_500]]
+    rc = bytes.maketrans(b"ACGT", b"TGCA")
+    seqs = []
+    for r in reads:
+        seqs += [r, r.translate(rc)[::-1]]
+    got, st = hip_rows(seqs, 1000)
+    assert st["paired"] == 1
+    want = oo.oracle_overlaps(seqs, 1000)
+    assert len(want) >= 8
+    assert np.array_equal(got, want)
+
+
+def test_wide_index_matches_goldens(monkeypatch):
+    """Large-read-set flavour of the scan (W K-mers per read, word-aligned probes), forced on small
+    goldens: ladders (2-bit), low-complexity repeats, shards, mirror off, and 8-bit reads."""
+    monkeypatch.setenv("PHASM_INDEX", "wide")
+    for name in gu.LADDER_NAMES:
+        _, seqs, m, want = gu.ladder_case(name)
+        got, st = hip_rows(seqs, m)
+        assert st["wide_index"] == 1, name
+        assert np.array_equal(got, want), name
+    for name, seqs, m, want in gu.repeats_cases():
+        got, st = hip_rows(seqs, m)
+        assert st["wide_index"] == (1 if m >= 63 else 0)   # needs min_length >= 2W-1
+        assert np.array_equal(got, want), name
+    _, seqs, m, want = gu.ladder_case("ladder_varlen")
+    got, _ = hip_rows(seqs, m, shard=3)
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("PHASM_NO_MIRROR", "1")
+    got, st = hip_rows(seqs, m)
+    assert st["paired"] == 0 and np.array_equal(got, want)
+    # 8-bit reads: W = 8, needs min_length >= 15
+    rng = np.random.default_rng(6)
+    alpha = np.frombuffer(b"ACGTNacgt", dtype=np.uint8)
+    genome = alpha[rng.integers(0, len(alpha), size=5000)].tobytes()
+    seqs8 = [genome[st:st + ln] for st, ln in zip(rng.integers(0, 4000, size=120), rng.integers(30, 900, size=120))]
+    for m8 in (15, 40):
+        got, st = hip_rows(seqs8, m8)
+        assert st["bits_per_base"] == 8 and st["wide_index"] == 1
+        assert np.array_equal(got, oo.oracle_overlaps(seqs8, m8)), m8
+
+
+def test_wide_index_midsize_against_oracle(monkeypatch):
+    monkeypatch.setenv("PHASM_INDEX", "wide")
+    cfg = synth.scaled(synth.CONFIGS["cfg2"], 2000)
+    seqs = [s for _, s in synth.oriented(synth.generate_reads(cfg))]
+    got, st = hip_rows(seqs, 1000)
+    assert st["wide_index"] == 1
+    assert np.array_equal(got, oo.oracle_overlaps(seqs, 1000))
