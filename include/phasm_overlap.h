@@ -137,6 +137,10 @@ const void* po_result_device_rows(const po_result* r);
 po_status po_result_copy_to_device(po_result* r, void* dst_device);
 void po_result_free(po_result* r);
 
+/* Write one GFA2 edge line per row to the file descriptor, byte-identical to the reference's
+ * gfa_line("E", "*", a_id, b_id, astart, aend, bstart, bend, "*")  (assembler.py:46-48, gfa.py:230-231). */
+po_status po_write_gfa_edges(po_result* r, int fd, uint64_t* lines_out);
+
 po_status po_get_stats(const po_handle* h, po_stats* out);
 const char* po_last_error(const po_handle* h);
 int po_abi_version(void);

@@ -64,6 +64,7 @@ SYMBOLS = [
     ("po_result_device_rows", ctypes.c_void_p, [_P]),
     ("po_result_copy_to_device", ctypes.c_int, [_P, ctypes.c_void_p]),
     ("po_result_free", None, [_P]),
+    ("po_write_gfa_edges", ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
     ("po_get_stats", ctypes.c_int, [_P, ctypes.POINTER(PoStats)]),
     ("po_last_error", ctypes.c_char_p, [_P]),
 ]

@@ -30,11 +30,22 @@ def overlap(args) -> int:
         args.output.write(gfa.gfa_line("S", name, len(seq), "*"))
         overlapper.add_sequence(name + "+", seq)
         overlapper.add_sequence(name + "-", reverse_complement(seq))
-    rows = overlapper.overlaps_array(args.min_length)
-    logger.info("Writing %d overlaps to GFA2...", len(rows))
-    gfa.write_edges(args.output, rows, overlapper.ids())
+    res = overlapper.overlaps_result(args.min_length)
+    logger.info("Writing %d overlaps to GFA2...", len(res))
+    try:
+        try:
+            args.output.fileno()
+            native = True
+        except (AttributeError, OSError, ValueError):
+            native = False
+        if native:
+            n = res.write_gfa_edges(args.output)       # formatted in C, straight to the descriptor
+        else:
+            n = gfa.write_edges(args.output, res.rows(), overlapper.ids())
+    finally:
+        res.free()
     logger.info("Done.")
-    return len(rows)
+    return n
 
 
 def main(argv=None) -> int:

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -841,6 +843,69 @@ void po_result_free(po_result* r) {
     }
     r->d_rows.release();
     delete r;
+}
+
+// GFA2 edge lines for every row, byte-identical to the reference's
+// gfa_line("E", "*", a_id, b_id, astart, aend, bstart, bend, "*")  (assembler.py:46-48, gfa.py:230-231).
+po_status po_write_gfa_edges(po_result* r, int fd, uint64_t* lines_out) {
+    if (!r || fd < 0) return PO_ERR_INVALID;
+    po_handle* h = r->h;
+    if (r->elem != sizeof(po_row)) return fail(h, PO_ERR_INVALID, "po_write_gfa_edges needs a row result");
+    if (lines_out) *lines_out = 0;
+    if (r->count == 0) return PO_OK;
+    const po_row* rows = po_result_rows(r);
+    if (!rows) return PO_ERR_HIP;
+    try {
+        std::string buf;
+        buf.reserve(1 << 22);
+        auto put_int = [&](long long v) {
+            char tmp[24];
+            int n = 0;
+            bool neg = v < 0;
+            unsigned long long u = neg ? 0ull - (unsigned long long)v : (unsigned long long)v;
+            do {
+                tmp[n++] = (char)('0' + u % 10);
+                u /= 10;
+            } while (u);
+            if (neg) buf.push_back('-');
+            while (n) buf.push_back(tmp[--n]);
+        };
+        auto flush = [&]() -> bool {
+            const char* p = buf.data();
+            size_t left = buf.size();
+            while (left) {
+                ssize_t w = ::write(fd, p, left);
+                if (w < 0) return false;
+                p += w;
+                left -= (size_t)w;
+            }
+            buf.clear();
+            return true;
+        };
+        for (uint64_t i = 0; i < r->count; ++i) {
+            const po_row& x = rows[i];
+            if (x.a_idx >= h->ids.size() || x.b_idx >= h->ids.size()) return fail(h, PO_ERR_INVALID, "row names an unknown read");
+            buf.append("E\t*\t");
+            buf.append(h->ids[x.a_idx]);
+            buf.push_back('\t');
+            buf.append(h->ids[x.b_idx]);
+            buf.push_back('\t');
+            put_int(x.astart);
+            buf.push_back('\t');
+            put_int(x.aend);
+            buf.push_back('\t');
+            put_int(x.bstart);
+            buf.push_back('\t');
+            put_int(x.bend);
+            buf.append("\t*\n");
+            if (buf.size() > (1u << 22) - 4096 && !flush()) return fail(h, PO_ERR_INVALID, "write failed");
+        }
+        if (!flush()) return fail(h, PO_ERR_INVALID, "write failed");
+    } catch (const std::bad_alloc&) {
+        return fail(h, PO_ERR_NOMEM, "out of host memory");
+    }
+    if (lines_out) *lines_out = r->count;
+    return PO_OK;
 }
 
 po_status po_get_stats(const po_handle* h, po_stats* out) {

@@ -74,6 +74,13 @@ class OverlapResult:
         buf = (ctypes.c_char * (n * self._dtype.itemsize)).from_address(p)
         return np.frombuffer(buf, dtype=self._dtype).copy()
 
+    def write_gfa_edges(self, fileobj) -> int:
+        """Native bulk writer of the GFA2 ``E`` lines (``po_write_gfa_edges``) to a real file."""
+        fileobj.flush()
+        n = ctypes.c_uint64()
+        _check(self._owner._h, self._lib.po_write_gfa_edges(self._ptr, fileobj.fileno(), ctypes.byref(n)))
+        return int(n.value)
+
     def device_ptr(self) -> int:
         return int(self._lib.po_result_device_rows(self._ptr) or 0)
 

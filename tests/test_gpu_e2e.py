@@ -37,6 +37,25 @@ def test_cli_overlap_writes_reference_lines(tmp_path):
     assert sorted(e_lines) == want_lines
 
 
+def test_native_and_python_edge_writers_agree(tmp_path):
+    _, seqs, m, want = gu.ladder_case("ladder_varlen")
+    ov = ExactOverlapper()
+    ids = []
+    for i, s in enumerate(seqs):
+        ids.append("read %d/x%s" % (i // 2, "+-"[i % 2]))
+        ov.add_sequence(ids[-1], s)
+    res = ov.overlaps_result(m)
+    path = tmp_path / "edges.gfa"
+    with open(path, "w") as f:
+        f.write("H\tVN:z:2.0\n")
+        assert res.write_gfa_edges(f) == len(want)
+    py = io.StringIO()
+    gfa.write_edges(py, res.rows(), ids)
+    res.free()
+    ov.close()
+    assert path.read_text() == "H\tVN:z:2.0\n" + py.getvalue()
+
+
 def test_merge_helper_single_gpu():
     from phasm_amd.dist import rows_tensor_to_struct, sharded_overlaps
     _, seqs, m, want = gu.ladder_case("ladder_varlen")
