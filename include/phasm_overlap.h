@@ -93,6 +93,12 @@ po_status po_set_device(po_handle* h, int device);
  * other than upper-case A/C/G/T switches the handle to the 8-bit representation.           */
 po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const char* seq, size_t seq_len);
 
+/* FASTA ingest for `phasm overlap` (the reference uses dinopy.FastaReader / dinopy.reverse_complement,
+ * phasm/cli/assembler.py:32-40): the record name is the whole header line, sequence lines are joined,
+ * blank lines skipped.  both_strands != 0 adds every record as name+"+" / sequence and name+"-" /
+ * reverse complement, exactly what the CLI feeds the overlapper (:38-40). */
+po_status po_add_fasta(po_handle* h, const char* path, int both_strands, uint64_t* n_records);
+
 uint32_t po_num_sequences(const po_handle* h);
 po_status po_get_id(const po_handle* h, uint32_t idx, const char** id, size_t* id_len);
 uint32_t po_get_length(const po_handle* h, uint32_t idx);

@@ -50,6 +50,7 @@ SYMBOLS = [
     ("po_destroy", None, [_P]),
     ("po_set_device", ctypes.c_int, [_P, ctypes.c_int]),
     ("po_add_sequence", ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]),
+    ("po_add_fasta", ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
     ("po_num_sequences", ctypes.c_uint32, [_P]),
     ("po_get_id", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]),
     ("po_get_length", ctypes.c_uint32, [_P, ctypes.c_uint32]),

@@ -26,10 +26,17 @@ def overlap(args) -> int:
     args.output.write(gfa.gfa_header())
     overlapper = ExactOverlapper(device=getattr(args, "device", None))
     logger.info("Packing reads and searching for pairwise overlaps on the GPU...")
-    for name, seq in read_fasta(args.fasta_input):
-        args.output.write(gfa.gfa_line("S", name, len(seq), "*"))
-        overlapper.add_sequence(name + "+", seq)
-        overlapper.add_sequence(name + "-", reverse_complement(seq))
+    if isinstance(args.fasta_input, (str, bytes)) and not getattr(args, "python_ingest", False):
+        # native parse + reverse complement + 2-bit pack in one pass (po_add_fasta)
+        overlapper.add_fasta(args.fasta_input, both_strands=True)
+        ids, lens = overlapper.ids(), overlapper.lengths()
+        for i in range(0, len(ids), 2):
+            args.output.write(gfa.gfa_line("S", ids[i][:-1], int(lens[i]), "*"))
+    else:
+        for name, seq in read_fasta(args.fasta_input):
+            args.output.write(gfa.gfa_line("S", name, len(seq), "*"))
+            overlapper.add_sequence(name + "+", seq)
+            overlapper.add_sequence(name + "-", reverse_complement(seq))
     res = overlapper.overlaps_result(args.min_length)
     logger.info("Writing %d overlaps to GFA2...", len(res))
     try:
@@ -58,6 +65,7 @@ def main(argv=None) -> int:
     p.add_argument("-o", "--output", type=argparse.FileType("w"), default=sys.stdout,
                    help="Output file (default: stdout)")
     p.add_argument("--device", type=int, default=None, help="HIP device ordinal (default 0)")
+    p.add_argument("--python-ingest", action="store_true", help="parse the FASTA in Python instead of po_add_fasta")
     p.add_argument("fasta_input", help="FASTA file with reads")
     p.set_defaults(func=overlap)
     args = parser.parse_args(argv)

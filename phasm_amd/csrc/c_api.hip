@@ -702,6 +702,90 @@ po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const cha
     return PO_OK;
 }
 
+// FASTA ingest for the overlap command (the reference delegates this to dinopy.FastaReader and
+// dinopy.reverse_complement, assembler.py:32-40): header = the whole line after '>', sequence lines
+// concatenated, blank lines skipped, bytes kept as they are; with both_strands every record is added
+// as name+"+" / sequence and name+"-" / reverse complement (IUPAC-aware, case preserving).
+po_status po_add_fasta(po_handle* h, const char* path, int both_strands, uint64_t* n_records) {
+    if (!h || !path) return PO_ERR_INVALID;
+    if (n_records) *n_records = 0;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(h, PO_ERR_INVALID, std::string("cannot open ") + path);
+    static unsigned char comp[256];
+    static bool comp_init = false;
+    if (!comp_init) {
+        for (int i = 0; i < 256; ++i) comp[i] = (unsigned char)i;
+        const char* from = "ACGTURYKMBVDHSWNacgturykmbvdhswn";
+        const char* to = "TGCAAYRMKVBHDSWNtgcaayrmkvbhdswn";
+        for (int i = 0; from[i]; ++i) comp[(unsigned char)from[i]] = (unsigned char)to[i];
+        comp_init = true;
+    }
+    po_status st = PO_OK;
+    uint64_t nrec = 0;
+    try {
+        std::string name, seq, rc, line;
+        bool have = false;
+        std::vector<char> buf(1 << 22);
+        auto flush_record = [&]() -> po_status {
+            if (!have) return PO_OK;
+            ++nrec;
+            if (!both_strands) return po_add_sequence(h, name.data(), name.size(), seq.data(), seq.size());
+            std::string id = name + "+";
+            po_status s1 = po_add_sequence(h, id.data(), id.size(), seq.data(), seq.size());
+            if (s1 != PO_OK) return s1;
+            rc.resize(seq.size());
+            for (size_t i = 0, n = seq.size(); i < n; ++i) rc[i] = (char)comp[(unsigned char)seq[n - 1 - i]];
+            id.back() = '-';
+            return po_add_sequence(h, id.data(), id.size(), rc.data(), rc.size());
+        };
+        auto handle_line = [&](const char* p, size_t n) -> po_status {
+            while (n && (p[n - 1] == '\r' || p[n - 1] == '\n')) --n;
+            if (n == 0) return PO_OK;
+            if (p[0] == '>') {
+                po_status s1 = flush_record();
+                if (s1 != PO_OK) return s1;
+                name.assign(p + 1, n - 1);
+                seq.clear();
+                have = true;
+            } else if (have) {
+                while (n && (p[n - 1] == ' ' || p[n - 1] == '\t')) --n;
+                size_t b = 0;
+                while (b < n && (p[b] == ' ' || p[b] == '\t')) ++b;
+                seq.append(p + b, n - b);
+            }
+            return PO_OK;
+        };
+        size_t got;
+        while (st == PO_OK && (got = std::fread(buf.data(), 1, buf.size(), f)) > 0) {
+            size_t pos = 0;
+            while (pos < got && st == PO_OK) {
+                const char* nl = static_cast<const char*>(std::memchr(buf.data() + pos, '\n', got - pos));
+                if (!nl) {
+                    line.append(buf.data() + pos, got - pos);
+                    pos = got;
+                } else {
+                    const size_t len = (size_t)(nl - (buf.data() + pos)) + 1;
+                    if (line.empty()) {
+                        st = handle_line(buf.data() + pos, len);
+                    } else {
+                        line.append(buf.data() + pos, len);
+                        st = handle_line(line.data(), line.size());
+                        line.clear();
+                    }
+                    pos += len;
+                }
+            }
+        }
+        if (st == PO_OK && !line.empty()) st = handle_line(line.data(), line.size());
+        if (st == PO_OK) st = flush_record();
+    } catch (const std::bad_alloc&) {
+        st = fail(h, PO_ERR_NOMEM, "out of host memory in po_add_fasta");
+    }
+    std::fclose(f);
+    if (n_records) *n_records = nrec;
+    return st;
+}
+
 uint32_t po_num_sequences(const po_handle* h) { return h ? (uint32_t)h->len.size() : 0; }
 
 po_status po_get_id(const po_handle* h, uint32_t idx, const char** id, size_t* id_len) {

@@ -19,6 +19,7 @@ so callers that want throughput do not have to build millions of Python tuples.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -116,6 +117,13 @@ class ExactOverlapper:
         bid = _to_bytes(id, "id")
         bseq = _to_bytes(seq, "seq")
         _check(self._h, self._lib.po_add_sequence(self._h, bid, len(bid), bseq, len(bseq)))
+
+    def add_fasta(self, path: str, both_strands: bool = True) -> int:
+        """Native FASTA ingest (``po_add_fasta``): every record as ``name+`` / sequence and ``name-`` /
+        reverse complement, as ``phasm overlap`` adds them (assembler.py:38-40).  Returns the record count."""
+        n = ctypes.c_uint64()
+        _check(self._h, self._lib.po_add_fasta(self._h, os.fsencode(path), 1 if both_strands else 0, ctypes.byref(n)))
+        return int(n.value)
 
     def overlaps(self, min_length: int) -> List[OverlapT]:
         arr = self.overlaps_array(min_length)

@@ -26,6 +26,9 @@ def test_cli_overlap_writes_reference_lines(tmp_path):
     synth.write_fasta(str(fa), reads, width=70)           # multi-line records
     out = tmp_path / "out.gfa"
     assert cli.main(["overlap", str(fa), "-l", str(m), "-o", str(out)]) == 0
+    out_py = tmp_path / "out_py.gfa"
+    assert cli.main(["overlap", str(fa), "-l", str(m), "-o", str(out_py), "--python-ingest"]) == 0
+    assert out.read_bytes() == out_py.read_bytes()   # native ingest == Python ingest, byte for byte
     lines = out.read_text().splitlines(keepends=True)
     assert lines[0] == "H\tVN:z:2.0\n"
     s_lines = [l for l in lines if l.startswith("S\t")]

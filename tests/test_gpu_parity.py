@@ -262,3 +262,46 @@ def test_wide_index_midsize_against_oracle(monkeypatch):
     got, st = hip_rows(seqs, 1000)
     assert st["wide_index"] == 1
     assert np.array_equal(got, oo.oracle_overlaps(seqs, 1000))
+
+
+@pytest.mark.parametrize("index", ["narrow", "wide"])
+def test_seeded_fuzz_against_oracle(index, monkeypatch):
+    """Random read sets the goldens do not cover: mixed lengths around the word/tile boundaries
+    (31..33, 63..65, 2047..2049 bases), tandem repeats, duplicated and contained reads, both strands or
+    not, min_length from 1 up, both index flavours -- HIP rows must equal the CPU oracle's."""
+    monkeypatch.setenv("PHASM_INDEX", index)
+    rng = np.random.default_rng(2024)
+    rc = bytes.maketrans(b"ACGT", b"TGCA")
+    for trial in range(40):
+        glen = int(rng.integers(300, 6000))
+        if rng.random() < 0.3:   # low-complexity genome
+            unit = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=int(rng.integers(1, 12))))
+            genome = (unit * (glen // len(unit) + 1))[:glen]
+            genome = bytearray(genome)
+            for pos in rng.integers(0, glen, size=glen // 50):
+                genome[pos] = b"ACGT"[rng.integers(4)]
+            genome = bytes(genome)
+        else:
+            genome = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=glen))
+        special = [31, 32, 33, 63, 64, 65, 127, 128, 129, 2047, 2048, 2049]
+        reads = []
+        for _ in range(int(rng.integers(4, 60))):
+            ln = int(rng.choice(special)) if rng.random() < 0.3 else int(rng.integers(1, 2500))
+            ln = min(ln, glen)
+            st = int(rng.integers(0, glen - ln + 1))
+            r = genome[st:st + ln]
+            if rng.random() < 0.5:
+                r = r.translate(rc)[::-1]
+            reads.append(r)
+            if rng.random() < 0.1:
+                reads.append(r)                       # exact duplicate
+        if rng.random() < 0.6:                        # both strands, as the CLI adds them
+            seqs = []
+            for r in reads:
+                seqs += [r, r.translate(rc)[::-1]]
+        else:
+            seqs = reads
+        m = int(rng.choice([1, 2, 5, 31, 32, 33, 62, 63, 64, 100, 500]))
+        got, st = hip_rows(seqs, m)
+        want = oo.oracle_overlaps(seqs, m)
+        assert np.array_equal(got, want), (trial, m, len(seqs), st["wide_index"], st["paired"])

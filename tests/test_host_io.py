@@ -55,3 +55,27 @@ def test_generator_is_seeded_and_shaped():
     assert c1.len_sd > 0 and synth.CONFIGS["cfg2"].n_reads == 50_000
     sc = synth.scaled(synth.CONFIGS["cfg2"], 800)
     assert sc.genome_len == 80_000 and sc.n_reads == 800
+
+
+def test_native_fasta_ingest_matches_python_reader(tmp_path):
+    from phasm_amd.overlapper import ExactOverlapper
+    txt = (b">read1 some description\nACGT\nacgt\n\n>read2\r\n\nNNNN\r\nAC \n>empty\n>last|x y\nTTGACGTTGCAAGGT\nAC")
+    path = tmp_path / "r.fasta"
+    path.write_bytes(txt)
+    recs = list(read_fasta(str(path)))
+    ov = ExactOverlapper()
+    assert ov.add_fasta(str(path)) == len(recs) == 4
+    want_ids, want_len = [], []
+    for name, seq in recs:
+        want_ids += [name + "+", name + "-"]
+        want_len += [len(seq), len(seq)]
+    assert ov.ids() == want_ids
+    assert ov.lengths().tolist() == want_len
+    single = ExactOverlapper()
+    assert single.add_fasta(str(path), both_strands=False) == 4
+    assert single.ids() == [n for n, _ in recs]
+    import pytest
+    with pytest.raises(ValueError):
+        single.add_fasta(str(tmp_path / "missing.fasta"))
+    ov.close()
+    single.close()
