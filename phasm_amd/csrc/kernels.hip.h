@@ -199,11 +199,11 @@ __global__ void k_table_insert(const uint64_t* __restrict__ words, const uint64_
     read_slot[r] = i;
     if (bits == 2) {
         // 2-bit reads: 64-bit blocks addressed by sequence bits themselves (uniform for DNA, no
-        // multiply): block = bits 5.. of the first 16 bases, one bit in the block's low word from
-        // bases 0-2, one in its high word from bases 16-18.  See filter_tile<2>.
+        // multiply): block = bits 5.. of the first 16 bases, two bits in the block's low word (from
+        // bases 0-2 and 9-11), one in its high word (from bases 16-18).  See filter_tile<2>.
         const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
         const uint32_t blk = (lo >> 5) & ((1u << (bloom_log2 - 6)) - 1u);
-        atomicOr(&bloom[2 * blk], 1u << (lo & 31));
+        atomicOr(&bloom[2 * blk], (1u << (lo & 31)) | (1u << ((lo >> 19) & 31)));
         atomicOr(&bloom[2 * blk + 1], 1u << (hi & 31));
     } else {
         uint32_t bword, bmask;
@@ -519,9 +519,11 @@ __device__ inline uint64_t window(uint64_t w0, uint64_t w1, int s) {
 // filter; bit s of the result = position s passes.
 //  BITS == 8: hashed blocked Bloom filter, 32-bit blocks, 3 bits per key (bloom_slot).
 //  BITS == 2: the packed bases are already uniform bits, so no hash: T[s] = the 32 bits of the read
-//  starting at base s; a K-mer's block is T[s] bits 5.., its two bits are T[s] & 31 in the block's
-//  low word and T[s+16] & 31 (bases 16-18) in its high word.  One ds_read_b64 and ~10 VALU ops per
-//  position; T[s+16] is shared between positions s and s+16.
+//  starting at base s; a K-mer's block is T[s] bits 5..18, its three bits are T[s] & 31 and
+//  (T[s] >> 19) & 31 (bases 9-11, clear of the block index) in the block's low word and
+//  T[s+16] & 31 (bases 16-18) in its high word.  One ds_read_b64 and ~12 VALU ops per position;
+//  T[s+16] is shared between positions s and s+16.  Three bits keep the survivors near 2.6 % of the
+//  positions (1 % are real), so that a lane rarely has more than NPEND of them.
 template <int BITS>
 __device__ inline uint32_t filter_tile(const uint32_t* __restrict__ s_bloom, uint32_t bloom_log2, uint64_t w0,
                                        uint64_t w1, uint64_t kmask) {
@@ -542,7 +544,7 @@ __device__ inline uint32_t filter_tile(const uint32_t* __restrict__ s_bloom, uin
         for (int s = 0; s < 32; ++s) {
             const uint32_t t1 = T[s] & klo, t2 = T[s + 16] & khi;
             const uint2 blk = blocks[(t1 >> 5) & bmask];
-            hitmask |= ((blk.x >> (t1 & 31)) & (blk.y >> (t2 & 31)) & 1u) << s;
+            hitmask |= ((blk.x >> (t1 & 31)) & (blk.x >> ((t1 >> 19) & 31)) & (blk.y >> (t2 & 31)) & 1u) << s;
         }
     } else {
         const uint32_t wshift = 32 - (bloom_log2 - 5);
