@@ -89,8 +89,11 @@ void po_destroy(po_handle* h);
 po_status po_set_device(po_handle* h, int device);
 
 /* addSequence(id, seq)  -- src/overlapper.cpp:22-26.  Copies id and seq (the caller may
- * free them at once).  seq is compared byte-wise, like the reference's CharString: any byte
- * other than upper-case A/C/G/T switches the handle to the 8-bit representation.           */
+ * free them at once).  seq is compared byte-wise, like the reference's CharString.  Reads are
+ * stored at 2 bits per base; bytes other than upper-case A/C/G/T (N, IUPAC codes, lower case) are
+ * kept as sparse exception records beside the 2-bit codes and compared exactly after the packed
+ * compare.  Only when such bytes are dense (more than len/64 + 16 in one read) does the whole handle
+ * move to the slower 8-bits-per-base representation.                                        */
 po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const char* seq, size_t seq_len);
 
 /* FASTA ingest for `phasm overlap` (the reference uses dinopy.FastaReader / dinopy.reverse_complement,

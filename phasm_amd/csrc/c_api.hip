@@ -51,14 +51,21 @@ struct po_handle {
     std::vector<uint32_t> len;
     std::vector<uint64_t> woff;
     std::vector<uint64_t> words;
+    // 2-bit mode: bytes other than upper-case A/C/G/T are stored as code 0 plus an exception record
+    // (position, byte), sorted by read then position; exc_off has one entry per read + 1
+    std::vector<uint32_t> exc_off{0};
+    std::vector<uint32_t> exc_pos;
+    std::vector<uint8_t> exc_byte;
+    std::vector<uint8_t> pair_state;  // per read pair: 0 = check codes on device, 1 = verified on host, 2 = not a pair
     uint64_t total_bases = 0;
     bool dirty = true;
 
     // device read set + tiling (built at upload)
-    DevBuf d_words, d_woff, d_len, d_tiles, d_read_tile0;
+    DevBuf d_words, d_woff, d_len, d_tiles, d_read_tile0, d_exc_off, d_exc_pos, d_exc_byte, d_pair_state;
     std::vector<uint32_t> h_read_tile0;  // n_reads + 1
     uint32_t n_tiles = 0;
     uint32_t max_len = 0;
+    size_t n_exc_uploaded = 0;
     bool paired = false;  // every read 2i+1 is the reverse complement of read 2i (checked on device at upload)
 
     // per-call workspace (grow-only)
@@ -153,7 +160,9 @@ const BaseLut g_lut;
 
 // Append one read to the packed store.  Layout: every read starts on a 16-byte boundary and is
 // followed by at least one zero guard word (kernels read one word past the last data word).
-// bits == 2: returns false (and appends nothing) if a byte is not upper-case A/C/G/T.
+// bits == 2: bytes other than upper-case A/C/G/T become exception records (code 0 in the packed
+// words); returns false (and appends nothing) when they are too dense for that (> n/64 + 16), in
+// which case the caller moves the whole handle to 8 bits per base.
 bool append_packed(po_handle* h, const unsigned char* s, size_t n, int bits) {
     const size_t per = 64 / bits;
     const size_t old_size = h->words.size();
@@ -185,9 +194,20 @@ bool append_packed(po_handle* h, const unsigned char* s, size_t n, int bits) {
             w[full] = acc;
         }
         if (bad & 0x80) {
-            h->words.resize(old_size);
-            return false;
+            size_t cnt = 0;
+            for (size_t i = 0; i < n; ++i) cnt += lut[s[i]] >> 7;
+            if (cnt > n / 64 + 16) {
+                h->words.resize(old_size);
+                return false;
+            }
+            for (size_t i = 0; i < n; ++i) {
+                if (lut[s[i]] & 0x80) {
+                    h->exc_pos.push_back((uint32_t)i);
+                    h->exc_byte.push_back(s[i]);
+                }
+            }
         }
+        h->exc_off.push_back((uint32_t)h->exc_pos.size());
     } else {
         for (size_t i = 0; i < n; ++i) w[i >> 3] |= (uint64_t)s[i] << ((i & 7) * 8);
     }
@@ -195,8 +215,17 @@ bool append_packed(po_handle* h, const unsigned char* s, size_t n, int bits) {
     return true;
 }
 
-// A non-ACGT byte arrived: re-encode everything held so far at 8 bits per base (lossless: all of
-// it was upper-case ACGT).
+// The bytes of read r as they were added (2-bit mode: codes + exception records).
+void materialize(const po_handle* h, size_t r, const uint64_t* words, const uint64_t* woff, std::vector<unsigned char>& out) {
+    const uint32_t n = h->len[r];
+    out.resize(n);
+    const uint64_t* w = words + woff[r];
+    for (uint32_t i = 0; i < n; ++i) out[i] = "ACGT"[(w[i >> 5] >> ((i & 31) * 2)) & 3];
+    for (uint32_t e = h->exc_off[r]; e < h->exc_off[r + 1]; ++e) out[h->exc_pos[e]] = h->exc_byte[e];
+}
+
+// Non-ACGT bytes too dense for exception records: re-encode everything held so far at 8 bits per
+// base (lossless).
 void widen_to_bytes(po_handle* h) {
     std::vector<uint64_t> old_words;
     std::vector<uint64_t> old_off;
@@ -204,13 +233,55 @@ void widen_to_bytes(po_handle* h) {
     old_off.swap(h->woff);
     std::vector<unsigned char> tmp;
     for (size_t r = 0; r < h->len.size(); ++r) {
-        const uint32_t n = h->len[r];
-        tmp.resize(n);
-        const uint64_t* w = old_words.data() + old_off[r];
-        for (uint32_t i = 0; i < n; ++i) tmp[i] = "ACGT"[(w[i >> 5] >> ((i & 31) * 2)) & 3];
-        append_packed(h, tmp.data(), n, 8);
+        materialize(h, r, old_words.data(), old_off.data(), tmp);
+        append_packed(h, tmp.data(), h->len[r], 8);
     }
     h->bits = 8;
+    h->exc_off.assign(1, 0);
+    h->exc_pos.clear();
+    h->exc_byte.clear();
+    h->pair_state.clear();
+}
+
+// IUPAC-aware complement, identity on everything else (the table of phasm_amd/io/fasta.py)
+const unsigned char* comp_table() {
+    static unsigned char comp[256];
+    static bool init = false;
+    if (!init) {
+        for (int i = 0; i < 256; ++i) comp[i] = (unsigned char)i;
+        const char* from = "ACGTURYKMBVDHSWNacgturykmbvdhswn";
+        const char* to = "TGCAAYRMKVBHDSWNtgcaayrmkvbhdswn";
+        for (int i = 0; from[i]; ++i) comp[(unsigned char)from[i]] = (unsigned char)to[i];
+        init = true;
+    }
+    return comp;
+}
+
+// 2-bit mode, after read r (odd index) was appended: if it or its partner r-1 carries exception
+// records, decide on the host whether the two are exact reverse complements of each other under a
+// complement map that is an involution on the bytes present (the device check only sees 2-bit codes).
+void host_pair_check(po_handle* h, size_t r, const unsigned char* s) {
+    const size_t pair = r / 2;
+    if (h->pair_state.size() <= pair) h->pair_state.resize(pair + 1, 0);
+    const bool has_exc = h->exc_off[r - 1] != h->exc_off[r] || h->exc_off[r] != h->exc_off[r + 1];
+    if (!has_exc) return;  // state 0: the device compares the codes
+    const uint32_t n = h->len[r];
+    uint8_t state = 1;
+    if (h->len[r - 1] != n) {
+        state = 2;
+    } else {
+        std::vector<unsigned char> prev;
+        materialize(h, r - 1, h->words.data(), h->woff.data(), prev);
+        const unsigned char* c = comp_table();
+        for (uint32_t i = 0; i < n; ++i) {
+            const unsigned char x = prev[n - 1 - i], y = s[i];
+            if (c[x] != y || c[y] != x) {
+                state = 2;
+                break;
+            }
+        }
+    }
+    h->pair_state[pair] = state;
 }
 
 inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -261,14 +332,32 @@ po_status upload(po_handle* h) {
         HIP_TRY(h, hipMemcpyAsync(h->d_tiles.p, tiles.data(), (size_t)h->n_tiles * sizeof(po::TileRec), hipMemcpyHostToDevice, h->stream));
     }
     HIP_TRY(h, hipMemcpyAsync(h->d_read_tile0.p, h->h_read_tile0.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, h->stream));
+    // exception records (2-bit mode only; usually none)
+    const size_t n_exc = h->bits == 2 ? h->exc_pos.size() : 0;
+    if (n_exc) {
+        PO_TRY(ensure(h, h->d_exc_off, ((size_t)n + 1) * 4));
+        PO_TRY(ensure(h, h->d_exc_pos, n_exc * 4));
+        PO_TRY(ensure(h, h->d_exc_byte, n_exc));
+        HIP_TRY(h, hipMemcpyAsync(h->d_exc_off.p, h->exc_off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_exc_pos.p, h->exc_pos.data(), n_exc * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_exc_byte.p, h->exc_byte.data(), n_exc, hipMemcpyHostToDevice, h->stream));
+    }
+    h->n_exc_uploaded = n_exc;
     // strand pairing: decides whether po_overlaps may compute one member of each mirror pair
     h->paired = false;
     const bool try_paired = h->bits == 2 && n >= 2 && (n % 2) == 0 && !getenv("PHASM_NO_MIRROR");
     if (try_paired) {
         PO_TRY(ensure(h, h->d_scalars, 64));
         HIP_TRY(h, hipMemsetAsync(h->d_scalars.p, 0, 64, h->stream));
+        const uint8_t* pair_state = nullptr;
+        if (n_exc) {  // pairs with exception records were compared byte-wise on the host
+            h->pair_state.resize(n / 2, 0);
+            PO_TRY(ensure(h, h->d_pair_state, n / 2));
+            HIP_TRY(h, hipMemcpyAsync(h->d_pair_state.p, h->pair_state.data(), n / 2, hipMemcpyHostToDevice, h->stream));
+            pair_state = h->d_pair_state.as<uint8_t>();
+        }
         hipLaunchKernelGGL(po::k_paired_check, dim3(cdiv((uint64_t)(n / 2) * 64, 256)), dim3(256), 0, h->stream,
-                           h->d_words.as<uint64_t>(), h->d_woff.as<uint64_t>(), h->d_len.as<uint32_t>(), n / 2,
+                           h->d_words.as<uint64_t>(), h->d_woff.as<uint64_t>(), h->d_len.as<uint32_t>(), n / 2, pair_state,
                            h->d_scalars.as<uint32_t>());
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(h->pinned, h->d_scalars.p, 8, hipMemcpyDeviceToHost, h->stream));
@@ -526,7 +615,9 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             const uint32_t lds_words = (uint32_t)std::min<uint64_t>(need_words, 8192);
             hipLaunchKernelGGL(po::k_verify_a<BITS>, dim3(r_end - r_begin), dim3(po::VER_BLOCK), (size_t)lds_words * 8, st,
                                words, woff, len, h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_p,
-                               A.cand_b, r_begin, lds_words, paired, h->d_type.as<uint8_t>());
+                               A.cand_b, r_begin, lds_words, paired,
+                               h->n_exc_uploaded ? h->d_exc_off.as<uint32_t>() : nullptr, h->d_exc_pos.as<uint32_t>(),
+                               h->d_exc_byte.as<uint8_t>(), h->d_type.as<uint8_t>());
         }
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
@@ -660,7 +751,7 @@ void po_destroy(po_handle* h) {
     if (h->dev_ready) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
-        DevBuf* bufs[] = {&h->d_words, &h->d_woff, &h->d_len, &h->d_tiles, &h->d_read_tile0, &h->d_truemask,
+        DevBuf* bufs[] = {&h->d_words, &h->d_woff, &h->d_len, &h->d_tiles, &h->d_read_tile0, &h->d_exc_off, &h->d_exc_pos, &h->d_exc_byte, &h->d_pair_state, &h->d_truemask,
                           &h->d_table, &h->d_slot_cnt, &h->d_slot_cur, &h->d_slot_start, &h->d_read_slot, &h->d_chain,
                           &h->d_chain_tmp, &h->d_long_list, &h->d_bloom, &h->d_selfrep, &h->d_tile_count, &h->d_tile_off,
                           &h->d_ps_blocks, &h->d_scalars, &h->d_cand_a, &h->d_cand_p, &h->d_cand_b, &h->d_type,
@@ -696,6 +787,7 @@ po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const cha
         h->len.push_back((uint32_t)seq_len);
         h->total_bases += seq_len;
         h->dirty = true;
+        if (h->bits == 2 && (h->len.size() & 1) == 0 && !h->exc_pos.empty()) host_pair_check(h, h->len.size() - 1, s);
     } catch (const std::bad_alloc&) {
         return fail(h, PO_ERR_NOMEM, "out of host memory in po_add_sequence");
     }
@@ -711,15 +803,7 @@ po_status po_add_fasta(po_handle* h, const char* path, int both_strands, uint64_
     if (n_records) *n_records = 0;
     FILE* f = std::fopen(path, "rb");
     if (!f) return fail(h, PO_ERR_INVALID, std::string("cannot open ") + path);
-    static unsigned char comp[256];
-    static bool comp_init = false;
-    if (!comp_init) {
-        for (int i = 0; i < 256; ++i) comp[i] = (unsigned char)i;
-        const char* from = "ACGTURYKMBVDHSWNacgturykmbvdhswn";
-        const char* to = "TGCAAYRMKVBHDSWNtgcaayrmkvbhdswn";
-        for (int i = 0; from[i]; ++i) comp[(unsigned char)from[i]] = (unsigned char)to[i];
-        comp_init = true;
-    }
+    const unsigned char* comp = comp_table();
     po_status st = PO_OK;
     uint64_t nrec = 0;
     try {

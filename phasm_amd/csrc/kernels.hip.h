@@ -893,6 +893,35 @@ __global__ __launch_bounds__(256) void k_selfrep(const uint64_t* __restrict__ wo
 // candidate hands its lanes to the group's next candidate at once.  The window of a that faces b is
 // funnel-shifted out of three LDS words.
 // type: bit0 = suffix-prefix (A) candidate holds, bit1 = b wholly contained at p (B); 0 = mismatch.
+// Do the exception records of a inside [p, p+n) equal those of b inside [0, n) (same offsets, same
+// bytes)?  Records are sorted by position; they are rare, one lane walks them.
+__device__ inline bool exceptions_equal(const uint32_t* __restrict__ exc_off, const uint32_t* __restrict__ exc_pos,
+                                        const uint8_t* __restrict__ exc_byte, uint32_t a, uint32_t p, uint32_t b,
+                                        uint32_t n) {
+    uint32_t ia = exc_off[a];
+    const uint32_t ea = exc_off[a + 1];
+    uint32_t ib = exc_off[b];
+    const uint32_t eb = exc_off[b + 1];
+    if (ia == ea && ib == eb) return true;
+    {  // first record of a at or after p
+        uint32_t lo = ia, hi = ea;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (exc_pos[mid] < p) lo = mid + 1; else hi = mid;
+        }
+        ia = lo;
+    }
+    for (;;) {
+        const bool ha = ia < ea && exc_pos[ia] - p < n;
+        const bool hb = ib < eb && exc_pos[ib] < n;
+        if (!ha && !hb) return true;
+        if (ha != hb) return false;
+        if (exc_pos[ia] - p != exc_pos[ib] || exc_byte[ia] != exc_byte[ib]) return false;
+        ++ia;
+        ++ib;
+    }
+}
+
 constexpr int VER_GROUP = 16;
 constexpr int VER_BLOCK = 256;
 #ifndef PO_VER_BLOCKS
@@ -908,6 +937,9 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
                                                          const uint32_t* __restrict__ cand_p,
                                                          const uint32_t* __restrict__ cand_b, uint32_t r_begin,
                                                          uint32_t lds_words, uint32_t paired,
+                                                         const uint32_t* __restrict__ exc_off,
+                                                         const uint32_t* __restrict__ exc_pos,
+                                                         const uint8_t* __restrict__ exc_byte,
                                                          uint8_t* __restrict__ type) {
     constexpr int W = 64 / BITS;
     extern __shared__ uint64_t s_a64[];
@@ -934,7 +966,7 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
     bool have = c < seg1;
     // per candidate: nbits = compared bits, q = first dword of a's window, sh = its bit offset,
     // d = this lane's first dword of b in the current step, keep = rows it can give
-    uint32_t nbits = 0, sh = 0, q = 0, d = 0, keep = 0, nblk = 1;
+    uint32_t nbits = 0, sh = 0, q = 0, d = 0, keep = 0, nblk = 1, cur_p = 0, cur_b = 0;
     const uint32_t* B = reinterpret_cast<const uint32_t*>(words);
     // Candidate metadata runs two candidates ahead of the compare loop, so that a group starting a
     // new candidate has (p, b, len[b], woff[b]) in registers already: m0 = the next candidate to
@@ -963,6 +995,8 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
         m1p = cand_p[c2];
         m1b = cand_b[c2];
         const uint32_t rem = la - p;
+        cur_p = p;
+        cur_b = b;
         keep = keep_bits(a, b, rem, lb, paired);
         const uint32_t n = rem < lb ? rem : lb;
         nbits = keep ? n * BITS : 0;
@@ -1022,7 +1056,14 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
             d += nblk * BLK;
             nblk = VER_BLOCKS;
             if (mismatch || (d - 4 * sub) * 32 >= nbits) {  // group-uniform: candidate finished
-                if (sub == 0) type[c] = mismatch ? (uint8_t)0 : (uint8_t)keep;
+                if (sub == 0) {
+                    uint32_t t = mismatch ? 0u : keep;
+                    // 2-bit reads with exception records (non-ACGT bytes, stored as code 0): the packed
+                    // compare only proved the codes equal; the bytes are equal iff the exception
+                    // records inside the compared range also agree
+                    if (t && exc_off && !exceptions_equal(exc_off, exc_pos, exc_byte, a, cur_p, cur_b, nbits / BITS)) t = 0;
+                    type[c] = (uint8_t)t;
+                }
                 c += NGROUPS;
                 have = c < seg1;
                 if (have) init();
@@ -1193,13 +1234,19 @@ __global__ __launch_bounds__(256) void k_emit_cands(const Cand* __restrict__ can
 // complemented (~).  Any failure bumps *n_bad.
 __global__ __launch_bounds__(256) void k_paired_check(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
                                                       const uint32_t* __restrict__ len, uint32_t n_pairs,
+                                                      const uint8_t* __restrict__ pair_state,
                                                       uint32_t* __restrict__ n_bad) {
     const uint32_t pair = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (pair >= n_pairs) return;
     const uint32_t lane = lane_id();
     const uint32_t L = len[2 * pair];
     bool bad = false;
-    if (len[2 * pair + 1] != L) {
+    // pairs with exception records (non-ACGT bytes) were compared byte-wise on the host:
+    // 1 = reverse complements, 2 = not; 0 = compare the 2-bit codes here
+    const uint32_t hs = pair_state ? pair_state[pair] : 0u;
+    if (hs != 0) {
+        bad = hs == 2;
+    } else if (len[2 * pair + 1] != L) {
         bad = true;
     } else {
         const uint64_t* __restrict__ R = words + woff[2 * pair];
