@@ -604,7 +604,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             WA.cand_b = A.cand_b;
             hipLaunchKernelGGL((po::k_wide_scan<BITS, true>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA);
         } else {
-            hipLaunchKernelGGL((po::k_scan_fill<BITS>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, A);
+            hipLaunchKernelGGL((po::k_scan_fill<BITS>), dim3(cdiv(ntiles, 4 * po::FILL_TILES)), dim3(256), 0, st, A);
         }
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(h->ev[EV_FILL], st));

@@ -793,53 +793,86 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead loads of the last pass
 }
 
-// Scan pass 2 (fill): one wave per tile, ordinary grid.  Positions with candidates come from
-// truemask; each is probed again (L2-resident table) and its (a, p, b) triples are written at
-// tile_off[t] in ascending p, chain order (ascending b).
+// Scan pass 2 (fill): one wave per FILL_TILES consecutive tiles, ordinary grid.  Positions with
+// candidates come from truemask; each is probed again (L2-resident table) and its (a, p, b) triples
+// are written in ascending (tile, p), chain order (ascending b).  Consecutive tiles own consecutive
+// candidate ranges (tile_off is a running sum), so the wave writes one contiguous range starting at
+// tile_off[first tile]; pooling the hits of several tiles fills the 64-entry probe rounds and turns
+// four short latency chains into one.
+constexpr int FILL_TILES = 4;
+
 template <int BITS>
 __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
     constexpr int W = 64 / BITS;
     __shared__ uint64_t q_kmer[4 * WAVE];
-    __shared__ uint32_t q_p[4 * WAVE];
+    __shared__ uint32_t q_src[4 * WAVE];
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     uint64_t* qk = q_kmer + wave * WAVE;
-    uint32_t* qp = q_p + wave * WAVE;
-    const uint32_t t = __builtin_amdgcn_readfirstlane(A.tile_begin + blockIdx.x * 4 + wave);
-    if (t >= A.tile_end) return;
-    uint32_t hitmask = A.truemask[(size_t)t * WAVE + lane];
-    const uint32_t nh = __popc(hitmask);
-    const uint32_t incl = wave_incl_scan(nh);
-    const uint32_t total = read_last_lane(incl);
-    if (total == 0) return;
-    const TileRec rec = A.tiles[t];
-    uint64_t w0 = 0, w1 = 0;
-    if (hitmask) {
-        w0 = A.words[rec.wabs + lane];
-        w1 = A.words[rec.wabs + lane + 1];
+    uint32_t* qs = q_src + wave * WAVE;
+    const uint32_t t0 = __builtin_amdgcn_readfirstlane(A.tile_begin + (blockIdx.x * 4 + wave) * FILL_TILES);
+    if (t0 >= A.tile_end) return;
+    uint32_t hm[FILL_TILES], rk[FILL_TILES];
+#pragma unroll
+    for (int i = 0; i < FILL_TILES; ++i) hm[i] = t0 + i < A.tile_end ? A.truemask[(size_t)(t0 + i) * WAVE + lane] : 0u;
+    uint32_t total = 0;
+#pragma unroll
+    for (int i = 0; i < FILL_TILES; ++i) {
+        const uint32_t nh = __popc(hm[i]);
+        const uint32_t incl = wave_incl_scan(nh);
+        rk[i] = total + incl - nh;  // rank of this lane's first hit of tile i among the wave's hits
+        total += read_last_lane(incl);
     }
-    const uint32_t a = rec.read, la = rec.la;
-    const uint32_t p0 = (rec.word0 + lane) * W;
-    uint32_t rank = incl - nh;
-    uint32_t base = A.tile_off[t];
+    if (total == 0) return;
+    uint32_t t_read[FILL_TILES], t_la[FILL_TILES], t_word0[FILL_TILES];
+    uint64_t w0[FILL_TILES], w1[FILL_TILES];
+#pragma unroll
+    for (int i = 0; i < FILL_TILES; ++i) {
+        const TileRec rec = A.tiles[min(t0 + i, A.tile_end - 1)];
+        t_read[i] = rec.read;
+        t_la[i] = rec.la;
+        t_word0[i] = rec.word0;
+        w0[i] = 0;
+        w1[i] = 0;
+        if (hm[i]) {
+            w0[i] = A.words[rec.wabs + lane];
+            w1[i] = A.words[rec.wabs + lane + 1];
+        }
+    }
+    uint32_t out = A.tile_off[t0];
     for (uint32_t r0 = 0; r0 < total; r0 += WAVE) {
-        while (hitmask && rank < r0 + WAVE) {
-            const uint32_t s = __ffs(hitmask) - 1;
-            hitmask &= hitmask - 1;
-            qk[rank - r0] = funnel(w0, w1, s * BITS) & A.kmask;
-            qp[rank - r0] = p0 + s;
-            ++rank;
+#pragma unroll
+        for (int i = 0; i < FILL_TILES; ++i) {
+            while (hm[i] && rk[i] < r0 + WAVE) {
+                const uint32_t sft = __ffs(hm[i]) - 1;
+                hm[i] &= hm[i] - 1;
+                qk[rk[i] - r0] = funnel(w0[i], w1[i], sft * BITS) & A.kmask;
+                qs[rk[i] - r0] = ((uint32_t)i << 16) | (lane << 8) | sft;
+                ++rk[i];
+            }
         }
         wave_lds_fence();
         const bool has = r0 + lane < total;
         const uint64_t kmer = qk[lane];
-        const uint32_t p = qp[lane];
+        const uint32_t src = qs[lane];
         wave_lds_fence();
         uint32_t z = 0, w = 0;
         if (has) table_probe(A.table, A.tbits, kmer, z, w);
+        // the entry's tile: read, length, position
+        const uint32_t ti = src >> 16;
+        uint32_t a = t_read[0], la = t_la[0], word0 = t_word0[0];
+#pragma unroll
+        for (int i = 1; i < FILL_TILES; ++i) {
+            if (ti == (uint32_t)i) {
+                a = t_read[i];
+                la = t_la[i];
+                word0 = t_word0[i];
+            }
+        }
+        const uint32_t p = (word0 + ((src >> 8) & 255u)) * W + (src & 255u);
         uint32_t n = 0;
         if (w) for_each_candidate(A.chain, A.len, A.paired, z, w, a, la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
         const uint32_t inc = wave_incl_scan(n);
-        uint32_t off = base + inc - n;
+        uint32_t off = out + inc - n;
         if (n) {
             for_each_candidate(A.chain, A.len, A.paired, z, w, a, la - p, [&](uint32_t b, uint32_t, uint32_t) {
                 A.cand_a[off] = a;
@@ -848,7 +881,7 @@ __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
                 ++off;
             });
         }
-        base += read_last_lane(inc);
+        out += read_last_lane(inc);
     }
 }
 
