@@ -71,7 +71,7 @@ struct po_handle {
     // per-call workspace (grow-only)
     DevBuf d_table, d_slot_cnt, d_slot_cur, d_slot_start, d_read_slot, d_chain, d_chain_tmp, d_long_list;
     DevBuf d_bloom, d_selfrep, d_tile_count, d_tile_off, d_truemask, d_ps_blocks, d_scalars;
-    DevBuf d_cand_a, d_cand_p, d_cand_b, d_type, d_rowcnt, d_row_off, d_flag;
+    DevBuf d_cand_a, d_cand_p, d_cand_b, d_type, d_rowcnt, d_row_off, d_flag, d_pair_key, d_pair_min;
     DevBuf spare_rows;
     int live_results = 0;
 
@@ -526,7 +526,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         // reads (wide index: its scan does not look for prefix recurrences)
         const uint32_t blocks = std::min<uint32_t>(cdiv((uint64_t)h->n_tiles * 64, 256), (uint32_t)h->n_cu * 8);
         hipLaunchKernelGGL(po::k_selfrep<BITS>, dim3(blocks), dim3(256), 0, st, words, h->d_tiles.as<po::TileRec>(),
-                           h->n_tiles, wide ? 0u : tile_begin, wide ? 0u : tile_end, m, kmask, selfrep);
+                           h->n_tiles, wide ? 0u : tile_begin, wide ? 0u : tile_end, m, kmask, selfrep,
+                           reinterpret_cast<uint32_t*>(scalars + 2));
     }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev[EV_INDEX], st));
@@ -547,6 +548,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     A.len = len;
     A.paired = paired;
     A.selfrep = selfrep;
+    A.n_selfrep = reinterpret_cast<uint32_t*>(scalars + 2);  // scalars[2] lo: reads with a self-repeating prefix
     A.tile_count = h->d_tile_count.as<uint32_t>();
     A.tile_off = h->d_tile_off.as<uint32_t>();
     A.truemask = h->d_truemask.as<uint32_t>();
@@ -578,9 +580,11 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     }
     HIP_TRY(h, hipGetLastError());
     PO_TRY(prefix_sum<uint32_t>(h, A.tile_count + tile_begin, ntiles, h->d_tile_off.as<uint32_t>() + tile_begin, &h->pinned[1]));
+    HIP_TRY(h, hipMemcpyAsync(h->pinned + 8, scalars + 2, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipEventRecord(h->ev[EV_COUNT], st));
     HIP_TRY(h, hipStreamSynchronize(st));
     const uint64_t n_cand64 = h->pinned[1];
+    const uint32_t n_selfrep_reads = (uint32_t)h->pinned[8];
     S.n_candidates = n_cand64;
     if (n_cand64 >= 0xFFFFFF00ull)
         return fail(h, PO_ERR_CAPACITY, "candidate count " + std::to_string(n_cand64) + " exceeds one call's capacity (2^32)");
@@ -622,9 +626,32 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
         // ---- select + row offsets
+        unsigned long long* pkey = nullptr;
+        uint32_t* pmin = nullptr;
+        uint32_t pbits = 0;
+        if (n_selfrep_reads) {
+            // some read's prefix recurs inside it: A candidates of such b may be non-longest duplicates
+            uint32_t* n_suspect = reinterpret_cast<uint32_t*>(scalars + 2) + 1;
+            hipLaunchKernelGGL(po::k_count_suspects, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_b,
+                               h->d_type.as<uint8_t>(), n_cand, selfrep, n_suspect);
+            HIP_TRY(h, hipMemcpyAsync(h->pinned + 8, scalars + 2, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(h, hipStreamSynchronize(st));
+            const uint32_t n_sus = (uint32_t)(h->pinned[8] >> 32);
+            if (n_sus) {
+                pbits = 4;
+                while ((1ull << pbits) < 2ull * n_sus) ++pbits;
+                PO_TRY(ensure(h, h->d_pair_key, ((size_t)1 << pbits) * 8));
+                PO_TRY(ensure(h, h->d_pair_min, ((size_t)1 << pbits) * 4));
+                HIP_TRY(h, hipMemsetAsync(h->d_pair_key.p, 0xFF, ((size_t)1 << pbits) * 8, st));
+                HIP_TRY(h, hipMemsetAsync(h->d_pair_min.p, 0xFF, ((size_t)1 << pbits) * 4, st));
+                pkey = h->d_pair_key.as<unsigned long long>();
+                pmin = h->d_pair_min.as<uint32_t>();
+                hipLaunchKernelGGL(po::k_select_mark, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_b,
+                                   h->d_type.as<uint8_t>(), n_cand, selfrep, pkey, pmin, pbits);
+            }
+        }
         hipLaunchKernelGGL(po::k_select, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_b,
-                           h->d_type.as<uint8_t>(), n_cand, selfrep, h->d_read_tile0.as<uint32_t>(),
-                           h->d_tile_off.as<uint32_t>(), paired, h->d_rowcnt.as<uint8_t>());
+                           h->d_type.as<uint8_t>(), n_cand, selfrep, pkey, pmin, pbits, paired, h->d_rowcnt.as<uint8_t>());
         HIP_TRY(h, hipGetLastError());
         PO_TRY(prefix_sum<uint8_t>(h, h->d_rowcnt.as<uint8_t>(), n_cand, h->d_row_off.as<uint32_t>(), &h->pinned[2]));
         HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
@@ -755,7 +782,7 @@ void po_destroy(po_handle* h) {
                           &h->d_table, &h->d_slot_cnt, &h->d_slot_cur, &h->d_slot_start, &h->d_read_slot, &h->d_chain,
                           &h->d_chain_tmp, &h->d_long_list, &h->d_bloom, &h->d_selfrep, &h->d_tile_count, &h->d_tile_off,
                           &h->d_ps_blocks, &h->d_scalars, &h->d_cand_a, &h->d_cand_p, &h->d_cand_b, &h->d_type,
-                          &h->d_rowcnt, &h->d_row_off, &h->d_flag, &h->spare_rows};
+                          &h->d_rowcnt, &h->d_row_off, &h->d_flag, &h->d_pair_key, &h->d_pair_min, &h->spare_rows};
         for (DevBuf* b : bufs) b->release();
         for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(h->ev[i]);
         (void)hipEventDestroy(h->ev_up0);

@@ -23,9 +23,9 @@ namespace po {
 // carried across loop iterations)
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
+constexpr uint32_t NO_SELFREP = 0xFFFFFFFFu;
 constexpr uint64_t KEY_EMPTY = ~0ull;          // slot-claim sentinel; a real all-ones K-mer lives
                                                // in the dedicated extra slot at index 1<<tbits
-constexpr uint32_t NO_SELFREP = 0xFFFFFFFFu;
 constexpr int WAVE = 64;
 constexpr int SCAN_BLOCK = 1024;               // 16 waves: one persistent workgroup per CU (<= 128 VGPRs)
 constexpr int TILE_WORDS = 64;                 // one 64-bit word per lane
@@ -70,6 +70,12 @@ __host__ __device__ inline void bloom_slot(uint64_t k, uint32_t bloom_log2, uint
     (void)h2;
     word = h1 >> (32 - (bloom_log2 - 5));
     mask = (1u << ((h1 >> 7) & 31)) | (1u << ((h1 >> 12) & 31)) | (1u << ((h1 >> 2) & 31));
+}
+
+// selfrep[a] = smallest p > 0 at which a's own prefix K-mer recurs; *n_marked counts the reads that
+// have one (the host skips the duplicate-A machinery of k_select when there are none)
+__device__ inline void note_selfrep(uint32_t* __restrict__ selfrep, uint32_t a, uint32_t p, uint32_t* __restrict__ n_marked) {
+    if (atomicMin(&selfrep[a], p) == NO_SELFREP) atomicAdd(n_marked, 1u);
 }
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & (WAVE - 1); }
@@ -502,6 +508,7 @@ struct ScanArgs {
     const uint32_t* len;
     uint32_t paired;
     uint32_t* selfrep;     // COUNT: min p>0 at which a read's own prefix K-mer recurs
+    uint32_t* n_selfrep;   //        number of reads that have one
     uint32_t* tile_count;  // COUNT out: candidates per tile
     uint32_t* truemask;    // COUNT out / FILL in: per (tile, lane) bit s set = position p0+s has candidates
     const uint32_t* tile_off;  // FILL in
@@ -611,6 +618,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
     const uint64_t* __restrict__ words = A.words;
     const TileRec* __restrict__ tiles = A.tiles;
     uint32_t* __restrict__ selfrep = A.selfrep;
+    uint32_t* __restrict__ n_selfrep = A.n_selfrep;
     uint32_t* __restrict__ truemask = A.truemask;
     uint32_t* __restrict__ tile_count = A.tile_count;
     const uint32_t paired = A.paired, m = A.m, tile_end = A.tile_end;
@@ -637,10 +645,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
         uint32_t n = 0;
         if (p > 0) {
             if (s.w & SLOT_SINGLE) {
-                if (s.z == a) atomicMin(&selfrep[a], p);
+                if (s.z == a) note_selfrep(selfrep, a, p, n_selfrep);
             } else {
                 for (uint32_t j = 0; j < s.w; ++j)
-                    if (chain[s.z + j] == a) atomicMin(&selfrep[a], p);
+                    if (chain[s.z + j] == a) note_selfrep(selfrep, a, p, n_selfrep);
             }
         }
         for_each_candidate(chain, len, paired, s.z, s.w, a, la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
@@ -890,7 +898,7 @@ __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
 template <int BITS>
 __global__ __launch_bounds__(256) void k_selfrep(const uint64_t* __restrict__ words, const TileRec* __restrict__ tiles,
                                                  uint32_t n_tiles, uint32_t skip_begin, uint32_t skip_end, uint32_t m,
-                                                 uint64_t kmask, uint32_t* selfrep) {
+                                                 uint64_t kmask, uint32_t* selfrep, uint32_t* n_selfrep) {
     constexpr int W = 64 / BITS;
     const uint32_t lane = lane_id();
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -912,7 +920,7 @@ __global__ __launch_bounds__(256) void k_selfrep(const uint64_t* __restrict__ wo
                 if (kmer == key_a && p > 0 && p <= pmax) best = p;
             }
         }
-        if (best != NO_SELFREP) atomicMin(&selfrep[rec.read], best);
+        if (best != NO_SELFREP) note_selfrep(selfrep, rec.read, best, n_selfrep);
     }
 }
 
@@ -1107,20 +1115,56 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
 
 // ----------------------------------------------------------------------------------------
 // select: rows per candidate.  B rows: every occurrence.  A rows: only the longest per (a,b),
-// i.e. the smallest p.  Candidates of one `a` are contiguous and in ascending p, so an A
-// candidate loses iff an earlier candidate of the same (a,b) also verified as A.  Two A hits
-// for one (a,b) force b's prefix K-mer to recur inside b (period p-p'), so only reads with
-// selfrep[b] set need the look-back.
+// i.e. the smallest p = the smallest candidate index (candidates of one a come in ascending p).
+// Two A hits for one (a,b) force b's prefix K-mer to recur inside b (period p-p'), so only
+// candidates whose b has selfrep[b] set can be duplicates -- none at all in non-repetitive data,
+// where the host skips this machinery.  Where they exist, k_select_mark records the smallest
+// verified-A candidate index per (a,b) in an open-addressed table (size 2x the number of such
+// candidates: O(1) per candidate, also for tandem repeats with thousands of hits per pair) and
+// k_select drops every other one.
 // ----------------------------------------------------------------------------------------
+__device__ inline uint32_t pair_slot(uint32_t a, uint32_t b, uint32_t tbits) {
+    uint32_t h1, h2;
+    kmer_hash(((uint64_t)a << 32) | b, h1, h2);
+    return (h1 ^ (h2 >> 3)) >> (32 - tbits);
+}
+
+__global__ void k_count_suspects(const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type, uint32_t n_cand,
+                                 const uint32_t* __restrict__ selfrep, uint32_t* __restrict__ n_suspect) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool sus = i < n_cand && (type[i] & 1u) && selfrep[cand_b[i]] != NO_SELFREP;
+    const uint64_t bal = __ballot(sus);
+    if (lane_id() == 0 && bal) atomicAdd(n_suspect, (uint32_t)__popcll(bal));
+}
+
+__global__ void k_select_mark(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_b,
+                              const uint8_t* __restrict__ type, uint32_t n_cand, const uint32_t* __restrict__ selfrep,
+                              unsigned long long* __restrict__ pkey, uint32_t* __restrict__ pmin, uint32_t tbits) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cand || !(type[i] & 1u)) return;
+    const uint32_t a = cand_a[i], b = cand_b[i];
+    if (selfrep[b] == NO_SELFREP) return;
+    const unsigned long long key = ((unsigned long long)a << 32) | b;  // a != b, so never ~0
+    const uint32_t tmask = (1u << tbits) - 1u;
+    uint32_t s = pair_slot(a, b, tbits);
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&pkey[s], ~0ull, key);
+        if (prev == ~0ull || prev == key) break;
+        s = (s + 1u) & tmask;
+    }
+    atomicMin(&pmin[s], i);
+}
+
 // Rows per verified candidate in emission order: A row, [its mirror], B row, [its mirror].
 __device__ inline uint32_t rows_of(uint32_t t, uint32_t a, uint32_t b, uint32_t paired) {
     if (!paired) return (t & 1u) + ((t >> 1) & 1u);
     return ((t & 1u) ? (a == (b ^ 1u) ? 1u : 2u) : 0u) + ((t & 2u) ? 2u : 0u);
 }
 
+// pkey == nullptr: no read has a self-repeating prefix, every verified A candidate is the longest
 __global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_b,
                          uint8_t* __restrict__ type, uint32_t n_cand, const uint32_t* __restrict__ selfrep,
-                         const uint32_t* __restrict__ read_tile0, const uint32_t* __restrict__ tile_off,
+                         const unsigned long long* __restrict__ pkey, const uint32_t* __restrict__ pmin, uint32_t tbits,
                          uint32_t paired, uint8_t* __restrict__ rowcnt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_cand) return;
@@ -1130,20 +1174,16 @@ __global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __
         return;
     }
     const uint32_t a = cand_a[i], b = cand_b[i];
-    if ((t & 1u) && selfrep[b] != NO_SELFREP) {
-        // An earlier entry that itself lost its A bit still has a winner further back, and the
-        // winner (smallest p) never loses it: concurrent clearing cannot change the outcome.
-        const uint32_t seg0 = tile_off[read_tile0[a]];
-        for (uint32_t j = seg0; j < i; ++j) {
-            if (cand_b[j] == b && (type[j] & 1u)) {
-                t &= ~1u;
-                type[i] = (uint8_t)t;
-                break;
-            }
+    if (pkey && (t & 1u) && selfrep[b] != NO_SELFREP) {
+        const unsigned long long key = ((unsigned long long)a << 32) | b;
+        const uint32_t tmask = (1u << tbits) - 1u;
+        uint32_t s = pair_slot(a, b, tbits);
+        while (pkey[s] != key) s = (s + 1u) & tmask;  // k_select_mark inserted it
+        if (pmin[s] != i) {  // a longer overlap of the same pair exists
+            t &= ~1u;
+            type[i] = (uint8_t)t;
         }
     }
-    // paired-strand mode: every row is written with its strand mirror, except the A row of
-    // (x+, x-) / (x-, x+), which is its own mirror
     rowcnt[i] = (uint8_t)rows_of(t, a, b, paired);
 }
 

@@ -354,3 +354,28 @@ def test_sparse_non_acgt_bytes_stay_on_the_2bit_path():
     bad[j] = bytes(b)
     got, st = hip_rows(bad, 500)
     assert st["paired"] == 0 and np.array_equal(got, oo.oracle_overlaps(bad, 500))
+
+
+def test_tandem_repeats_many_hits_per_pair():
+    """Reads from a short-period tandem repeat: every read's prefix recurs inside itself and inside the
+    others hundreds of times, so each ordered pair has hundreds of verified A candidates of which only
+    the longest may be reported (plus every containment occurrence).  The duplicate resolution is a
+    hash table keyed by (a, b), not a quadratic look-back."""
+    rng = np.random.default_rng(5)
+    unit = b"ACGGTCA"
+    genome = bytearray(unit * 600)
+    for pos in rng.integers(0, len(genome), size=12):      # a few point differences
+        genome[pos] = b"ACGT"[rng.integers(4)]
+    genome = bytes(genome)
+    rc = bytes.maketrans(b"ACGT", b"TGCA")
+    seqs = []
+    for _ in range(50):
+        ln = int(rng.integers(700, 1600))
+        st = int(rng.integers(0, len(genome) - ln))
+        r = genome[st:st + ln]
+        seqs += [r, r.translate(rc)[::-1]]
+    for m in (64, 300):
+        got, st = hip_rows(seqs, m)
+        want = oo.oracle_overlaps(seqs, m)
+        assert st["n_candidates"] > 20 * len(want) > 0      # far more hits than rows
+        assert np.array_equal(got, want), m
