@@ -119,10 +119,20 @@ def main() -> int:
         else:
             # exchange the compact form (verified candidates, 16 B), expand to rows on every rank
             merged = merge_row_shards(local_shard_candidates(ov, m, rank, world, merge_device))
+            shard_st = ov.stats()          # stage timings of this rank's shard (before the expansion)
             res = expand_candidates(ov, merged)
             n = len(res)
             res.free()
         st = ov.stats()
+        if world > 1:
+            # the expansion saw every rank's candidates: scale its byte counters to this rank's share
+            for k in ("verify_bytes_algo", "sum_overlap_bases", "n_rows"):
+                st[k] = st[k] // world
+            for k in stage_keys:
+                if k not in ("ms_emit",):
+                    st[k] = shard_st[k]
+            st["n_candidates"] = shard_st["n_candidates"]
+            st["shard_bases"] = shard_st["shard_bases"]
         if timed:
             for k in stage_keys:
                 acc[k] += st[k]

@@ -87,6 +87,9 @@ def expand_candidates(ov, cands: torch.Tensor):
     if cands.device.type != "cuda":
         cands = cands.cuda()
     cands = cands.contiguous()
+    # the library works on its own HIP stream: the collective / concatenation that produced `cands`
+    # must have finished on torch's stream before it reads them
+    torch.cuda.current_stream(cands.device).synchronize()
     res = ov.expand_result(cands.data_ptr(), cands.shape[0])
     return res
 
