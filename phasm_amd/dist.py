@@ -30,7 +30,7 @@ from ._lib import CAND_DTYPE, ROW_DTYPE
 def merge_row_shards(local: torch.Tensor, group=None) -> torch.Tensor:
     """All-gather variable-length ``int32[n_local, k]`` tensors (k = 6 rows / 4 candidates); every
     rank gets the concatenation in rank order.  Any backend (RCCL on GPU, gloo on CPU)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
     ws = dist.get_world_size(group)
     dev = local.device

@@ -71,6 +71,29 @@ def test_merge_helper_single_gpu():
     ov.close()
 
 
+def test_rccl_collectives_one_rank_group():
+    """The N>1 merge goes through RCCL (`nccl` backend).  A one-rank process group on this GPU runs the
+    very same calls (count all-gather, padded all_gather_into_tensor of int32[n,4], expansion)."""
+    import torch.distributed as dist
+    from phasm_amd.dist import rows_tensor_to_struct, sharded_overlaps
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        _, seqs, m, want = gu.ladder_case("ladder_cfg2_mini")
+        ov = ExactOverlapper(device=0)
+        for i, s in enumerate(seqs):
+            ov.add_sequence("r%d" % i, s)
+        t = sharded_overlaps(ov, m, device=dev)
+        whole = ov.overlaps_array(m)
+        assert np.array_equal(rows_tensor_to_struct(t), whole)
+        assert np.array_equal(oo.sort_rows(oo.struct_to_rows(whole)), want)
+        ov.close()
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.skipif(os.environ.get("PHASM_SKIP_FULL") == "1", reason="full-size run disabled")
 def test_full_size_cfg2_properties():
     """50k x 15 kb (100k oriented reads): too big for the CPU oracle in seconds, so check what must
