@@ -162,6 +162,8 @@ LADDER = {
     # BASELINE.json configs[0] at FULL size: 1k reads (~10 kb), min-overlap 1000 -- the reference's own
     # CPU-runnable case (about 40 s of reference time)
     "cfg1_full": (synth.CONFIGS["cfg1"], 1000),
+    # BASELINE.json configs[1] density (75x per haplotype) at 1 000 reads = 2 000 oriented x 15 kb
+    "cfg2_1k": (synth.scaled(synth.CONFIGS["cfg2"], 1000), 1000),
 }
 
 

@@ -43,7 +43,7 @@ def repeats_cases():
 
 
 LADDER_NAMES = ["ladder_small", "ladder_varlen", "ladder_cfg1_mini", "ladder_cfg2_mini",
-                "ladder_cfg4_noise", "cfg1_full"]
+                "ladder_cfg4_noise", "cfg1_full", "cfg2_1k"]
 
 
 def ladder_case(name):
