@@ -70,7 +70,7 @@ struct po_handle {
 
     // per-call workspace (grow-only)
     DevBuf d_table, d_slot_cnt, d_slot_cur, d_slot_start, d_read_slot, d_chain, d_chain_tmp, d_long_list;
-    DevBuf d_bloom, d_selfrep, d_tile_count, d_tile_off, d_truemask, d_ps_blocks, d_scalars;
+    DevBuf d_bloom, d_selfrep, d_tile_count, d_tile_off, d_truemask, d_ps_blocks, d_scalars, d_left, d_left_cnt;
     DevBuf d_cand_a, d_cand_p, d_cand_b, d_type, d_rowcnt, d_row_off, d_flag, d_pair_key, d_pair_min;
     DevBuf spare_rows;
     int live_results = 0;
@@ -556,6 +556,11 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     A.tile_count = h->d_tile_count.as<uint32_t>();
     A.tile_off = h->d_tile_off.as<uint32_t>();
     A.truemask = h->d_truemask.as<uint32_t>();
+#ifdef PO_STAMPS
+    PO_TRY(ensure(h, h->d_flag, (size_t)4096 * 64));
+    HIP_TRY(h, hipMemsetAsync(h->d_flag.p, 0, (size_t)4096 * 64, st));
+    A.dbg = h->d_flag.as<unsigned long long>();
+#endif
     uint32_t scan_waves = po::SCAN_BLOCK / 64;
     if (const char* e = getenv("PHASM_SCAN_WAVES")) scan_waves = std::max(1, std::min(16, atoi(e)));
     const uint32_t scan_grid = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)h->n_cu, cdiv(ntiles, scan_waves)));
@@ -580,9 +585,28 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         if (scan_lds > h->lds_max) return fail(h, PO_ERR_HIP, "device LDS too small for the scan kernel");
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan_probe<BITS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
+        const uint32_t n_scan_waves = scan_grid * scan_waves;
+        PO_TRY(ensure(h, h->d_left, (size_t)n_scan_waves * po::LEFT_CAP * sizeof(uint2)));
+        PO_TRY(ensure(h, h->d_left_cnt, (size_t)n_scan_waves * 4));
+        HIP_TRY(h, hipMemsetAsync(h->d_left_cnt.p, 0, (size_t)n_scan_waves * 4, st));
+        A.left = h->d_left.as<uint2>();
+        A.left_cnt = h->d_left_cnt.as<uint32_t>();
         hipLaunchKernelGGL((po::k_scan_probe<BITS>), dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
+        hipLaunchKernelGGL((po::k_scan_fixup<BITS>), dim3(n_scan_waves), dim3(64), 0, st, A, n_scan_waves);
     }
     HIP_TRY(h, hipGetLastError());
+#ifdef PO_STAMPS
+    if (!wide) {
+        std::vector<unsigned long long> dbg(4096 * 8);
+        HIP_TRY(h, hipMemcpyAsync(dbg.data(), h->d_flag.p, dbg.size() * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        double sum[6] = {0, 0, 0, 0, 0, 0};
+        for (size_t w = 0; w < 4096; ++w) for (int k = 0; k < 6; ++k) sum[k] += (double)dbg[w * 8 + k];
+        if (sum[5] > 0)
+            std::fprintf(stderr, "[stamps] per pass (cycles): wait_rw %.0f  filter %.0f  wait_probe %.0f  consume %.0f  issue %.0f  (passes %.0f)\n",
+                         sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5], sum[3] / sum[5], sum[4] / sum[5], sum[5]);
+    }
+#endif
     PO_TRY(prefix_sum<uint32_t>(h, A.tile_count + tile_begin, ntiles, h->d_tile_off.as<uint32_t>() + tile_begin, &h->pinned[1]));
     HIP_TRY(h, hipMemcpyAsync(h->pinned + 8, scalars + 2, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipEventRecord(h->ev[EV_COUNT], st));
@@ -782,7 +806,7 @@ void po_destroy(po_handle* h) {
     if (h->dev_ready) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
-        DevBuf* bufs[] = {&h->d_words, &h->d_woff, &h->d_len, &h->d_tiles, &h->d_read_tile0, &h->d_exc_off, &h->d_exc_pos, &h->d_exc_byte, &h->d_pair_state, &h->d_truemask,
+        DevBuf* bufs[] = {&h->d_words, &h->d_woff, &h->d_len, &h->d_tiles, &h->d_read_tile0, &h->d_left, &h->d_left_cnt, &h->d_exc_off, &h->d_exc_pos, &h->d_exc_byte, &h->d_pair_state, &h->d_truemask,
                           &h->d_table, &h->d_slot_cnt, &h->d_slot_cur, &h->d_slot_start, &h->d_read_slot, &h->d_chain,
                           &h->d_chain_tmp, &h->d_long_list, &h->d_bloom, &h->d_selfrep, &h->d_tile_count, &h->d_tile_off,
                           &h->d_ps_blocks, &h->d_scalars, &h->d_cand_a, &h->d_cand_p, &h->d_cand_b, &h->d_type,

@@ -509,6 +509,9 @@ struct ScanArgs {
     uint32_t paired;
     uint32_t* selfrep;     // COUNT: min p>0 at which a read's own prefix K-mer recurs
     uint32_t* n_selfrep;   //        number of reads that have one
+    unsigned long long* dbg;  // diagnostic builds (-DPO_STAMPS): per wave, cycles per pipeline stage
+    uint2* left;           // COUNT out: per wave LEFT_CAP deferred positions {tile, lane << 8 | s}
+    uint32_t* left_cnt;    //            and how many each wave deferred
     uint32_t* tile_count;  // COUNT out: candidates per tile
     uint32_t* truemask;    // COUNT out / FILL in: per (tile, lane) bit s set = position p0+s has candidates
     const uint32_t* tile_off;  // FILL in
@@ -599,6 +602,12 @@ __device__ inline void for_each_candidate(const uint32_t* __restrict__ chain, co
 // selfrep[a] = first recurrence of a's own prefix.
 // Out: truemask[tile][lane] bit s = position has candidates; tile_count[tile] = their number.
 constexpr int NPEND = 4;
+constexpr uint32_t LEFT_CAP = 512;   // deferred positions per scan wave before it falls back to resolving them in place
+#ifdef PO_STAMPS
+#define PO_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PO_STAMP(var) do { } while (0)
+#endif
 
 template <int BITS>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  // A stays in SGPRs: never take its address
@@ -654,6 +663,24 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
         for_each_candidate(chain, len, paired, s.z, s.w, a, la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
         return n;
     };
+    // Positions that cannot be settled from registers (a third table slot is needed, the slot heads a
+    // chain of several reads, or the lane has more than NPEND survivors) are not resolved here: a
+    // dependent load would force `s_waitcnt vmcnt(0)` and drain the whole look-ahead (the tile words
+    // come from HBM).  They are appended to this wave's leftover list with plain stores and settled by
+    // k_scan_fixup afterwards.  Only when the list is full does the wave resolve them in place.
+    uint2* __restrict__ my_left = A.left + (size_t)(blockIdx.x * nwaves + wave) * LEFT_CAP;
+    uint32_t left_n = 0;  // wave-uniform
+    auto defer = [&](bool want, uint32_t tile, uint32_t lane_s) __attribute__((always_inline)) -> bool {
+        // returns true when the position was deferred; false = list full, caller resolves it in place
+        // (every lane of the wave must call this together: left_n has to stay wave-uniform)
+        const uint64_t bal = __ballot(want);
+        if (bal == 0) return false;
+        const uint32_t cnt = (uint32_t)__popcll(bal);
+        if (left_n + cnt > LEFT_CAP) return false;
+        if (want) my_left[left_n + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = uint2{tile, lane_s};
+        left_n = __builtin_amdgcn_readfirstlane(left_n + cnt);
+        return want;
+    };
 
     // Hand-scheduled software pipeline over this wave's tiles k = t, t+stride, ...  The three load
     // streams of the steady state are issued with inline asm so that the waits can be COUNTED
@@ -690,12 +717,19 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
             ps1[i] = ld16(&table[1]);
         }
     }
+#ifdef PO_STAMPS
+    unsigned long long acc_s[6] = {0, 0, 0, 0, 0, 0};
+#endif
     // one pass; returns false after the last tile has been retired
     auto pass = [&](u32x4& wcur, u32x4& wnext) __attribute__((always_inline)) -> bool {
         const bool have_tile = t < tile_end;  // wave-uniform
         const uint32_t tn = t + stride;
+        unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0;
+        (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)st5;
+        PO_STAMP(st0);
         // ---- R and W of the previous pass have 2*NPEND probe loads behind them
         asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r_lo), "+v"(r_hi), "+v"(wcur) : "n"(2 * NPEND) : "memory");
+        PO_STAMP(st1);
         TileRec rec1;  // tile k+1
         rec1.wabs = ((uint64_t)__builtin_amdgcn_readfirstlane(r_lo.y) << 32) | __builtin_amdgcn_readfirstlane(r_lo.x);
         rec1.wread = ((uint64_t)__builtin_amdgcn_readfirstlane(r_lo.w) << 32) | __builtin_amdgcn_readfirstlane(r_lo.z);
@@ -718,31 +752,40 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
             const uint32_t nvalid = rec.la - m - p0 + 1;  // positions whose suffix/containment can reach min_length
             if (nvalid < (uint32_t)W) hitmask &= (1u << nvalid) - 1u;
         }
+        PO_STAMP(st2);
         // ---- the previous tile's probes have only this pass's R and W (3 loads) behind them
         asm volatile("s_waitcnt vmcnt(3)" : "+v"(ps0[0]), "+v"(ps0[1]), "+v"(ps0[2]), "+v"(ps0[3]), "+v"(ps1[0]),
                      "+v"(ps1[1]), "+v"(ps1[2]), "+v"(ps1[3])
                      :
                      : "memory");
+        PO_STAMP(st3);
         static_assert(NPEND == 4, "the wait above names NPEND probe registers");
         if (prev_t != 0xFFFFFFFFu) {
             uint32_t tmk = prev_mask, cnt = prev_cnt;
 #pragma unroll
             for (int i = 0; i < NPEND; ++i) {
-                if (pvalid & (1u << i)) {
+                {
+                    const bool on = (pvalid & (1u << i)) != 0;
                     u32x4 s = ps0[i];
-                    if (pk[i] != KEY_EMPTY && s.w != 0 && (((uint64_t)s.y << 32) | s.x) != pk[i]) {  // linear probing
-                        s = ps1[i];
-                        uint32_t j = (pidx[i] + 1u) & tmask;
-                        while (s.w != 0 && (((uint64_t)s.y << 32) | s.x) != pk[i]) {
-                            j = (j + 1u) & tmask;
-                            s = *reinterpret_cast<const u32x4*>(&table[j]);
+                    if (on && pk[i] != KEY_EMPTY && s.w != 0 && (((uint64_t)s.y << 32) | s.x) != pk[i]) s = ps1[i];  // linear probing
+                    const bool settled = s.w == 0 || (((uint64_t)s.y << 32) | s.x) == pk[i];
+                    // needs a third slot, or heads a chain of several reads -> leftover list
+                    const bool hard = on && (!settled || (s.w != 0 && !(s.w & SLOT_SINGLE)));
+                    const bool deferred = defer(hard, prev_t, (lane << 8) | psh[i]);
+                    if (on && !deferred) {
+                        if (!settled) {  // (leftover list full) resolve in place
+                            uint32_t j = (pidx[i] + 1u) & tmask;
+                            while (s.w != 0 && (((uint64_t)s.y << 32) | s.x) != pk[i]) {
+                                j = (j + 1u) & tmask;
+                                s = *reinterpret_cast<const u32x4*>(&table[j]);
+                            }
                         }
-                    }
-                    if (s.w != 0) {
-                        const uint32_t n = count_slot(s, prev_a, prev_la, prev_p0 + psh[i]);
-                        if (n) {
-                            tmk |= 1u << psh[i];
-                            cnt += n;
+                        if (s.w != 0) {
+                            const uint32_t n = count_slot(s, prev_a, prev_la, prev_p0 + psh[i]);
+                            if (n) {
+                                tmk |= 1u << psh[i];
+                                cnt += n;
+                            }
                         }
                     }
                 }
@@ -751,6 +794,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
             cnt = wave_sum(cnt);
             if (lane == 0) tile_count[prev_t] = cnt;
         }
+        PO_STAMP(st4);
         if (!have_tile) return false;
         // ---- request the table slots of this tile's survivors: always 2*NPEND loads per lane
         // (entries without a survivor read slot 0)
@@ -774,7 +818,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
             ps1[i] = ld16(&table[(idx + 1u) & tmask]);
             pvalid |= (on ? 1u : 0u) << i;
         }
-        while (hitmask) {  // rare: more than NPEND survivors in one lane -> resolve them now
+        while (__any(hitmask != 0)) {  // more than NPEND survivors in a lane: defer them, one per lane per round
+            const bool want = hitmask != 0;
+            const uint32_t sft = want ? __ffs(hitmask) - 1 : 0;
+            const bool ok = defer(want, t, (lane << 8) | sft);  // all lanes take part, every round
+            if (!__any(ok)) break;                              // leftover list full
+            if (ok) hitmask &= hitmask - 1;
+        }
+        while (hitmask) {  // leftover list full: resolve them now
             const uint32_t sft = __ffs(hitmask) - 1;
             hitmask &= hitmask - 1;
             const uint64_t kmer = funnel(w0, w1, sft * BITS) & kmask;
@@ -794,11 +845,65 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
         prev_p0 = p0;
         t = tn;
         rec = rec1;
+#ifdef PO_STAMPS
+        PO_STAMP(st5);
+        acc_s[0] += st1 - st0;  // wait for record + words
+        acc_s[1] += st2 - st1;  // look-ahead issue + filter
+        acc_s[2] += st3 - st2;  // wait for probes
+        acc_s[3] += st4 - st3;  // consume + retire
+        acc_s[4] += st5 - st4;  // probe issue (+ overflow path)
+        acc_s[5] += 1;
+#endif
         return true;
     };
     while (pass(wa, wb) && pass(wb, wa)) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead loads of the last pass
+    if (lane == 0) A.left_cnt[blockIdx.x * nwaves + wave] = left_n;
+#ifdef PO_STAMPS
+    if (A.dbg && lane == 0) {
+        unsigned long long* o = A.dbg + (size_t)(blockIdx.x * nwaves + wave) * 8;
+        for (int k = 0; k < 6; ++k) o[k] = acc_s[k];
+    }
+#endif
+}
+
+// Settle the positions the scan waves deferred (k_scan_probe: third table slot needed, chain of several
+// reads, more than NPEND survivors in a lane): one thread each, ordinary dependent loads, results
+// added to the tile's truemask bit and candidate count.  Runs after k_scan_probe has retired every tile.
+template <int BITS>
+__global__ void k_scan_fixup(const ScanArgs A, uint32_t n_waves) {
+    constexpr int W = 64 / BITS;
+    const uint32_t wv = blockIdx.x;  // one workgroup per scan wave's list
+    if (wv >= n_waves) return;
+    const uint32_t cnt = A.left_cnt[wv];
+    const uint2* __restrict__ list = A.left + (size_t)wv * LEFT_CAP;
+    for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) {
+        const uint2 e = list[k];
+        const uint32_t t = e.x, ln = e.y >> 8, sft = e.y & 255u;
+        if (t < A.tile_begin || t >= A.tile_end || ln >= (uint32_t)WAVE || sft >= (uint32_t)W) continue;  // (defensive)
+        const TileRec rec = A.tiles[t];
+        const uint64_t w0 = A.words[rec.wabs + ln], w1 = A.words[rec.wabs + ln + 1];
+        const uint64_t kmer = funnel(w0, w1, sft * BITS) & A.kmask;
+        uint32_t z = 0, w = 0;
+        table_probe(A.table, A.tbits, kmer, z, w);
+        if (!w) continue;
+        const uint32_t a = rec.read, p = (rec.word0 + ln) * W + sft;
+        if (p > 0) {
+            if (w & SLOT_SINGLE) {
+                if (z == a) note_selfrep(A.selfrep, a, p, A.n_selfrep);
+            } else {
+                for (uint32_t j = 0; j < w; ++j)
+                    if (A.chain[z + j] == a) note_selfrep(A.selfrep, a, p, A.n_selfrep);
+            }
+        }
+        uint32_t n = 0;
+        for_each_candidate(A.chain, A.len, A.paired, z, w, a, rec.la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
+        if (n) {
+            atomicOr(&A.truemask[(size_t)t * WAVE + ln], 1u << sft);
+            atomicAdd(&A.tile_count[t], n);
+        }
+    }
 }
 
 // Scan pass 2 (fill): one wave per FILL_TILES consecutive tiles, ordinary grid.  Positions with
