@@ -70,7 +70,7 @@ struct po_handle {
 
     // per-call workspace (grow-only)
     DevBuf d_table, d_slot_cnt, d_slot_cur, d_slot_start, d_read_slot, d_chain, d_chain_tmp, d_long_list;
-    DevBuf d_bloom, d_selfrep, d_tile_count, d_tile_off, d_truemask, d_ps_blocks, d_scalars, d_left, d_left_cnt;
+    DevBuf d_bloom, d_selfrep, d_tile_count, d_tile_off, d_truemask, d_ps_blocks, d_scalars, d_left, d_left_cnt, d_tile_extra;
     DevBuf d_cand_a, d_cand_p, d_cand_b, d_type, d_rowcnt, d_row_off, d_flag, d_pair_key, d_pair_min;
     DevBuf spare_rows;
     int live_results = 0;
@@ -581,7 +581,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     if (wide) {
         hipLaunchKernelGGL((po::k_wide_scan<BITS, false>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA);
     } else {
-        const size_t scan_lds = bloom_bytes;
+        const size_t scan_lds = (size_t)scan_waves * po::SCAN_LDS_PER_WAVE + bloom_bytes;
         if (scan_lds > h->lds_max) return fail(h, PO_ERR_HIP, "device LDS too small for the scan kernel");
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan_probe<BITS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
@@ -589,10 +589,15 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         PO_TRY(ensure(h, h->d_left, (size_t)n_scan_waves * po::LEFT_CAP * sizeof(uint2)));
         PO_TRY(ensure(h, h->d_left_cnt, (size_t)n_scan_waves * 4));
         HIP_TRY(h, hipMemsetAsync(h->d_left_cnt.p, 0, (size_t)n_scan_waves * 4, st));
+        PO_TRY(ensure(h, h->d_tile_extra, ((size_t)h->n_tiles + 1) * 4));
+        HIP_TRY(h, hipMemsetAsync(h->d_tile_extra.as<uint32_t>() + tile_begin, 0, (size_t)ntiles * 4, st));
         A.left = h->d_left.as<uint2>();
         A.left_cnt = h->d_left_cnt.as<uint32_t>();
+        A.tile_extra = h->d_tile_extra.as<uint32_t>();
         hipLaunchKernelGGL((po::k_scan_probe<BITS>), dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
         hipLaunchKernelGGL((po::k_scan_fixup<BITS>), dim3(n_scan_waves), dim3(64), 0, st, A, n_scan_waves);
+        hipLaunchKernelGGL(po::k_add_extra, dim3(cdiv(ntiles, 256)), dim3(256), 0, st, A.tile_count, A.tile_extra, tile_begin,
+                           tile_end);
     }
     HIP_TRY(h, hipGetLastError());
 #ifdef PO_STAMPS
@@ -806,7 +811,7 @@ void po_destroy(po_handle* h) {
     if (h->dev_ready) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
-        DevBuf* bufs[] = {&h->d_words, &h->d_woff, &h->d_len, &h->d_tiles, &h->d_read_tile0, &h->d_left, &h->d_left_cnt, &h->d_exc_off, &h->d_exc_pos, &h->d_exc_byte, &h->d_pair_state, &h->d_truemask,
+        DevBuf* bufs[] = {&h->d_words, &h->d_woff, &h->d_len, &h->d_tiles, &h->d_read_tile0, &h->d_left, &h->d_left_cnt, &h->d_tile_extra, &h->d_exc_off, &h->d_exc_pos, &h->d_exc_byte, &h->d_pair_state, &h->d_truemask,
                           &h->d_table, &h->d_slot_cnt, &h->d_slot_cur, &h->d_slot_start, &h->d_read_slot, &h->d_chain,
                           &h->d_chain_tmp, &h->d_long_list, &h->d_bloom, &h->d_selfrep, &h->d_tile_count, &h->d_tile_off,
                           &h->d_ps_blocks, &h->d_scalars, &h->d_cand_a, &h->d_cand_p, &h->d_cand_b, &h->d_type,

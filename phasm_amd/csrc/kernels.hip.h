@@ -512,6 +512,7 @@ struct ScanArgs {
     unsigned long long* dbg;  // diagnostic builds (-DPO_STAMPS): per wave, cycles per pipeline stage
     uint2* left;           // COUNT out: per wave LEFT_CAP deferred positions {tile, lane << 8 | s}
     uint32_t* left_cnt;    //            and how many each wave deferred
+    uint32_t* tile_extra;  //            candidates resolved in place when a leftover list was full (zeroed; rare)
     uint32_t* tile_count;  // COUNT out: candidates per tile
     uint32_t* truemask;    // COUNT out / FILL in: per (tile, lane) bit s set = position p0+s has candidates
     const uint32_t* tile_off;  // FILL in
@@ -594,15 +595,15 @@ __device__ inline void for_each_candidate(const uint32_t* __restrict__ chain, co
 // Scan pass 1 (filter + count), ONE kernel.  Persistent workgroups (grid <= #CUs); the filter
 // lives in LDS for the whole launch.  One wave per tile = 64 words = 64*W positions; lane l owns
 // word l (+ the next one for windows that straddle) and tests its W positions against the filter
-// (filter_tile: VALU + one LDS read per position).  Each lane then requests the table slots of its
-// OWN survivors (up to NPEND of them; two consecutive 16-byte slots each) from L2 and goes straight
-// on to filter the next tile -- the replies are consumed one tile later, so the probe latency hides
-// under the filter arithmetic.  Everything a lane needs to finish a position stays in its
-// registers: no compaction, no LDS traffic besides the filter, no atomics except the rare
-// selfrep[a] = first recurrence of a's own prefix.
+// (filter_tile: VALU + one LDS read per position).  The wave's survivors (about 40 of 2048 positions)
+// are compacted through a 64-entry wave-private LDS queue, so that every lane settles at most ONE
+// survivor per tile: it requests the two candidate table slots from L2 and the wave goes straight on
+// to filter the next tile -- the replies are consumed one tile later, under the filter arithmetic.
+// Positions that cannot be settled from registers (a third table slot, a chain of several reads, a
+// 65th survivor) go to a per-wave leftover list and are settled afterwards by k_scan_fixup.
 // Out: truemask[tile][lane] bit s = position has candidates; tile_count[tile] = their number.
-constexpr int NPEND = 4;
 constexpr uint32_t LEFT_CAP = 512;   // deferred positions per scan wave before it falls back to resolving them in place
+constexpr int SCAN_LDS_PER_WAVE = WAVE * 4 + WAVE * 4;  // queue of positions, result masks
 #ifdef PO_STAMPS
 #define PO_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -612,11 +613,15 @@ constexpr uint32_t LEFT_CAP = 512;   // deferred positions per scan wave before 
 template <int BITS>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  // A stays in SGPRs: never take its address
     constexpr int W = 64 / BITS;
-    extern __shared__ uint32_t s_bloom[];
+    extern __shared__ uint64_t smem[];
     const uint32_t nwaves = blockDim.x >> 6;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t* qs = reinterpret_cast<uint32_t*>(smem) + wave * WAVE;             // queue: lane << 8 | s
+    uint32_t* tm = reinterpret_cast<uint32_t*>(smem) + (nwaves + wave) * WAVE;  // result mask per owner lane
+    uint32_t* s_bloom = reinterpret_cast<uint32_t*>(smem) + 2 * nwaves * WAVE;
     const uint32_t bloom_words = (1u << A.bloom_log2) >> 5;
     for (uint32_t i = threadIdx.x; i < bloom_words; i += blockDim.x) s_bloom[i] = A.bloom[i];
+    tm[lane] = 0;
     __syncthreads();
 
     const uint32_t stride = gridDim.x * nwaves;
@@ -633,21 +638,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
     const uint32_t paired = A.paired, m = A.m, tile_end = A.tile_end;
     const uint64_t kmask = A.kmask;
 
-    // probes in flight: they belong to the PREVIOUS tile of this wave
-    uint64_t pk[NPEND];
-    u32x4 ps0[NPEND], ps1[NPEND];
-    uint32_t pidx[NPEND], psh[NPEND];
-    uint32_t pvalid = 0;
-    uint32_t prev_t = 0xFFFFFFFFu, prev_a = 0, prev_la = 0, prev_p0 = 0;
-    uint32_t prev_mask = 0, prev_cnt = 0;  // results of survivors beyond NPEND, resolved at issue time
-#pragma unroll
-    for (int i = 0; i < NPEND; ++i) {
-        pk[i] = 0;
-        ps0[i] = u32x4{0, 0, 0, 0};
-        ps1[i] = u32x4{0, 0, 0, 0};
-        pidx[i] = 0;
-        psh[i] = 0;
-    }
+    // the probe in flight: it belongs to the PREVIOUS tile of this wave
+    uint64_t pk = 0;
+    u32x4 ps0 = {0, 0, 0, 0}, ps1 = {0, 0, 0, 0};
+    uint32_t pidx = 0, psrc = 0;
+    bool pon = false;
+    uint32_t prev_t = 0xFFFFFFFFu, prev_a = 0, prev_la = 0, prev_word0 = 0;
 
     // a found slot -> number of candidates of position p of read a (and the selfrep side effect)
     auto count_slot = [&](u32x4 s, uint32_t a, uint32_t la, uint32_t p) __attribute__((always_inline)) -> uint32_t {
@@ -663,11 +659,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
         for_each_candidate(chain, len, paired, s.z, s.w, a, la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
         return n;
     };
-    // Positions that cannot be settled from registers (a third table slot is needed, the slot heads a
-    // chain of several reads, or the lane has more than NPEND survivors) are not resolved here: a
-    // dependent load would force `s_waitcnt vmcnt(0)` and drain the whole look-ahead (the tile words
-    // come from HBM).  They are appended to this wave's leftover list with plain stores and settled by
-    // k_scan_fixup afterwards.  Only when the list is full does the wave resolve them in place.
+    // Leftover list: a dependent load in the steady state would force `s_waitcnt vmcnt(0)` and drain the
+    // whole look-ahead (the tile words come from HBM), so hard positions are appended here with plain
+    // stores.  Only when the list is full does the wave resolve them in place.
     uint2* __restrict__ my_left = A.left + (size_t)(blockIdx.x * nwaves + wave) * LEFT_CAP;
     uint32_t left_n = 0;  // wave-uniform
     auto defer = [&](bool want, uint32_t tile, uint32_t lane_s) __attribute__((always_inline)) -> bool {
@@ -687,7 +681,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
     // (hipcc falls back to vmcnt(0) at every use here, which would serialise the probes):
     //   R(k+2)  record of tile k+2     2 x dwordx4   issued in pass k, used from pass k+1
     //   W(k+1)  words of tile k+1      1 x dwordx4   issued in pass k, used in pass k+1
-    //   P(k)    table slots of tile k  2*NPEND x dwordx4, issued at the end of pass k, used in pass k+1
+    //   P(k)    table slots of tile k  2 x dwordx4   issued at the end of pass k, used in pass k+1
     // vm ops complete in issue order, and vmcnt(N) waits until at most N are outstanding, so a wait
     // needs N <= (ops issued after the one wanted).  Stores and the rare compiler-tracked loads only
     // add younger ops, so the counts below are lower bounds: safe.  Every steady-state load is
@@ -711,11 +705,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
         r_lo = ld16(rp);
         r_hi = ld16(reinterpret_cast<const char*>(rp) + 16);
         wa = ld16(&words[rec.wabs + lane]);  // (tail padding keeps every lane in bounds)
-#pragma unroll
-        for (int i = 0; i < NPEND; ++i) {  // dummy probes: same queue shape as the steady state
-            ps0[i] = ld16(&table[0]);
-            ps1[i] = ld16(&table[1]);
-        }
+        ps0 = ld16(&table[0]);               // dummy probe: same queue shape as the steady state
+        ps1 = ld16(&table[1]);
     }
 #ifdef PO_STAMPS
     unsigned long long acc_s[6] = {0, 0, 0, 0, 0, 0};
@@ -727,8 +718,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
         unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0;
         (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)st5;
         PO_STAMP(st0);
-        // ---- R and W of the previous pass have 2*NPEND probe loads behind them
-        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r_lo), "+v"(r_hi), "+v"(wcur) : "n"(2 * NPEND) : "memory");
+        // ---- R and W of the previous pass have the 2 probe loads behind them
+        asm volatile("s_waitcnt vmcnt(2)" : "+v"(r_lo), "+v"(r_hi), "+v"(wcur) : : "memory");
         PO_STAMP(st1);
         TileRec rec1;  // tile k+1
         rec1.wabs = ((uint64_t)__builtin_amdgcn_readfirstlane(r_lo.y) << 32) | __builtin_amdgcn_readfirstlane(r_lo.x);
@@ -753,78 +744,55 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
             if (nvalid < (uint32_t)W) hitmask &= (1u << nvalid) - 1u;
         }
         PO_STAMP(st2);
-        // ---- the previous tile's probes have only this pass's R and W (3 loads) behind them
-        asm volatile("s_waitcnt vmcnt(3)" : "+v"(ps0[0]), "+v"(ps0[1]), "+v"(ps0[2]), "+v"(ps0[3]), "+v"(ps1[0]),
-                     "+v"(ps1[1]), "+v"(ps1[2]), "+v"(ps1[3])
-                     :
-                     : "memory");
+        // ---- the previous tile's probe has only this pass's R and W (3 loads) behind it
+        asm volatile("s_waitcnt vmcnt(3)" : "+v"(ps0), "+v"(ps1) : : "memory");
         PO_STAMP(st3);
-        static_assert(NPEND == 4, "the wait above names NPEND probe registers");
         if (prev_t != 0xFFFFFFFFu) {
-            uint32_t tmk = prev_mask, cnt = prev_cnt;
-#pragma unroll
-            for (int i = 0; i < NPEND; ++i) {
-                {
-                    const bool on = (pvalid & (1u << i)) != 0;
-                    u32x4 s = ps0[i];
-                    if (on && pk[i] != KEY_EMPTY && s.w != 0 && (((uint64_t)s.y << 32) | s.x) != pk[i]) s = ps1[i];  // linear probing
-                    const bool settled = s.w == 0 || (((uint64_t)s.y << 32) | s.x) == pk[i];
-                    // needs a third slot, or heads a chain of several reads -> leftover list
-                    const bool hard = on && (!settled || (s.w != 0 && !(s.w & SLOT_SINGLE)));
-                    const bool deferred = defer(hard, prev_t, (lane << 8) | psh[i]);
-                    if (on && !deferred) {
-                        if (!settled) {  // (leftover list full) resolve in place
-                            uint32_t j = (pidx[i] + 1u) & tmask;
-                            while (s.w != 0 && (((uint64_t)s.y << 32) | s.x) != pk[i]) {
-                                j = (j + 1u) & tmask;
-                                s = *reinterpret_cast<const u32x4*>(&table[j]);
-                            }
-                        }
-                        if (s.w != 0) {
-                            const uint32_t n = count_slot(s, prev_a, prev_la, prev_p0 + psh[i]);
-                            if (n) {
-                                tmk |= 1u << psh[i];
-                                cnt += n;
-                            }
-                        }
+            u32x4 s = ps0;
+            if (pon && pk != KEY_EMPTY && s.w != 0 && (((uint64_t)s.y << 32) | s.x) != pk) s = ps1;  // linear probing
+            const bool settled = s.w == 0 || (((uint64_t)s.y << 32) | s.x) == pk;
+            // needs a third slot, or heads a chain of several reads -> leftover list
+            const bool hard = pon && (!settled || (s.w != 0 && !(s.w & SLOT_SINGLE)));
+            const bool deferred = defer(hard, prev_t, psrc);
+            uint32_t n = 0;
+            if (pon && !deferred) {
+                if (!settled) {  // (leftover list full) resolve in place
+                    uint32_t j = (pidx + 1u) & tmask;
+                    while (s.w != 0 && (((uint64_t)s.y << 32) | s.x) != pk) {
+                        j = (j + 1u) & tmask;
+                        s = *reinterpret_cast<const u32x4*>(&table[j]);
                     }
                 }
+                if (s.w != 0) n = count_slot(s, prev_a, prev_la, (prev_word0 + (psrc >> 8)) * W + (psrc & 255u));
+                if (n) atomicOr(&tm[psrc >> 8], 1u << (psrc & 255u));
             }
-            truemask[(size_t)prev_t * WAVE + lane] = tmk;
-            cnt = wave_sum(cnt);
-            if (lane == 0) tile_count[prev_t] = cnt;
+            wave_lds_fence();
+            truemask[(size_t)prev_t * WAVE + lane] = tm[lane];  // each lane owns the mask of its word
+            tm[lane] = 0;
+            n = wave_sum(n);
+            if (lane == 0) tile_count[prev_t] = n;
         }
         PO_STAMP(st4);
         if (!have_tile) return false;
-        // ---- request the table slots of this tile's survivors: always 2*NPEND loads per lane
-        // (entries without a survivor read slot 0)
-        pvalid = 0;
-        prev_mask = 0;
-        prev_cnt = 0;
-#pragma unroll
-        for (int i = 0; i < NPEND; ++i) {
-            const bool on = hitmask != 0;
-            const uint32_t sft = on ? __ffs(hitmask) - 1 : 0;
-            hitmask &= hitmask - 1;  // (0 stays 0)
-            const uint64_t kmer = funnel(w0, w1, sft * BITS) & kmask;
-            const uint32_t lo = (uint32_t)kmer, hi = (uint32_t)(kmer >> 32);
-            uint32_t idx = ((lo ^ ((hi << 13) | (hi >> 19))) * 0x9E3779B1u) >> (32 - tbits);
-            if (kmer == KEY_EMPTY) idx = tmask + 1u;  // the all-ones key lives in the extra slot
-            if (!on) idx = 0;
-            pk[i] = kmer;
-            psh[i] = sft;
-            pidx[i] = idx;
-            ps0[i] = ld16(&table[idx]);
-            ps1[i] = ld16(&table[(idx + 1u) & tmask]);
-            pvalid |= (on ? 1u : 0u) << i;
+        // ---- compact this tile's survivors: survivor number r goes to lane r
+        const uint32_t nh = __popc(hitmask);
+        const uint32_t incl = wave_incl_scan(nh);
+        const uint32_t total = read_last_lane(incl);
+        uint32_t rank = incl - nh;
+        while (hitmask && rank < (uint32_t)WAVE) {  // the queue only names the position: (lane, s)
+            const uint32_t sft = __ffs(hitmask) - 1;
+            hitmask &= hitmask - 1;
+            qs[rank] = (lane << 8) | sft;
+            ++rank;
         }
-        while (__any(hitmask != 0)) {  // more than NPEND survivors in a lane: defer them, one per lane per round
+        while (__any(hitmask != 0)) {  // survivors beyond the 64th: defer them, one per lane per round
             const bool want = hitmask != 0;
             const uint32_t sft = want ? __ffs(hitmask) - 1 : 0;
             const bool ok = defer(want, t, (lane << 8) | sft);  // all lanes take part, every round
             if (!__any(ok)) break;                              // leftover list full
             if (ok) hitmask &= hitmask - 1;
         }
+        uint32_t ovf_n = 0;
         while (hitmask) {  // leftover list full: resolve them now
             const uint32_t sft = __ffs(hitmask) - 1;
             hitmask &= hitmask - 1;
@@ -832,17 +800,42 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
             uint32_t z = 0, w = 0;
             table_probe(table, tbits, kmer, z, w);
             if (w) {
-                const uint32_t n = count_slot(u32x4{0, 0, z, w}, rec.read, rec.la, p0 + sft);
-                if (n) {
-                    prev_mask |= 1u << sft;
-                    prev_cnt += n;
+                const uint32_t nn = count_slot(u32x4{0, 0, z, w}, rec.read, rec.la, p0 + sft);
+                if (nn) {
+                    atomicOr(&tm[lane], 1u << sft);  // picked up when this tile is retired
+                    ovf_n += nn;
                 }
             }
+        }
+        wave_lds_fence();
+        // ---- request the two table slots of this lane's survivor: always 2 loads per lane (lanes
+        // without one read slot 0)
+        pon = lane < total;
+        {
+            psrc = pon ? qs[lane] : 0u;
+            // the K-mer is cut out of the owner lane's two words, fetched across the wave (ds_bpermute)
+            const uint32_t sl = psrc >> 8;
+            const uint32_t x0 = __shfl((uint32_t)w0, sl, WAVE), x1 = __shfl((uint32_t)(w0 >> 32), sl, WAVE);
+            const uint32_t x2 = __shfl((uint32_t)w1, sl, WAVE), x3 = __shfl((uint32_t)(w1 >> 32), sl, WAVE);
+            const uint64_t kmer = funnel(((uint64_t)x1 << 32) | x0, ((uint64_t)x3 << 32) | x2, (psrc & 255u) * BITS) & kmask;
+            const uint32_t lo = (uint32_t)kmer, hi = (uint32_t)(kmer >> 32);
+            uint32_t idx = ((lo ^ ((hi << 13) | (hi >> 19))) * 0x9E3779B1u) >> (32 - tbits);
+            if (kmer == KEY_EMPTY) idx = tmask + 1u;  // the all-ones key lives in the extra slot
+            if (!pon) idx = 0;
+            pk = kmer;
+            pidx = idx;
+            ps0 = ld16(&table[idx]);
+            ps1 = ld16(&table[(idx + 1u) & tmask]);
+        }
+        wave_lds_fence();  // queue reads done before the next tile overwrites it
+        if (__any(ovf_n != 0)) {  // (leftover list was full) counts resolved in place join the tile later
+            const uint32_t e = wave_sum(ovf_n);
+            if (lane == 0) atomicAdd(&A.tile_extra[t], e);
         }
         prev_t = t;
         prev_a = rec.read;
         prev_la = rec.la;
-        prev_p0 = p0;
+        prev_word0 = rec.word0;
         t = tn;
         rec = rec1;
 #ifdef PO_STAMPS
@@ -851,7 +844,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
         acc_s[1] += st2 - st1;  // look-ahead issue + filter
         acc_s[2] += st3 - st2;  // wait for probes
         acc_s[3] += st4 - st3;  // consume + retire
-        acc_s[4] += st5 - st4;  // probe issue (+ overflow path)
+        acc_s[4] += st5 - st4;  // compaction + probe issue
         acc_s[5] += 1;
 #endif
         return true;
@@ -904,6 +897,11 @@ __global__ void k_scan_fixup(const ScanArgs A, uint32_t n_waves) {
             atomicAdd(&A.tile_count[t], n);
         }
     }
+}
+
+__global__ void k_add_extra(uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ tile_extra, uint32_t t0, uint32_t t1) {
+    const uint32_t t = t0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < t1 && tile_extra[t]) tile_count[t] += tile_extra[t];
 }
 
 // Scan pass 2 (fill): one wave per FILL_TILES consecutive tiles, ordinary grid.  Positions with
