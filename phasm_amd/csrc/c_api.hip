@@ -583,7 +583,9 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     } else {
         const size_t scan_lds = (size_t)scan_waves * po::SCAN_LDS_PER_WAVE + bloom_bytes;
         if (scan_lds > h->lds_max) return fail(h, PO_ERR_HIP, "device LDS too small for the scan kernel");
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan_probe<BITS>),
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan_probe<BITS, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan_probe<BITS, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
         const uint32_t n_scan_waves = scan_grid * scan_waves;
         PO_TRY(ensure(h, h->d_left, (size_t)n_scan_waves * po::LEFT_CAP * sizeof(uint2)));
@@ -594,7 +596,10 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         A.left = h->d_left.as<uint2>();
         A.left_cnt = h->d_left_cnt.as<uint32_t>();
         A.tile_extra = h->d_tile_extra.as<uint32_t>();
-        hipLaunchKernelGGL((po::k_scan_probe<BITS>), dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
+        if (K == W)
+            hipLaunchKernelGGL((po::k_scan_probe<BITS, true>), dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
+        else
+            hipLaunchKernelGGL((po::k_scan_probe<BITS, false>), dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
         hipLaunchKernelGGL((po::k_scan_fixup<BITS>), dim3(n_scan_waves), dim3(64), 0, st, A, n_scan_waves);
         hipLaunchKernelGGL(po::k_add_extra, dim3(cdiv(ntiles, 256)), dim3(256), 0, st, A.tile_count, A.tile_extra, tile_begin,
                            tile_end);

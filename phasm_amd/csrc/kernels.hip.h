@@ -535,14 +535,15 @@ __device__ inline uint64_t window(uint64_t w0, uint64_t w1, int s) {
 //  T[s+16] & 31 (bases 16-18) in its high word.  One ds_read_b64 and ~12 VALU ops per position;
 //  T[s+16] is shared between positions s and s+16.  Three bits keep the survivors near 2.6 % of the
 //  positions (1 % are real), so that a lane rarely has more than NPEND of them.
-template <int BITS>
+// FULLK: the anchor is a whole word (min_length >= W, the normal case): no K-mer mask to apply.
+template <int BITS, bool FULLK>
 __device__ inline uint32_t filter_tile(const uint32_t* __restrict__ s_bloom, uint32_t bloom_log2, uint64_t w0,
                                        uint64_t w1, uint64_t kmask) {
     constexpr int W = 64 / BITS;
     uint32_t hitmask = 0;
     if constexpr (BITS == 2) {
         const uint32_t x[4] = {(uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32)};
-        const uint32_t klo = (uint32_t)kmask, khi = (uint32_t)(kmask >> 32);
+        const uint32_t klo = FULLK ? ~0u : (uint32_t)kmask, khi = FULLK ? ~0u : (uint32_t)(kmask >> 32);
         const uint32_t bmask = (1u << (bloom_log2 - 6)) - 1u;
         const uint2* __restrict__ blocks = reinterpret_cast<const uint2*>(s_bloom);
         uint32_t T[48];
@@ -561,7 +562,7 @@ __device__ inline uint32_t filter_tile(const uint32_t* __restrict__ s_bloom, uin
         const uint32_t wshift = 32 - (bloom_log2 - 5);
 #pragma unroll
         for (int s = 0; s < W; ++s) {
-            const uint64_t kmer = window<BITS>(w0, w1, s) & kmask;
+            const uint64_t kmer = FULLK ? window<BITS>(w0, w1, s) : (window<BITS>(w0, w1, s) & kmask);
             const uint32_t lo = (uint32_t)kmer, hi = (uint32_t)(kmer >> 32);
             const uint32_t h1 = (lo ^ ((hi << 13) | (hi >> 19))) * 0x9E3779B1u;
             const uint32_t bm = (1u << ((h1 >> 7) & 31)) | (1u << ((h1 >> 12) & 31)) | (1u << ((h1 >> 2) & 31));
@@ -610,7 +611,7 @@ constexpr int SCAN_LDS_PER_WAVE = WAVE * 4 + WAVE * 4;  // queue of positions, r
 #define PO_STAMP(var) do { } while (0)
 #endif
 
-template <int BITS>
+template <int BITS, bool FULLK>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  // A stays in SGPRs: never take its address
     constexpr int W = 64 / BITS;
     extern __shared__ uint64_t smem[];
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
         uint32_t hitmask = 0;
         const uint32_t p0 = (rec.word0 + lane) * W;
         if (have_tile && rec.la >= m && p0 <= rec.la - m) {
-            hitmask = filter_tile<BITS>(s_bloom, A.bloom_log2, w0, w1, kmask);
+            hitmask = filter_tile<BITS, FULLK>(s_bloom, A.bloom_log2, w0, w1, kmask);
             const uint32_t nvalid = rec.la - m - p0 + 1;  // positions whose suffix/containment can reach min_length
             if (nvalid < (uint32_t)W) hitmask &= (1u << nvalid) - 1u;
         }

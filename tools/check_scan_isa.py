@@ -148,7 +148,7 @@ def main():
     errors, found = [], 0
     i = 0
     while i < len(asm):
-        m = re.match(r"^(_ZN2po12k_scan_probe\w+):", asm[i])
+        m = re.match(r"^(_ZN2po12k_scan_probe\w+):", asm[i].split(";")[0].strip())
         if m:
             j = i
             while "s_endpgm" not in asm[j]:
