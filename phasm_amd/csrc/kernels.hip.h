@@ -545,7 +545,7 @@ __device__ inline uint32_t filter_tile(const uint32_t* __restrict__ s_bloom, uin
         const uint32_t x[4] = {(uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32)};
         const uint32_t klo = FULLK ? ~0u : (uint32_t)kmask, khi = FULLK ? ~0u : (uint32_t)(kmask >> 32);
         const uint32_t bmask = (1u << (bloom_log2 - 6)) - 1u;
-        const uint2* __restrict__ blocks = reinterpret_cast<const uint2*>(s_bloom);
+        const uint32_t amask = bmask << 3;
         uint32_t T[48];
 #pragma unroll
         for (int s = 0; s < 48; ++s) {
@@ -555,7 +555,8 @@ __device__ inline uint32_t filter_tile(const uint32_t* __restrict__ s_bloom, uin
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
             const uint32_t t1 = T[s] & klo, t2 = T[s + 16] & khi;
-            const uint2 blk = blocks[(t1 >> 5) & bmask];
+            // byte offset of the block = ((t1 >> 5) & bmask) * 8; the filter sits at LDS offset 0
+            const uint2 blk = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_bloom) + ((t1 >> 2) & amask));
             hitmask |= ((blk.x >> (t1 & 31)) & (blk.x >> ((t1 >> 19) & 31)) & (blk.y >> (t2 & 31)) & 1u) << s;
         }
     } else {
@@ -617,10 +618,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
     extern __shared__ uint64_t smem[];
     const uint32_t nwaves = blockDim.x >> 6;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    uint32_t* qs = reinterpret_cast<uint32_t*>(smem) + wave * WAVE;             // queue: lane << 8 | s
-    uint32_t* tm = reinterpret_cast<uint32_t*>(smem) + (nwaves + wave) * WAVE;  // result mask per owner lane
-    uint32_t* s_bloom = reinterpret_cast<uint32_t*>(smem) + 2 * nwaves * WAVE;
     const uint32_t bloom_words = (1u << A.bloom_log2) >> 5;
+    uint32_t* s_bloom = reinterpret_cast<uint32_t*>(smem);                      // filter first: its block offsets are LDS addresses
+    uint32_t* qs = s_bloom + bloom_words + wave * WAVE;                         // queue: lane << 8 | s
+    uint32_t* tm = s_bloom + bloom_words + (nwaves + wave) * WAVE;              // result mask per owner lane
     for (uint32_t i = threadIdx.x; i < bloom_words; i += blockDim.x) s_bloom[i] = A.bloom[i];
     tm[lane] = 0;
     __syncthreads();
