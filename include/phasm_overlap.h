@@ -150,6 +150,75 @@ void po_result_free(po_result* r);
  * gfa_line("E", "*", a_id, b_id, astart, aend, bstart, bend, "*")  (assembler.py:46-48, gfa.py:230-231). */
 po_status po_write_gfa_edges(po_result* r, int fd, uint64_t* lines_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * Next row of the path: the consumer of the E lines, stage 1 of
+ * `phasm layout` (phasm/cli/assembler.py:52-139) -- classify every alignment, drop contained reads,
+ * apply the alignment filters, build the assembly-graph edge list -- on the row array, on the device.
+ * --------------------------------------------------------------------------------------------- */
+
+/* The filter settings of `phasm layout` (assembler.py:78-87; CLI defaults :469-489). */
+typedef struct {
+    uint32_t min_read_length;    /* MinReadLength(n), phasm/filter.py:37-58; 0 = filter not installed  */
+    uint32_t min_overlap_length; /* MinOverlapLength(n), filter.py:61-74;   0 = filter not installed  */
+    uint32_t max_overhang_abs;   /* MaxOverhang(max_overhang, ratio), filter.py:104-122; default 1000 */
+    uint32_t reserved;           /* must be 0                                                         */
+    double max_overhang_rel;     /* default 0.8                                                       */
+} po_layout_params;
+
+/* One assembly-graph edge: g.add_edge(u, v, {weight, overlap_len}), phasm/assembly_graph.py:146-176.
+ * u, v are oriented-read indices of the handle (x+ = 2i, x- = 2i+1; reverse node = index ^ 1). */
+typedef struct {
+    uint32_t u, v;
+    int32_t weight, overlap_len;
+} po_edge;
+
+typedef struct {
+    uint64_t n_rows;             /* alignments looked at                                              */
+    uint64_t n_type[4];          /* rows per AlignmentType (phasm/alignments.py:16-20):               */
+                                 /*   0 OVERLAP_AB, 1 OVERLAP_BA, 2 A_CONTAINED, 3 B_CONTAINED         */
+    uint64_t n_short;            /* overlap rows with a read shorter than min_read_length             */
+    uint64_t n_min_overlap;      /* ... then: shorter than min_overlap_length                         */
+    uint64_t n_overhang;         /* ... then: overhang above the MaxOverhang threshold                */
+    uint64_t n_pass;             /* overlap rows that satisfy all three predicates                    */
+    uint64_t n_contained_reads;  /* reads (both strands count once) that are contained in another     */
+    uint64_t n_edges;            /* distinct (u, v) edges of the graph after the contained reads left */
+    float ms_classify, ms_dedupe, ms_emit, ms_total;
+} po_layout_stats;
+
+/* A read without sequence: one GFA2 segment line `S <name> <length> *` (gfa2_segment_to_read,
+ * phasm/io/gfa.py:33-46).  Adds the two oriented nodes name+"+" and name+"-" of that length.  A handle
+ * holds either sequences or segments, never both; po_overlaps* on a segment handle fails. */
+po_status po_add_segment(po_handle* h, const char* name, size_t name_len, uint32_t length);
+
+/* Wrap rows supplied by the caller (copied) into a result of this handle, e.g. alignments from
+ * another producer of the same wire format (phasm/cli/convert.py:65-133). */
+po_status po_result_from_rows(po_handle* h, const po_row* rows, uint64_t n, po_result** out);
+
+/* Read a GFA2 file the way `phasm layout` does (assembler.py:56-60, :96-98): pass 1 takes every S line
+ * (gfa2_parse_segments, phasm/io/gfa.py:107-109) into an EMPTY handle via po_add_segment, pass 2 turns
+ * every E line into a row (gfa2_parse_edge + gfa2_line_to_la, gfa.py:72-104: ids end in the strand
+ * character, positions may carry a trailing `$`).  An E line naming an unknown segment fails, as the
+ * reference's dict lookup does. */
+po_status po_add_gfa(po_handle* h, const char* path, uint64_t* n_segments, po_result** rows_out);
+
+/* Stage 1 of `phasm layout` on the rows of `rows` (a result of this handle):
+ *   1. classify each row (LocalAlignment.classify, phasm/alignments.py:248-258);
+ *   2. ContainedReads (filter.py:77-101): the contained read of every *_CONTAINED row is marked;
+ *   3. MinReadLength / MinOverlapLength / MaxOverhang on the remaining rows (filter.py:37-74, 104-122);
+ *   4. build_assembly_graph (assembly_graph.py:136-179): two edges per surviving row; a later row
+ *      overwrites the attributes of an edge an earlier row added (networkx add_edge);
+ *   5. every marked read loses both of its nodes and their edges (assembler.py:113-126).
+ * `edges_out` holds po_edge[po_result_count] (read with po_result_rows cast to const po_edge*, or the
+ * device pointer), ordered by producing row.  The edge SET equals the reference's `g.edges(data=True)`
+ * at "Final graph" (assembler.py:136) for any order of the input lines; the reference's per-filter
+ * `filtered` log counters depend on line order and are not reproduced.
+ * removed_reads_out (may be NULL): po_num_sequences()/2 bytes, 1 = read i (nodes 2i, 2i+1) was contained.
+ * Needs the handle's ids in strand pairs (2i = name+"+", 2i+1 = name+"-", what po_add_fasta with
+ * both_strands, the CLI and po_add_segment produce); otherwise PO_ERR_INVALID. */
+po_status po_layout_edges(po_handle* h, po_result* rows, const po_layout_params* params,
+                          uint8_t* removed_reads_out, po_result** edges_out);
+po_status po_get_layout_stats(const po_handle* h, po_layout_stats* out);
+
 po_status po_get_stats(const po_handle* h, po_stats* out);
 const char* po_last_error(const po_handle* h);
 int po_abi_version(void);

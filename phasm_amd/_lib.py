@@ -23,6 +23,28 @@ ROW_DTYPE = np.dtype([("a_idx", "<u4"), ("b_idx", "<u4"), ("astart", "<i4"),
 CAND_DTYPE = np.dtype([("a_idx", "<u4"), ("p", "<u4"), ("b_idx", "<u4"), ("type", "<u4")])
 
 
+EDGE_DTYPE = np.dtype([("u", "<u4"), ("v", "<u4"), ("weight", "<i4"), ("overlap_len", "<i4")])
+
+
+class PoLayoutParams(ctypes.Structure):
+    _fields_ = [("min_read_length", ctypes.c_uint32), ("min_overlap_length", ctypes.c_uint32),
+                ("max_overhang_abs", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("max_overhang_rel", ctypes.c_double)]
+
+
+class PoLayoutStats(ctypes.Structure):
+    _fields_ = [("n_rows", ctypes.c_uint64), ("n_type", ctypes.c_uint64 * 4), ("n_short", ctypes.c_uint64),
+                ("n_min_overlap", ctypes.c_uint64), ("n_overhang", ctypes.c_uint64), ("n_pass", ctypes.c_uint64),
+                ("n_contained_reads", ctypes.c_uint64), ("n_edges", ctypes.c_uint64),
+                ("ms_classify", ctypes.c_float), ("ms_dedupe", ctypes.c_float), ("ms_emit", ctypes.c_float),
+                ("ms_total", ctypes.c_float)]
+
+    def as_dict(self) -> dict:
+        d = {name: getattr(self, name) for name, _ in self._fields_}
+        d["n_type"] = list(self.n_type)
+        return d
+
+
 class PoStats(ctypes.Structure):
     _fields_ = [
         ("bits_per_base", ctypes.c_uint32), ("kmer", ctypes.c_uint32),
@@ -66,6 +88,11 @@ SYMBOLS = [
     ("po_result_copy_to_device", ctypes.c_int, [_P, ctypes.c_void_p]),
     ("po_result_free", None, [_P]),
     ("po_write_gfa_edges", ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
+    ("po_add_segment", ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]),
+    ("po_result_from_rows", ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(_P)]),
+    ("po_add_gfa", ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(_P)]),
+    ("po_layout_edges", ctypes.c_int, [_P, _P, ctypes.POINTER(PoLayoutParams), ctypes.c_void_p, ctypes.POINTER(_P)]),
+    ("po_get_layout_stats", ctypes.c_int, [_P, ctypes.POINTER(PoLayoutStats)]),
     ("po_get_stats", ctypes.c_int, [_P, ctypes.POINTER(PoStats)]),
     ("po_last_error", ctypes.c_char_p, [_P]),
 ]

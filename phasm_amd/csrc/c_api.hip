@@ -5,6 +5,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -13,9 +16,11 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "kernels.hip.h"
+#include "layout.hip.h"
 
 namespace {
 
@@ -76,6 +81,13 @@ struct po_handle {
     int live_results = 0;
 
     po_stats stats = {};
+
+    // layout stage 1 (po_layout_edges)
+    bool segments_only = false;  // reads were added by po_add_segment: lengths and names, no sequence
+    int ids_paired = -1;         // -1 unknown, 0/1: ids come in (name+"+", name+"-") pairs
+    hipEvent_t ev_lay[4] = {};
+    DevBuf d_lay_len, d_lay_cnt, d_rflag, d_removed, d_ekey, d_ecnt, d_ewin, d_eoff;
+    po_layout_stats lstats = {};
 };
 
 struct po_result {
@@ -140,7 +152,7 @@ po_status init_device(po_handle* h) {
     for (int i = 0; i < EV_N; ++i) HIP_TRY(h, hipEventCreate(&h->ev[i]));
     HIP_TRY(h, hipEventCreate(&h->ev_up0));
     HIP_TRY(h, hipEventCreate(&h->ev_up1));
-    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->pinned), 64, hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->pinned), 512, hipHostMallocDefault));
     h->dev_ready = true;
     return PO_OK;
 }
@@ -797,6 +809,227 @@ po_status run_expand(po_handle* h, const void* d_cands, uint64_t n, po_result* r
     return PO_OK;
 }
 
+
+// ---- layout stage 1 (po_layout_edges): rows -> contained reads + assembly-graph edges ----------
+
+// ids come in strand pairs: ids[2i] = name + "+", ids[2i+1] = name + "-"  (assembler.py:39-40)
+bool ids_are_strand_pairs(po_handle* h) {
+    if (h->ids_paired >= 0) return h->ids_paired == 1;
+    bool ok = (h->ids.size() % 2) == 0;
+    for (size_t i = 0; ok && i < h->ids.size(); i += 2) {
+        const std::string &p = h->ids[i], &m = h->ids[i + 1];
+        ok = !p.empty() && p.size() == m.size() && p.back() == '+' && m.back() == '-' &&
+             std::memcmp(p.data(), m.data(), p.size() - 1) == 0;
+    }
+    h->ids_paired = ok ? 1 : 0;
+    return ok;
+}
+
+po_status rows_to_device(po_handle* h, po_result* r) {
+    if (r->count == 0 || r->d_rows.p) return PO_OK;
+    if (!r->host) return fail(h, PO_ERR_INVALID, "result holds no rows");
+    PO_TRY(ensure(h, r->d_rows, r->count * r->elem));
+    HIP_TRY(h, hipMemcpyAsync(r->d_rows.p, r->host, r->count * r->elem, hipMemcpyHostToDevice, h->stream));
+    return PO_OK;
+}
+
+po_status run_layout(po_handle* h, po_result* rows, const po_layout_params& prm, uint8_t* removed_out, po_result* res) {
+    PO_TRY(init_device(h));
+    hipStream_t st = h->stream;
+    po_layout_stats& L = h->lstats;
+    L = po_layout_stats();
+    res->count = 0;
+    res->elem = sizeof(po_edge);
+    const uint32_t n_nodes = (uint32_t)h->len.size();
+    const uint64_t n_rows64 = rows->count;
+    if (n_rows64 >= 0x7FFFFFF0ull) return fail(h, PO_ERR_CAPACITY, "po_layout_edges: more than 2^31 rows in one call");
+    const uint32_t n_rows = (uint32_t)n_rows64;
+    const uint32_t n_names = n_nodes / 2;
+    L.n_rows = n_rows;
+    for (hipEvent_t& e : h->ev_lay)
+        if (!e) HIP_TRY(h, hipEventCreate(&e));
+    PO_TRY(rows_to_device(h, rows));
+    PO_TRY(ensure(h, h->d_lay_len, ((size_t)n_nodes + 1) * 4));
+    PO_TRY(ensure(h, h->d_lay_cnt, 128));
+    PO_TRY(ensure(h, h->d_scalars, 64));
+    PO_TRY(ensure(h, h->d_rflag, (size_t)n_rows + 1));
+    PO_TRY(ensure(h, h->d_removed, (size_t)n_names + 1));
+    if (n_nodes) HIP_TRY(h, hipMemcpyAsync(h->d_lay_len.p, h->len.data(), (size_t)n_nodes * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemsetAsync(h->d_lay_cnt.p, 0, 128, st));
+    HIP_TRY(h, hipMemsetAsync(h->d_removed.p, 0, (size_t)n_names + 1, st));
+    unsigned long long* cnt = h->d_lay_cnt.as<unsigned long long>();
+    const po::Row* d_rows = rows->d_rows.as<po::Row>();
+    const uint32_t* d_len = h->d_lay_len.as<uint32_t>();
+    po::LayoutParams P;
+    P.min_read_length = prm.min_read_length;
+    P.min_overlap_length = prm.min_overlap_length;
+    P.max_overhang_abs = prm.max_overhang_abs;
+    P.pad = 0;
+    P.max_overhang_rel = prm.max_overhang_rel;
+    const uint32_t stride_grid = std::max<uint32_t>(1u, std::min<uint32_t>(cdiv(n_rows, 256), (uint32_t)h->n_cu * 8));
+    HIP_TRY(h, hipEventRecord(h->ev_lay[0], st));
+    if (n_rows) {
+        hipLaunchKernelGGL(po::k_layout_classify, dim3(stride_grid), dim3(256), 0, st, d_rows, n_rows, d_len, n_nodes, P,
+                           h->d_rflag.as<uint8_t>(), h->d_removed.as<uint8_t>(), cnt);
+        hipLaunchKernelGGL(po::k_count_bytes, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(cdiv(n_names, 256), 256u))), dim3(256), 0,
+                           st, h->d_removed.as<uint8_t>(), n_names, cnt + po::LC_N);
+        HIP_TRY(h, hipGetLastError());
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_lay[1], st));
+    HIP_TRY(h, hipMemcpyAsync(h->pinned + 16, cnt, (po::LC_N + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    const uint64_t* c = h->pinned + 16;
+    if (c[po::LC_INVALID]) return fail(h, PO_ERR_INVALID, "po_layout_edges: a row names a read the handle does not hold");
+    for (int t = 0; t < 4; ++t) L.n_type[t] = c[po::LC_TYPE0 + t];
+    L.n_short = c[po::LC_SHORT];
+    L.n_min_overlap = c[po::LC_MINOVL];
+    L.n_overhang = c[po::LC_OVERHANG];
+    L.n_pass = c[po::LC_PASS];
+    L.n_contained_reads = c[po::LC_N];
+    uint64_t n_edges = 0;
+    if (L.n_pass) {
+        // (u, v) -> last writer: 3 slots per surviving row (<= 2 distinct edges each: load <= 2/3, 1/3 when
+        // every edge has its strand-mirror twin), 16-byte slots
+        if (3 * L.n_pass + 64 >= 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "po_layout_edges: too many edges for one call");
+        const uint32_t n_slots = (uint32_t)(3 * L.n_pass + 64);
+        PO_TRY(ensure(h, h->d_ekey, (size_t)n_slots * sizeof(po::EdgeSlot)));
+        PO_TRY(ensure(h, h->d_ecnt, (size_t)n_rows));
+        PO_TRY(ensure(h, h->d_ewin, (size_t)n_rows));
+        PO_TRY(ensure(h, h->d_eoff, ((size_t)n_rows + 1) * 4));
+        HIP_TRY(h, hipMemsetAsync(h->d_ekey.p, 0xFF, (size_t)n_slots * sizeof(po::EdgeSlot), st));
+        hipLaunchKernelGGL(po::k_layout_insert, dim3(stride_grid), dim3(256), 0, st, d_rows, n_rows, d_len, h->d_rflag.as<uint8_t>(),
+                           h->d_removed.as<uint8_t>(), h->d_ekey.as<po::EdgeSlot>(), n_slots);
+        hipLaunchKernelGGL(po::k_layout_winner, dim3(cdiv(n_rows, 256)), dim3(256), 0, st, d_rows, n_rows, d_len,
+                           h->d_rflag.as<uint8_t>(), h->d_removed.as<uint8_t>(), h->d_ekey.as<po::EdgeSlot>(), n_slots,
+                           h->d_ecnt.as<uint8_t>(), h->d_ewin.as<uint8_t>());
+        HIP_TRY(h, hipGetLastError());
+        PO_TRY(prefix_sum<uint8_t>(h, h->d_ecnt.as<uint8_t>(), n_rows, h->d_eoff.as<uint32_t>(), &h->pinned[2]));
+        HIP_TRY(h, hipEventRecord(h->ev_lay[2], st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        n_edges = h->pinned[2];
+        PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_edges * sizeof(po_edge), 256)));
+        if (n_edges) {
+            hipLaunchKernelGGL(po::k_layout_emit, dim3(cdiv(n_rows, 256)), dim3(256), 0, st, d_rows, n_rows, d_len,
+                               h->d_rflag.as<uint8_t>(), h->d_ewin.as<uint8_t>(), h->d_eoff.as<uint32_t>(),
+                               res->d_rows.as<po::Edge>());
+            HIP_TRY(h, hipGetLastError());
+        }
+    } else {
+        HIP_TRY(h, hipEventRecord(h->ev_lay[2], st));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_lay[3], st));
+    if (removed_out && n_names) HIP_TRY(h, hipMemcpyAsync(removed_out, h->d_removed.p, n_names, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    res->count = n_edges;
+    L.n_edges = n_edges;
+    (void)hipEventElapsedTime(&L.ms_classify, h->ev_lay[0], h->ev_lay[1]);
+    (void)hipEventElapsedTime(&L.ms_dedupe, h->ev_lay[1], h->ev_lay[2]);
+    (void)hipEventElapsedTime(&L.ms_emit, h->ev_lay[2], h->ev_lay[3]);
+    (void)hipEventElapsedTime(&L.ms_total, h->ev_lay[0], h->ev_lay[3]);
+    return PO_OK;
+}
+
+// ---- GFA2 reader for `phasm layout` (S and E lines) ---------------------------------------------
+
+struct Field {
+    const char* p;
+    size_t n;
+};
+
+// Python's line.strip().split('\t'), then .strip() of a field
+inline void strip(const char*& p, size_t& n) {
+    auto ws = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f' || c == '\v'; };
+    while (n && ws(p[0])) ++p, --n;
+    while (n && ws(p[n - 1])) --n;
+}
+
+size_t split_tabs(const char* p, size_t n, Field* out, size_t max_fields) {
+    strip(p, n);
+    size_t k = 0;
+    const char* f0 = p;
+    for (size_t i = 0; i <= n; ++i) {
+        if (i == n || p[i] == '\t') {
+            if (k < max_fields) out[k] = Field{f0, (size_t)(p + i - f0)};
+            ++k;
+            f0 = p + i + 1;
+        }
+    }
+    return k;
+}
+
+// int(text) for a decimal field (optional sign, surrounding blanks); _gfa_pos_to_int (gfa.py:65-69) drops one
+// trailing '$' first
+bool parse_int(Field f, bool allow_dollar, long long& out) {
+    const char* p = f.p;
+    size_t n = f.n;
+    if (allow_dollar && n && p[n - 1] == '$') --n;
+    strip(p, n);
+    if (!n) return false;
+    bool neg = false;
+    if (*p == '+' || *p == '-') {
+        neg = *p == '-';
+        ++p, --n;
+    }
+    if (!n || n > 18) return false;
+    long long v = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (p[i] < '0' || p[i] > '9') return false;
+        v = v * 10 + (p[i] - '0');
+    }
+    out = neg ? -v : v;
+    return true;
+}
+
+// name -> read index (the reference keeps a dict, gfa.py:107-109)
+struct NameIndex {
+    std::vector<uint32_t> slot;  // read index + 1, 0 = empty
+    uint32_t mask = 0;
+    static uint64_t hash(const char* p, size_t n) {
+        uint64_t x = 1469598103934665603ull;
+        for (size_t i = 0; i < n; ++i) x = (x ^ (unsigned char)p[i]) * 1099511628211ull;
+        return x ^ (x >> 29);
+    }
+    void build(const po_handle* h) {
+        const size_t n_names = h->ids.size() / 2;
+        size_t cap = 16;
+        while (cap < 2 * n_names + 2) cap <<= 1;
+        slot.assign(cap, 0);
+        mask = (uint32_t)(cap - 1);
+        for (size_t i = 0; i < n_names; ++i) {
+            const std::string& id = h->ids[2 * i];
+            uint32_t s = (uint32_t)hash(id.data(), id.size() - 1) & mask;
+            while (slot[s]) s = (s + 1) & mask;
+            slot[s] = (uint32_t)i + 1;
+        }
+    }
+    long find(const po_handle* h, const char* p, size_t n) const {
+        uint32_t s = (uint32_t)hash(p, n) & mask;
+        while (slot[s]) {
+            const std::string& id = h->ids[2 * (size_t)(slot[s] - 1)];
+            if (id.size() - 1 == n && std::memcmp(id.data(), p, n) == 0) return (long)slot[s] - 1;
+            s = (s + 1) & mask;
+        }
+        return -1;
+    }
+};
+
+po_status add_segment(po_handle* h, const char* name, size_t name_len, uint32_t length) {
+    if (!h->len.empty() && !h->segments_only)
+        return fail(h, PO_ERR_INVALID, "this handle already holds sequences; segments need a handle of their own");
+    if (h->len.size() >= 0xFFFFFFF0ull - 2) return fail(h, PO_ERR_CAPACITY, "too many reads");
+    h->segments_only = true;
+    std::string id(name ? name : "", name_len);
+    id.push_back('+');
+    h->ids.push_back(id);
+    id.back() = '-';
+    h->ids.push_back(id);
+    h->len.push_back(length);
+    h->len.push_back(length);
+    h->total_bases += 2ull * length;
+    h->ids_paired = -1;
+    return PO_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -820,9 +1053,13 @@ void po_destroy(po_handle* h) {
                           &h->d_table, &h->d_slot_cnt, &h->d_slot_cur, &h->d_slot_start, &h->d_read_slot, &h->d_chain,
                           &h->d_chain_tmp, &h->d_long_list, &h->d_bloom, &h->d_selfrep, &h->d_tile_count, &h->d_tile_off,
                           &h->d_ps_blocks, &h->d_scalars, &h->d_cand_a, &h->d_cand_p, &h->d_cand_b, &h->d_type,
-                          &h->d_rowcnt, &h->d_row_off, &h->d_flag, &h->d_pair_key, &h->d_pair_min, &h->spare_rows};
+                          &h->d_rowcnt, &h->d_row_off, &h->d_flag, &h->d_pair_key, &h->d_pair_min, &h->spare_rows,
+                          &h->d_lay_len, &h->d_lay_cnt, &h->d_rflag, &h->d_removed, &h->d_ekey, &h->d_ecnt,
+                          &h->d_ewin, &h->d_eoff};
         for (DevBuf* b : bufs) b->release();
         for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(h->ev[i]);
+        for (hipEvent_t e : h->ev_lay)
+            if (e) (void)hipEventDestroy(e);
         (void)hipEventDestroy(h->ev_up0);
         (void)hipEventDestroy(h->ev_up1);
         if (h->pinned) (void)hipHostFree(h->pinned);
@@ -840,6 +1077,7 @@ po_status po_set_device(po_handle* h, int device) {
 
 po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const char* seq, size_t seq_len) {
     if (!h || (!id && id_len) || (!seq && seq_len)) return PO_ERR_INVALID;
+    if (h->segments_only) return fail(h, PO_ERR_INVALID, "this handle holds GFA segments (no sequences); use a new handle");
     if (seq_len > 0x7FFFFFF0ull) return fail(h, PO_ERR_CAPACITY, "read longer than 2^31 bases");
     if (h->len.size() >= 0xFFFFFFF0ull) return fail(h, PO_ERR_CAPACITY, "too many reads");
     try {
@@ -852,6 +1090,7 @@ po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const cha
         h->len.push_back((uint32_t)seq_len);
         h->total_bases += seq_len;
         h->dirty = true;
+        h->ids_paired = -1;
         if (h->bits == 2 && (h->len.size() & 1) == 0 && !h->exc_pos.empty()) host_pair_check(h, h->len.size() - 1, s);
     } catch (const std::bad_alloc&) {
         return fail(h, PO_ERR_NOMEM, "out of host memory in po_add_sequence");
@@ -960,6 +1199,7 @@ static po_status overlaps_common(po_handle* h, uint32_t min_length, uint32_t sha
     if (!h || !out) return PO_ERR_INVALID;
     *out = nullptr;
     if (nshards == 0 || shard >= nshards) return fail(h, PO_ERR_INVALID, "shard must be < nshards");
+    if (h->segments_only) return fail(h, PO_ERR_INVALID, "this handle holds GFA segments without sequences: nothing to overlap");
     po_result* r = new (std::nothrow) po_result();
     if (!r) return fail(h, PO_ERR_NOMEM, "out of host memory");
     r->h = h;
@@ -993,6 +1233,7 @@ po_status po_candidates_shard(po_handle* h, uint32_t min_length, uint32_t shard,
 po_status po_expand(po_handle* h, const void* candidates_device, uint64_t n_candidates, po_result** out) {
     if (!h || !out || (!candidates_device && n_candidates)) return PO_ERR_INVALID;
     *out = nullptr;
+    if (h->segments_only) return fail(h, PO_ERR_INVALID, "this handle holds GFA segments without sequences");
     po_result* r = new (std::nothrow) po_result();
     if (!r) return fail(h, PO_ERR_NOMEM, "out of host memory");
     r->h = h;
@@ -1056,7 +1297,8 @@ po_status po_result_copy_to_device(po_result* r, void* dst_device) {
     if (!r || (!dst_device && r->count)) return PO_ERR_INVALID;
     if (r->count == 0) return PO_OK;
     po_handle* h = r->h;
-    HIP_TRY(h, hipSetDevice(h->device));
+    PO_TRY(init_device(h));
+    PO_TRY(rows_to_device(h, r));
     HIP_TRY(h, hipMemcpyAsync(dst_device, r->d_rows.p, r->count * r->elem, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return PO_OK;
@@ -1138,6 +1380,186 @@ po_status po_write_gfa_edges(po_result* r, int fd, uint64_t* lines_out) {
         return fail(h, PO_ERR_NOMEM, "out of host memory");
     }
     if (lines_out) *lines_out = r->count;
+    return PO_OK;
+}
+
+po_status po_add_segment(po_handle* h, const char* name, size_t name_len, uint32_t length) {
+    if (!h || (!name && name_len)) return PO_ERR_INVALID;
+    try {
+        return add_segment(h, name, name_len, length);
+    } catch (const std::bad_alloc&) {
+        return fail(h, PO_ERR_NOMEM, "out of host memory in po_add_segment");
+    }
+}
+
+po_status po_result_from_rows(po_handle* h, const po_row* rows, uint64_t n, po_result** out) {
+    if (!h || !out || (!rows && n)) return PO_ERR_INVALID;
+    *out = nullptr;
+    po_result* r = new (std::nothrow) po_result();
+    if (!r) return fail(h, PO_ERR_NOMEM, "out of host memory");
+    r->h = h;
+    r->count = n;
+    if (n) {
+        r->host = std::malloc(n * sizeof(po_row));
+        if (!r->host) {
+            delete r;
+            return fail(h, PO_ERR_NOMEM, "out of host memory for the row array");
+        }
+        std::memcpy(r->host, rows, n * sizeof(po_row));
+    }
+    ++h->live_results;
+    *out = r;
+    return PO_OK;
+}
+
+po_status po_add_gfa(po_handle* h, const char* path, uint64_t* n_segments, po_result** rows_out) {
+    if (!h || !path || !rows_out) return PO_ERR_INVALID;
+    *rows_out = nullptr;
+    if (n_segments) *n_segments = 0;
+    if (!h->len.empty()) return fail(h, PO_ERR_INVALID, "po_add_gfa needs an empty handle");
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return fail(h, PO_ERR_INVALID, std::string("cannot open ") + path);
+    struct stat sb;
+    if (::fstat(fd, &sb) != 0) {
+        ::close(fd);
+        return fail(h, PO_ERR_INVALID, std::string("cannot stat ") + path);
+    }
+    const size_t size = (size_t)sb.st_size;
+    const char* data = nullptr;
+    if (size) {
+        void* m = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) {
+            ::close(fd);
+            return fail(h, PO_ERR_INVALID, std::string("cannot map ") + path);
+        }
+        data = static_cast<const char*>(m);
+    }
+    po_status st = PO_OK;
+    std::vector<po_row> rows;
+    try {
+        // every line of the file, '\n'-terminated (a '\r' before it is white space to strip())
+        auto for_lines = [&](char tag, auto&& fn) {
+            size_t pos = 0;
+            while (pos < size && st == PO_OK) {
+                const char* nl = static_cast<const char*>(std::memchr(data + pos, '\n', size - pos));
+                const size_t len = nl ? (size_t)(nl - (data + pos)) : size - pos;
+                if (len && data[pos] == tag) fn(data + pos, len);
+                pos += len + 1;
+            }
+        };
+        // pass 1: segments (gfa2_segment_to_read, gfa.py:33-46)
+        NameIndex idx;
+        std::vector<std::pair<std::string, uint32_t>> segs;
+        std::unordered_map<std::string, size_t> seen;
+        for_lines('S', [&](const char* p, size_t n) {
+            Field f[4];
+            long long length = 0;
+            if (split_tabs(p, n, f, 4) < 4 || !parse_int(f[2], false, length) || length < 0 || length > 0x7FFFFFF0ll) {
+                st = fail(h, PO_ERR_INVALID, "malformed GFA2 segment line: " + std::string(p, std::min<size_t>(n, 80)));
+                return;
+            }
+            strip(f[1].p, f[1].n);
+            std::string name(f[1].p, f[1].n);
+            auto it = seen.find(name);
+            if (it != seen.end()) {
+                segs[it->second].second = (uint32_t)length;  // dict semantics: one entry per name, the last length wins (gfa.py:109)
+            } else {
+                seen.emplace(name, segs.size());
+                segs.emplace_back(std::move(name), (uint32_t)length);
+            }
+        });
+        seen.clear();
+        if (st == PO_OK) {
+            for (auto& sgm : segs) {
+                if ((st = add_segment(h, sgm.first.data(), sgm.first.size(), sgm.second)) != PO_OK) break;
+            }
+        }
+        if (st == PO_OK) idx.build(h);
+        if (n_segments) *n_segments = segs.size();
+        segs.clear();
+        segs.shrink_to_fit();
+        // pass 2: edges (gfa2_parse_edge, gfa.py:72-87; gfa2_line_to_la, :90-104)
+        const char* last_a = nullptr;
+        size_t last_a_n = 0;
+        long last_a_idx = -1;
+        auto node_of = [&](Field f, bool cache) -> long {
+            strip(f.p, f.n);
+            if (f.n < 1) return -1;
+            const char strand = f.p[f.n - 1];
+            if (strand != '+' && strand != '-') return -1;
+            long r;
+            if (cache && last_a && last_a_n == f.n - 1 && std::memcmp(last_a, f.p, f.n - 1) == 0) {
+                r = last_a_idx;
+            } else {
+                r = idx.find(h, f.p, f.n - 1);
+                if (cache) last_a = f.p, last_a_n = f.n - 1, last_a_idx = r;
+            }
+            return r < 0 ? -1 : 2 * r + (strand == '-');
+        };
+        if (st == PO_OK) {
+            for_lines('E', [&](const char* p, size_t n) {
+                Field f[9];
+                long long v[4];
+                if (split_tabs(p, n, f, 9) < 9 || !parse_int(f[4], true, v[0]) || !parse_int(f[5], true, v[1]) ||
+                    !parse_int(f[6], true, v[2]) || !parse_int(f[7], true, v[3])) {
+                    st = fail(h, PO_ERR_INVALID, "malformed GFA2 edge line: " + std::string(p, std::min<size_t>(n, 80)));
+                    return;
+                }
+                const long a = node_of(f[2], true), b = node_of(f[3], false);
+                if (a < 0 || b < 0) {
+                    st = fail(h, PO_ERR_INVALID, "GFA2 edge names an unknown segment or strand: " + std::string(p, std::min<size_t>(n, 80)));
+                    return;
+                }
+                for (long long x : v)
+                    if (x < -0x7FFFFFFFll || x > 0x7FFFFFFFll) {
+                        st = fail(h, PO_ERR_INVALID, "GFA2 edge position out of range");
+                        return;
+                    }
+                rows.push_back(po_row{(uint32_t)a, (uint32_t)b, (int32_t)v[0], (int32_t)v[1], (int32_t)v[2], (int32_t)v[3]});
+            });
+        }
+    } catch (const std::bad_alloc&) {
+        st = fail(h, PO_ERR_NOMEM, "out of host memory in po_add_gfa");
+    }
+    if (data) ::munmap(const_cast<char*>(data), size);
+    ::close(fd);
+    if (st != PO_OK) return st;
+    return po_result_from_rows(h, rows.data(), rows.size(), rows_out);
+}
+
+po_status po_layout_edges(po_handle* h, po_result* rows, const po_layout_params* params, uint8_t* removed_reads_out,
+                          po_result** edges_out) {
+    if (!h || !rows || !params || !edges_out) return PO_ERR_INVALID;
+    *edges_out = nullptr;
+    if (rows->h != h) return fail(h, PO_ERR_INVALID, "po_layout_edges: the rows belong to another handle");
+    if (rows->elem != sizeof(po_row)) return fail(h, PO_ERR_INVALID, "po_layout_edges needs a row result");
+    if (params->reserved != 0 || !(params->max_overhang_rel == params->max_overhang_rel))
+        return fail(h, PO_ERR_INVALID, "po_layout_edges: bad parameters");
+    if (!ids_are_strand_pairs(h))
+        return fail(h, PO_ERR_INVALID, "po_layout_edges needs reads added as name+\"+\" / name+\"-\" pairs");
+    po_result* r = new (std::nothrow) po_result();
+    if (!r) return fail(h, PO_ERR_NOMEM, "out of host memory");
+    r->h = h;
+    po_status st;
+    try {
+        st = run_layout(h, rows, *params, removed_reads_out, r);
+    } catch (const std::bad_alloc&) {
+        st = fail(h, PO_ERR_NOMEM, "out of host memory in po_layout_edges");
+    }
+    if (st != PO_OK) {
+        if (h->dev_ready) (void)hipStreamSynchronize(h->stream);
+        r->d_rows.release();
+        delete r;
+        return st;
+    }
+    ++h->live_results;
+    *edges_out = r;
+    return PO_OK;
+}
+
+po_status po_get_layout_stats(const po_handle* h, po_layout_stats* out) {
+    if (!h || !out) return PO_ERR_INVALID;
+    *out = h->lstats;
     return PO_OK;
 }
 

@@ -25,7 +25,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import CAND_DTYPE, ROW_DTYPE, PoStats
+from ._lib import CAND_DTYPE, EDGE_DTYPE, ROW_DTYPE, PoLayoutParams, PoLayoutStats, PoStats
 
 OverlapT = Tuple[str, str, int, int, int, int]
 
@@ -184,6 +184,50 @@ class ExactOverlapper:
 
     def upload(self) -> None:
         _check(self._h, self._lib.po_upload(self._h))
+
+    # ---- the consumer side: stage 1 of `phasm layout` (phasm_amd/layout.py is the host mirror) ----
+    def add_segment(self, name, length: int) -> None:
+        """One GFA2 ``S`` line without sequence (``po_add_segment``): nodes ``name+`` and ``name-``."""
+        b = _to_bytes(name, "name")
+        _check(self._h, self._lib.po_add_segment(self._h, b, len(b), int(length)))
+
+    def add_gfa(self, path: str) -> Tuple[int, OverlapResult]:
+        """Read a GFA2 file into this (empty) handle: segments become sequence-less reads, ``E`` lines
+        the returned row result (``po_add_gfa``).  Returns (segment count, rows)."""
+        n = ctypes.c_uint64()
+        r = ctypes.c_void_p()
+        _check(self._h, self._lib.po_add_gfa(self._h, os.fsencode(path), ctypes.byref(n), ctypes.byref(r)))
+        return int(n.value), OverlapResult(self, r)
+
+    def result_from_rows(self, rows: np.ndarray) -> OverlapResult:
+        """Wrap caller-supplied rows (structured ROW_DTYPE or int array [n, 6]) into a result."""
+        if rows.dtype != ROW_DTYPE:
+            arr = np.asarray(rows)
+            out = np.empty(len(arr), dtype=ROW_DTYPE)
+            for k, name in enumerate(ROW_DTYPE.names):
+                out[name] = arr[:, k]
+            rows = out
+        rows = np.ascontiguousarray(rows)
+        r = ctypes.c_void_p()
+        _check(self._h, self._lib.po_result_from_rows(self._h, rows.ctypes.data_as(ctypes.c_void_p), len(rows), ctypes.byref(r)))
+        return OverlapResult(self, r)
+
+    def layout_edges(self, rows: OverlapResult, min_read_length: int = 0, min_overlap_length: int = 0,
+                     max_overhang_abs: int = 1000, max_overhang_rel: float = 0.8,
+                     want_removed: bool = True) -> Tuple[OverlapResult, Optional[np.ndarray]]:
+        """``po_layout_edges``: assembly-graph edges (EDGE_DTYPE result) and the contained-read flags."""
+        prm = PoLayoutParams(int(min_read_length), int(min_overlap_length), int(max_overhang_abs), 0, float(max_overhang_rel))
+        removed = np.zeros(len(self) // 2, dtype=np.uint8) if want_removed else None
+        r = ctypes.c_void_p()
+        _check(self._h, self._lib.po_layout_edges(
+            self._h, rows._ptr, ctypes.byref(prm),
+            removed.ctypes.data_as(ctypes.c_void_p) if removed is not None and len(removed) else None, ctypes.byref(r)))
+        return OverlapResult(self, r, EDGE_DTYPE), removed
+
+    def layout_stats(self) -> dict:
+        s = PoLayoutStats()
+        _check(self._h, self._lib.po_get_layout_stats(self._h, ctypes.byref(s)))
+        return s.as_dict()
 
     def __len__(self) -> int:
         return int(self._lib.po_num_sequences(self._h))

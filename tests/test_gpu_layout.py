@@ -1,0 +1,130 @@
+"""Stage 1 of `phasm layout` on the device (po_layout_edges) against the layout oracle, whose filter
+decisions are pinned by the reference's own classes (tests/golden/layout_cases.json).  Bit-exact
+integers; the edge list is compared as a sorted set (the reference's graph has no edge order)."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_utils as gu
+import layout_utils as lu
+from oracle import layout_oracle as lo
+from phasm_amd import layout, synth
+from phasm_amd.overlapper import ExactOverlapper
+
+pytestmark = pytest.mark.gpu
+
+CASES = lu.load_cases()
+
+
+def edge_array(e):
+    arr = np.stack([e["u"], e["v"], e["weight"], e["overlap_len"]], 1).astype(np.int64) if len(e) else np.empty((0, 4), np.int64)
+    return arr[np.lexsort((arr[:, 1], arr[:, 0]))] if len(arr) else arr
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_layout_edges_from_gfa_file_match_oracle(case, tmp_path):
+    p = tmp_path / "in.gfa"
+    p.write_text(case["text"])
+    got = layout.layout_from_gfa(str(p), **case["params"])
+    L = lu.node_lengths(case["lengths"])
+    want = lo.layout_sequential(case["rows"], L, **case["params"])
+    assert np.array_equal(edge_array(got.edges), lo.edges_dict_to_array(want["edges"]))
+    contained = np.zeros(len(case["names"]), dtype=bool)
+    for n in want["filters"][0]["nodes_to_remove"]:
+        contained[n >> 1] = True
+    assert got.contained.tolist() == contained.tolist()
+    st = got.stats
+    assert st["n_rows"] == len(case["rows"])
+    assert st["n_type"] == [want["types"].count(t) for t in range(4)]       # = the reference's classify() counts
+    assert st["n_contained_reads"] == int(contained.sum())
+    assert st["n_edges"] == len(want["edges"])
+    # the sequential pass count is a lower bound of the per-row predicate count (it also drops rows whose
+    # read was already known to be contained)
+    assert st["n_pass"] >= len(want["passed"])
+    assert st["n_pass"] + st["n_short"] + st["n_min_overlap"] + st["n_overhang"] == st["n_type"][0] + st["n_type"][1]
+
+
+@pytest.mark.parametrize("name", ["ladder_varlen", "ladder_cfg1_mini", "cfg1_full"])
+def test_overlap_then_layout_without_a_file(name):
+    """Rows straight from po_overlaps (still in HBM) into po_layout_edges."""
+    _, seqs, m, _ = gu.ladder_case(name)
+    ov = ExactOverlapper()
+    for i in range(len(seqs) // 2):
+        ov.add_sequence("read%d+" % i, seqs[2 * i])
+        ov.add_sequence("read%d-" % i, seqs[2 * i + 1])
+    res = ov.overlaps_result(m)
+    rows = res.rows()
+    for params in (layout.DEFAULTS, dict(layout.DEFAULTS, min_read_length=5000, min_overlap_length=2000)):
+        got = layout.build_assembly_graph(ov, res, **params)
+        r6 = np.stack([rows[k] for k in rows.dtype.names], 1).astype(np.int64)
+        want = lo.layout_vectorised(r6, ov.lengths(), **params)
+        assert np.array_equal(edge_array(got.edges), want["edges"])
+        assert got.contained.tolist() == want["contained"].tolist()
+        # exact overlaps have no overhang and every B row is a containment
+        assert got.stats["n_overhang"] == 0
+        assert got.stats["n_type"][1] == 0
+    res.free()
+    ov.close()
+
+
+def test_random_bulk_rows_against_vectorised_oracle():
+    rng = np.random.default_rng(42)
+    n_names = 3000
+    lengths = rng.integers(200, 3000, n_names)
+    L = np.repeat(lengths, 2)
+    n = 400_000
+    a = rng.integers(0, 2 * n_names, n)
+    b = rng.integers(0, 2 * n_names, n)
+    # the last 5 % of the rows: arbitrary ranges (every type, many containments) among the first 600 reads only,
+    # so that the other reads stay in the graph
+    g = n - n // 20
+    a[g:] = rng.integers(0, 1200, n - g)
+    b[g:] = rng.integers(0, 1200, n - g)
+    la, lb = L[a], L[b]
+    s = (rng.random(n) * la * 0.9).astype(np.int64)
+    e = s + 1 + (rng.random(n) * (la - s - 1)).astype(np.int64)
+    bs = (rng.random(n) * lb * 0.3).astype(np.int64)
+    be = bs + 1 + (rng.random(n) * (lb - bs - 1)).astype(np.int64)
+    # the rest: dovetails (a suffix of a = a prefix of b, shorter than both), some with small overhangs
+    l = np.maximum(np.minimum(la[:g], lb[:g]) // 2 - rng.integers(0, 50, g), 1)
+    oa = rng.integers(0, 3, g) * rng.integers(0, 20, g)
+    ob = rng.integers(0, 3, g) * rng.integers(0, 20, g)
+    oa = np.minimum(oa, la[:g] - l)
+    ob = np.minimum(ob, lb[:g] - l)
+    s[:g], e[:g], bs[:g], be[:g] = la[:g] - l - oa, la[:g] - oa, ob, ob + l
+    rows = np.stack([a, b, s, e, bs, be], 1)
+    ov = ExactOverlapper()
+    for i in range(n_names):
+        ov.add_segment("r%d" % i, int(lengths[i]))
+    res = ov.result_from_rows(rows)
+    for params in (layout.DEFAULTS, dict(min_read_length=400, min_overlap_length=150, max_overhang_abs=60, max_overhang_rel=0.3)):
+        got = layout.build_assembly_graph(ov, res, **params)
+        want = lo.layout_vectorised(rows, L, **params)
+        assert np.array_equal(edge_array(got.edges), want["edges"])
+        assert got.contained.tolist() == want["contained"].tolist()
+        assert got.stats["n_edges"] == len(want["edges"]) > 1000
+    res.free()
+    ov.close()
+
+
+def test_layout_needs_strand_paired_ids_and_own_rows():
+    ov = ExactOverlapper()
+    ov.add_sequence("a", "ACGTACGTAA")
+    ov.add_sequence("b", "ACGTAAGGTT")
+    res = ov.overlaps_result(3)
+    with pytest.raises(ValueError):
+        ov.layout_edges(res)
+    other = ExactOverlapper()
+    other.add_segment("x", 10)
+    with pytest.raises(ValueError):
+        other.layout_edges(res)
+    bad = other.result_from_rows(np.array([[0, 7, 0, 5, 0, 5]]))
+    with pytest.raises(ValueError):
+        other.layout_edges(bad)                 # node 7 does not exist
+    empty = other.result_from_rows(np.empty((0, 6), dtype=np.int64))
+    e, removed = other.layout_edges(empty)
+    assert len(e) == 0 and removed.tolist() == [0]
+    res.free()
+    ov.close()
+    other.close()
