@@ -63,6 +63,49 @@ def cpu_baseline(min_length: int, sample_reads: int) -> dict:
             "host_cores_available": os.cpu_count()}
 
 
+def layout_leg(ov: ExactOverlapper, m: int, with_cpu: bool) -> dict:
+    """Next row of the path: stage 1 of `phasm layout` -- classify, contained-read
+    and alignment filters, assembly-graph edges -- on the rows of one step, still resident in HBM."""
+    res = ov.overlaps_result(m)
+    for _ in range(2):
+        e, _r = ov.layout_edges(res, want_removed=False)
+        e.free()
+    K = 10
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    acc = 0.0
+    for _ in range(K):
+        e, _r = ov.layout_edges(res, want_removed=False)
+        acc += ov.layout_stats()["ms_total"]
+        e.free()
+    dt = (time.perf_counter() - t0) / K
+    st = ov.layout_stats()
+    algo = 24 * st["n_rows"] + 16 * st["n_edges"]           # every row read once, every edge written once
+    out = {"rows_per_sec": st["n_rows"] / dt, "ms_per_call": dt * 1e3, "device_ms": acc / K,
+           "n_rows": st["n_rows"], "n_edges": st["n_edges"], "n_contained_reads": st["n_contained_reads"],
+           "stage_ms": {k: round(st[k], 4) for k in ("ms_classify", "ms_dedupe", "ms_emit")},
+           "roofline": {"bound": "hbm", "kernel": "k_layout_insert + k_layout_winner (hash table, random access)",
+                        "achieved": algo / (acc / K * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo / (acc / K * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_call": int(algo)}}
+    if with_cpu:
+        from oracle import layout_oracle as lo
+        from oracle import overlap_oracle as oo
+        rows = oo.struct_to_rows(res.rows()[:1_000_000])
+        L = ov.lengths()
+        t1 = time.perf_counter()
+        lo.layout_vectorised(rows, L)
+        tv = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        lo.layout_sequential(rows[:100_000], L)
+        ts = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": len(rows) / tv, "unit": "rows/s", "cores": 1, "kind": "port",
+                               "sample": "first %d rows of the same step, numpy restatement (oracle/layout_oracle.py)" % len(rows),
+                               "literal_python_rows_per_sec": 100_000 / ts}
+    res.free()
+    return out
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,6 +252,7 @@ def main() -> int:
             res.free()
             out["pcie_inclusive"] = {"overlaps_per_sec": n_rows / (time.perf_counter() - t1),
                                      "note": "one step + D2H of the 24-byte row array to pageable host memory"}
+            out["layout_stage1"] = layout_leg(ov, m, not args.no_cpu_baseline)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(m, args.cpu_sample_reads)
     if world > 1:

@@ -100,9 +100,31 @@ SYMBOLS = [
 _lib = None
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch wheels bundle their own ``libamdhip64.so`` (SONAME
+    ``libamdhip64.so.7``) and link to it by its unversioned file name, so a process that loads this
+    library first (bound to /opt/rocm's copy) and torch afterwards ends up with two runtimes, and the second
+    one finds no device.  Loading torch's copy first -- by path, without importing torch -- makes both bind
+    to the same one, whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> ctypes.CDLL:
     global _lib
     if _lib is None:
+        _preload_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "%s not found: build it with `python -m phasm_amd.build` (hipcc, gfx950). "

@@ -8,6 +8,14 @@ rows -- all ``S`` lines first, then the ``E`` lines.  Row order differs from the
 rows are a-major in FASTA order, then by start position.
 
     python -m phasm_amd.cli overlap reads.fasta -l 1000 -o overlaps.gfa
+
+``layout-edges`` is the first stage of ``phasm layout`` (assembler.py:52-139, options :469-489) on the
+same device: read the overlap file, classify and filter the alignments, drop contained reads, and
+write the assembly graph as it stands before graph cleaning, in the reference's own graph format
+(``gfa2_write_graph``, phasm/io/gfa.py:283-327: one ``S`` line per read that still has an edge, one
+``E * u v weight len(u) 0 overlap_len *`` line per edge).
+
+    python -m phasm_amd.cli layout-edges overlaps.gfa -o graph.gfa
 """
 from __future__ import annotations
 
@@ -18,6 +26,7 @@ import sys
 from .io import gfa
 from .io.fasta import read_fasta, reverse_complement
 from .overlapper import ExactOverlapper
+from . import layout as layout_mod
 
 logger = logging.getLogger("phasm_amd")
 
@@ -55,6 +64,45 @@ def overlap(args) -> int:
     return n
 
 
+def write_stage1_graph(out, g: "layout_mod.AssemblyEdges", lengths) -> int:
+    """The graph after stage 1 in the format of gfa2_write_graph (phasm/io/gfa.py:283-327)."""
+    out.write(gfa.gfa_header())
+    e = g.edges
+    ids = g.ids
+    import numpy as np
+    used = np.zeros(len(ids) // 2, dtype=bool)
+    used[e["u"] >> 1] = True
+    used[e["v"] >> 1] = True
+    for i in np.flatnonzero(used).tolist():
+        out.write(gfa.gfa_line("S", ids[2 * i][:-1], int(lengths[2 * i]), "*"))
+    lu = np.asarray(lengths)[e["u"]]
+    chunk = 1 << 18
+    for lo in range(0, len(e), chunk):
+        sl = slice(lo, lo + chunk)
+        out.write("".join("E\t*\t%s\t%s\t%d\t%d\t0\t%d\t*\n" % t for t in
+                          zip([ids[u] for u in e["u"][sl].tolist()], [ids[v] for v in e["v"][sl].tolist()],
+                              e["weight"][sl].tolist(), lu[sl].tolist(), e["overlap_len"][sl].tolist())))
+    return len(e)
+
+
+def layout_edges(args) -> int:
+    ov = ExactOverlapper(device=getattr(args, "device", None))
+    try:
+        nseg, rows = ov.add_gfa(args.gfa_file)
+        logger.info("Read %d reads and %d local alignments from the GFA2 file.", nseg, len(rows))
+        try:
+            g = layout_mod.build_assembly_graph(ov, rows, args.min_read_length, args.min_overlap_length,
+                                                args.max_overhang_abs, args.max_overhang_rel)
+        finally:
+            rows.free()
+        st = g.stats
+        logger.info("%d contained reads removed; %d alignments pass the filters; graph has %d edges.",
+                    st["n_contained_reads"], st["n_pass"], st["n_edges"])
+        return write_stage1_graph(args.output, g, ov.lengths())
+    finally:
+        ov.close()
+
+
 def main(argv=None) -> int:
     parser = argparse.ArgumentParser(prog="phasm-amd", description="MI355X-native PHASM overlap step")
     parser.add_argument("-v", "--verbose", action="count", default=0)
@@ -68,6 +116,17 @@ def main(argv=None) -> int:
     p.add_argument("--python-ingest", action="store_true", help="parse the FASTA in Python instead of po_add_fasta")
     p.add_argument("fasta_input", help="FASTA file with reads")
     p.set_defaults(func=overlap)
+    # option names and defaults of `phasm layout`, assembler.py:469-489
+    q = sub.add_parser("layout-edges", help="Stage 1 of `phasm layout`: filter the alignments of an overlap file and "
+                                            "write the assembly graph before graph cleaning.")
+    q.add_argument("-l", "--min-read-length", type=int, default=0)
+    q.add_argument("-s", "--min-overlap-length", type=int, default=0)
+    q.add_argument("-a", "--max-overhang-abs", type=int, default=1000)
+    q.add_argument("-r", "--max-overhang-rel", type=float, default=0.8)
+    q.add_argument("-o", "--output", type=argparse.FileType("w"), default=sys.stdout)
+    q.add_argument("--device", type=int, default=None)
+    q.add_argument("gfa_file", help="GFA2 file with the reads (S lines) and their pairwise alignments (E lines)")
+    q.set_defaults(func=layout_edges)
     args = parser.parse_args(argv)
     if not getattr(args, "func", None):
         parser.print_help()

@@ -888,10 +888,10 @@ po_status run_layout(po_handle* h, po_result* rows, const po_layout_params& prm,
     L.n_contained_reads = c[po::LC_N];
     uint64_t n_edges = 0;
     if (L.n_pass) {
-        // (u, v) -> last writer: 3 slots per surviving row (<= 2 distinct edges each: load <= 2/3, 1/3 when
-        // every edge has its strand-mirror twin), 16-byte slots
-        if (3 * L.n_pass + 64 >= 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "po_layout_edges: too many edges for one call");
-        const uint32_t n_slots = (uint32_t)(3 * L.n_pass + 64);
+        // twin pair -> last writer row: 2 slots per surviving row (load <= 1/2; 1/4 when every row has its
+        // strand-mirror twin), 16-byte slots
+        if (2 * L.n_pass + 64 >= 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "po_layout_edges: too many edges for one call");
+        const uint32_t n_slots = (uint32_t)(2 * L.n_pass + 64);
         PO_TRY(ensure(h, h->d_ekey, (size_t)n_slots * sizeof(po::EdgeSlot)));
         PO_TRY(ensure(h, h->d_ecnt, (size_t)n_rows));
         PO_TRY(ensure(h, h->d_ewin, (size_t)n_rows));

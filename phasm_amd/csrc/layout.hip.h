@@ -14,6 +14,7 @@
 //   edges  = the two edges of every pass row with neither read in C, one record per distinct
 //            (u, v): networkx's add_edge overwrites the attributes of an existing edge, so the
 //            row that comes LAST in the array owns the edge    (k_layout_insert / _winner / _emit)
+//            -- a hash table keyed by the twin pair {(u, v), (v^1, u^1)} with an atomic max of the row
 // Nodes are oriented-read indices; the reverse node of x is x ^ 1 (reads are added as x+ / x-).
 #pragma once
 
@@ -45,7 +46,7 @@ constexpr unsigned long long EDGE_EMPTY = ~0ull;
 // the atomicMax and the later lookup touch one cache line
 struct __attribute__((aligned(16))) EdgeSlot {
     unsigned long long key;  // u << 32 | v; EDGE_EMPTY = free (memset 0xFF)
-    uint32_t writer;         // ~(2 * row + k): memset 0xFF = "no writer"; the smallest complement = the last row
+    uint32_t writer;         // ~row: memset 0xFF = "no writer"; the smallest complement = the last row
     uint32_t pad;
 };
 
@@ -139,9 +140,20 @@ __global__ __launch_bounds__(256) void k_layout_classify(const Row* __restrict__
     block_add<LC_N>(c, counters);
 }
 
-// Pass 2: every edge of a surviving row claims its (u, v) slot; the largest writer id 2*row + k stays
-// (stored complemented, so one memset(0xFF) initialises keys and writers) -- the row that the
-// reference's add_edge would have applied last.
+// The two edges of a row are twins: e2 = (v1 ^ 1, u1 ^ 1).  Every row that writes (u, v) also writes its
+// twin, so both edges have the same set of writers and the same LAST writer row: one table entry per twin
+// pair -- keyed by the smaller of the two 64-bit keys -- is enough.  (u == v ^ 1 makes the two edges one
+// and the same; the reference then applies edge 2 after edge 1, so edge 2's attributes stay.)
+__device__ inline unsigned long long pair_key(const Edge& e1, const Edge& e2, bool& self_twin) {
+    const unsigned long long k1 = ((unsigned long long)e1.u << 32) | e1.v;
+    const unsigned long long k2 = ((unsigned long long)e2.u << 32) | e2.v;
+    self_twin = k1 == k2;
+    return k1 < k2 ? k1 : k2;
+}
+
+// Pass 2: every surviving row claims the slot of its twin pair; the largest row index stays (stored
+// complemented, so one memset(0xFF) initialises keys and writers) -- the row whose add_edge calls the
+// reference would have applied last.
 __global__ __launch_bounds__(256) void k_layout_insert(const Row* __restrict__ rows, uint32_t n_rows,
                                                        const uint32_t* __restrict__ len,
                                                        const uint8_t* __restrict__ rflag,
@@ -152,24 +164,22 @@ __global__ __launch_bounds__(256) void k_layout_insert(const Row* __restrict__ r
         if (!(f & RF_PASS)) continue;
         const Row r = rows[i];
         if (removed[r.a_idx >> 1] | removed[r.b_idx >> 1]) continue;
-        Edge e[2];
-        row_edges(r, f & RF_TYPE, len[r.a_idx], len[r.b_idx], e[0], e[1]);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const unsigned long long key = ((unsigned long long)e[k].u << 32) | e[k].v;
-            uint32_t s = edge_slot(e[k].u, e[k].v, n_slots);
-            for (;;) {
-                unsigned long long cur = table[s].key;
-                if (cur == EDGE_EMPTY) cur = atomicCAS(&table[s].key, EDGE_EMPTY, key);
-                if (cur == EDGE_EMPTY || cur == key) break;
-                if (++s == n_slots) s = 0;
-            }
-            atomicMin(&table[s].writer, ~(2u * i + (uint32_t)k));
+        Edge e1, e2;
+        row_edges(r, f & RF_TYPE, len[r.a_idx], len[r.b_idx], e1, e2);
+        bool self_twin;
+        const unsigned long long key = pair_key(e1, e2, self_twin);
+        uint32_t s = edge_slot((uint32_t)(key >> 32), (uint32_t)key, n_slots);
+        for (;;) {
+            unsigned long long cur = table[s].key;
+            if (cur == EDGE_EMPTY) cur = atomicCAS(&table[s].key, EDGE_EMPTY, key);
+            if (cur == EDGE_EMPTY || cur == key) break;
+            if (++s == n_slots) s = 0;
         }
+        atomicMin(&table[s].writer, ~i);
     }
 }
 
-// Pass 3: which of its two edges does each row own?  ewin bit k = edge k; ecnt = how many.
+// Pass 3: does this row own its twin pair?  ewin bit k = edge k is emitted; ecnt = how many.
 __global__ __launch_bounds__(256) void k_layout_winner(const Row* __restrict__ rows, uint32_t n_rows,
                                                        const uint32_t* __restrict__ len,
                                                        const uint8_t* __restrict__ rflag,
@@ -183,20 +193,18 @@ __global__ __launch_bounds__(256) void k_layout_winner(const Row* __restrict__ r
     if (f & RF_PASS) {
         const Row r = rows[i];
         if (!(removed[r.a_idx >> 1] | removed[r.b_idx >> 1])) {
-            Edge e[2];
-            row_edges(r, f & RF_TYPE, len[r.a_idx], len[r.b_idx], e[0], e[1]);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const unsigned long long key = ((unsigned long long)e[k].u << 32) | e[k].v;
-                uint32_t s = edge_slot(e[k].u, e[k].v, n_slots);
-                for (;;) {  // k_layout_insert put the key there
-                    const uint4 q = *reinterpret_cast<const uint4*>(&table[s]);
-                    if ((((unsigned long long)q.y << 32) | q.x) == key) {
-                        if (q.z == ~(2u * i + (uint32_t)k)) win |= 1u << k;
-                        break;
-                    }
-                    if (++s == n_slots) s = 0;
+            Edge e1, e2;
+            row_edges(r, f & RF_TYPE, len[r.a_idx], len[r.b_idx], e1, e2);
+            bool self_twin;
+            const unsigned long long key = pair_key(e1, e2, self_twin);
+            uint32_t s = edge_slot((uint32_t)(key >> 32), (uint32_t)key, n_slots);
+            for (;;) {  // k_layout_insert put the key there
+                const uint4 q = *reinterpret_cast<const uint4*>(&table[s]);
+                if ((((unsigned long long)q.y << 32) | q.x) == key) {
+                    if (q.z == ~i) win = self_twin ? 2u : 3u;
+                    break;
                 }
+                if (++s == n_slots) s = 0;
             }
         }
     }

@@ -128,3 +128,33 @@ def test_layout_needs_strand_paired_ids_and_own_rows():
     res.free()
     ov.close()
     other.close()
+
+
+def test_cli_overlap_then_layout_edges_files(tmp_path):
+    """reads.fasta -> `overlap` -> overlaps.gfa -> `layout-edges` -> graph.gfa in gfa2_write_graph's
+    format (phasm/io/gfa.py:283-327); the edges equal the oracle's for the rows of the overlap file."""
+    from phasm_amd import cli
+    from phasm_amd.io import gfa
+    cfg = synth.SynthConfig(n_reads=150, read_len=5000, genome_len=40_000, ploidy=2, snp=0.005, seed=21,
+                            len_sd=1500.0, len_min=1000, len_max=9000)      # variable lengths: containments
+    reads = synth.generate_reads(cfg)
+    fa = tmp_path / "reads.fasta"
+    synth.write_fasta(str(fa), reads, width=80)
+    ovl = tmp_path / "overlaps.gfa"
+    graph = tmp_path / "graph.gfa"
+    assert cli.main(["overlap", str(fa), "-l", "500", "-o", str(ovl)]) == 0
+    assert cli.main(["layout-edges", str(ovl), "-l", "3000", "-s", "800", "-o", str(graph)]) == 0
+    names, lengths, rows = gfa.read_gfa2_rows(ovl.read_text().splitlines(True))
+    L = np.repeat(lengths, 2)
+    want = lo.layout_sequential(rows, L, min_read_length=3000, min_overlap_length=800)
+    assert len(want["edges"]) > 50
+    lines = graph.read_text().splitlines(True)
+    assert lines[0] == "H\tVN:z:2.0\n"
+    s_lines = [l for l in lines if l.startswith("S\t")]
+    e_lines = [l for l in lines if l.startswith("E\t")]
+    assert len(lines) == 1 + len(s_lines) + len(e_lines)
+    node = lambda n: names[n >> 1] + "+-"[n & 1]
+    want_e = sorted(gfa.gfa_line("E", "*", node(u), node(v), w, int(L[u]), 0, o, "*") for (u, v), (w, o) in want["edges"].items())
+    assert sorted(e_lines) == want_e
+    used = sorted({n >> 1 for uv in want["edges"] for n in uv})
+    assert s_lines == [gfa.gfa_line("S", names[i], int(lengths[i]), "*") for i in used]
