@@ -228,7 +228,7 @@ def main() -> int:
             "candidates_per_step": int(last["n_candidates"]),
             "stage_ms": {k: round(v, 4) for k, v in avg.items()},
             "load_seconds": round(t_load, 1),
-            "roofline": {"bound": "hbm", "kernel": "k_verify_a<%d>" % last["bits_per_base"],
+            "roofline": {"bound": "hbm", "kernel": "k_verify_a<%d, %s>" % (last["bits_per_base"], "true" if world > 1 else "false"),
                          "achieved": ver_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ver_gbs / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": int(ver_bytes),
@@ -241,7 +241,7 @@ def main() -> int:
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 tr = json.load(f).get(args.config, {}) if not args.reads and world == 1 else {}
-            out["roofline"]["traffic"] = tr.get("k_verify_a<%d>" % last["bits_per_base"])
+            out["roofline"]["traffic"] = tr.get("k_verify_a<%d, false>" % last["bits_per_base"])
         except (OSError, ValueError):
             pass
         if world == 1:

@@ -436,8 +436,10 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     S.kmer = K;
     S.n_reads = n;
     S.total_bases = h->total_bases;
-    const uint32_t paired = (BITS == 2 && h->paired) ? 1u : 0u;
-    S.paired = paired;
+    // strand-mirror mode + the read order that picks the canonical member of a mirror pair (keep_bits):
+    // 1 = index order (whole-set calls), 2 = scrambled block order (sharded calls, balances verify work)
+    const uint32_t paired = (BITS == 2 && h->paired) ? (nshards > 1 ? 2u : 1u) : 0u;
+    S.paired = paired ? 1u : 0u;
 
     uint32_t r_begin = 0, r_end = n;
     S.shard_bases = h->total_bases;
@@ -537,13 +539,19 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         hipLaunchKernelGGL(po::k_wide_finalize<BITS>, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt,
                            slot_start, chain64, len);
     }
-    if (nshards > 1 || wide) {
-        // selfrep of the reads the narrow scan of this call does not visit (sharded call), or of all
-        // reads (wide index: its scan does not look for prefix recurrences)
+    if (wide) {
+        // the wide scan does not look for prefix recurrences: one pass over all reads finds selfrep
         const uint32_t blocks = std::min<uint32_t>(cdiv((uint64_t)h->n_tiles * 64, 256), (uint32_t)h->n_cu * 8);
         hipLaunchKernelGGL(po::k_selfrep<BITS>, dim3(blocks), dim3(256), 0, st, words, h->d_tiles.as<po::TileRec>(),
-                           h->n_tiles, wide ? 0u : tile_begin, wide ? 0u : tile_end, m, kmask, selfrep,
-                           reinterpret_cast<uint32_t*>(scalars + 2));
+                           h->n_tiles, 0u, 0u, m, kmask, selfrep, reinterpret_cast<uint32_t*>(scalars + 2));
+    } else if (nshards > 1) {
+        // sharded call: the scan finds selfrep only for the shard's own reads.  Scanning all the others just
+        // for that costs more than the shard's own scan at 8 shards; instead every read outside the shard
+        // counts as "may repeat its prefix" (0), which sends all verified A candidates with such a b through
+        // the hashed longest-only selection below -- a few hundred thousand table inserts.
+        if (r_begin) hipLaunchKernelGGL(po::k_fill_u32, dim3(cdiv(r_begin, 256)), dim3(256), 0, st, selfrep, (uint64_t)r_begin, 0u);
+        if (r_end < n)
+            hipLaunchKernelGGL(po::k_fill_u32, dim3(cdiv(n - r_end, 256)), dim3(256), 0, st, selfrep + r_end, (uint64_t)(n - r_end), 0u);
     }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev[EV_INDEX], st));
@@ -634,7 +642,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     HIP_TRY(h, hipEventRecord(h->ev[EV_COUNT], st));
     HIP_TRY(h, hipStreamSynchronize(st));
     const uint64_t n_cand64 = h->pinned[1];
-    const uint32_t n_selfrep_reads = (uint32_t)h->pinned[8];
+    uint32_t n_selfrep_reads = (uint32_t)h->pinned[8];
+    if (nshards > 1 && !wide) n_selfrep_reads |= 1u;  // reads outside the shard are all suspects (see above)
     S.n_candidates = n_cand64;
     if (n_cand64 >= 0xFFFFFF00ull)
         return fail(h, PO_ERR_CAPACITY, "candidate count " + std::to_string(n_cand64) + " exceeds one call's capacity (2^32)");
@@ -667,7 +676,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             // a's words live in LDS (read length + 3 guard words); reads too long for 64 KB use the global path
             const uint64_t need_words = ((uint64_t)h->max_len + W - 1) / W + 3;
             const uint32_t lds_words = (uint32_t)std::min<uint64_t>(need_words, 8192);
-            hipLaunchKernelGGL(po::k_verify_a<BITS>, dim3(r_end - r_begin), dim3(po::VER_BLOCK), (size_t)lds_words * 8, st,
+            auto verify = paired == 2u ? po::k_verify_a<BITS, true> : po::k_verify_a<BITS, false>;
+            hipLaunchKernelGGL(verify, dim3(r_end - r_begin), dim3(po::VER_BLOCK), (size_t)lds_words * 8, st,
                                words, woff, len, h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_p,
                                A.cand_b, r_begin, lds_words, paired,
                                h->n_exc_uploaded ? h->d_exc_off.as<uint32_t>() : nullptr, h->d_exc_pos.as<uint32_t>(),
@@ -681,12 +691,17 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         uint32_t pbits = 0;
         if (n_selfrep_reads) {
             // some read's prefix recurs inside it: A candidates of such b may be non-longest duplicates
-            uint32_t* n_suspect = reinterpret_cast<uint32_t*>(scalars + 2) + 1;
-            hipLaunchKernelGGL(po::k_count_suspects, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_b,
-                               h->d_type.as<uint8_t>(), n_cand, selfrep, n_suspect);
-            HIP_TRY(h, hipMemcpyAsync(h->pinned + 8, scalars + 2, 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(h, hipStreamSynchronize(st));
-            const uint32_t n_sus = (uint32_t)(h->pinned[8] >> 32);
+            uint32_t n_sus;
+            if (nshards > 1 && !wide) {
+                n_sus = n_cand;  // upper bound, no counting pass and no host round trip (see the index step)
+            } else {
+                uint32_t* n_suspect = reinterpret_cast<uint32_t*>(scalars + 2) + 1;
+                hipLaunchKernelGGL(po::k_count_suspects, dim3(std::min<uint32_t>(cdiv(n_cand, 256), (uint32_t)h->n_cu * 8)), dim3(256), 0,
+                                   st, A.cand_b, h->d_type.as<uint8_t>(), n_cand, selfrep, n_suspect);
+                HIP_TRY(h, hipMemcpyAsync(h->pinned + 8, scalars + 2, 8, hipMemcpyDeviceToHost, st));
+                HIP_TRY(h, hipStreamSynchronize(st));
+                n_sus = (uint32_t)(h->pinned[8] >> 32);
+            }
             if (n_sus) {
                 pbits = 4;
                 while ((1ull << pbits) < 2ull * n_sus) ++pbits;

@@ -117,13 +117,35 @@ __device__ inline uint64_t funnel(uint64_t lo, uint64_t hi, uint32_t sh) {
     return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
 }
 
+// Strand-mirror pairs: candidate (a, b) and its mirror (flip(b), flip(a)) describe the same overlap.  With
+// c = flip(b) the two are the ordered pairs (a, c) and (c, a); exactly one of them is "canonical" (a == c
+// is its own mirror): the one whose a-side read comes first in a fixed order of the reads.  `paired` names
+// the order (both are bijections of the index, so exactly one member of a pair wins):
+//   1  plain index order, a <= c.  Whole-set calls: workgroups run in index order and read only b's of
+//      higher index, so the set of reads still in use shrinks as the kernel proceeds (verify 1.32 ms at
+//      config 2 against 1.39 ms for any scrambled order).
+//   2  blocks of 256 reads in bit-reversed block order (index order inside a block).  Sharded calls: ranks are
+//      equidistributed over any contiguous index range, so a-side shards balanced by bases are also balanced
+//      in verify work (plain order: the first of 8 shards had 15x the candidates of the last).
+// Measured and rejected: a per-pair coin flip (every tile half full instead of full and empty tiles: fill
+// and consume lose lane occupancy, 3.03 -> 3.29 ms); a multiplicative hash (its multiplies pushed
+// k_scan_fill from 54 to 121 VGPRs and k_scan_probe into scratch); bit-reversing from bit 0 or bit 3 on
+// (rank decided by the low index bits = by the XCD / CU a verify workgroup lands on: verify 1.33 -> 2.2-2.4 ms).
+__device__ inline uint32_t mirror_rank(uint32_t x, uint32_t paired) {
+    const uint32_t scrambled = __brev(x >> 8) | (x & 0xFFu);
+    return paired == 2u ? scrambled : x;
+}
+__device__ inline bool canonical_pair(uint32_t a, uint32_t c, uint32_t paired) {
+    return mirror_rank(a, paired) <= mirror_rank(c, paired);
+}
+
 // Which rows can candidate (a, p, b) give, and is it the member of its strand-mirror pair that this
 // library computes?  bit0: A (suffix of a = prefix of b; needs la-p <= lb), bit1: B (b inside a;
-// needs la-p >= lb).  Paired mode keeps A only for a <= flip(b) and B only for a on the + strand;
+// needs la-p >= lb).  Paired mode keeps A only for the canonical member and B only for a on the + strand;
 // k_emit writes the mirrored rows.  A read never pairs with itself (overlapper.cpp:72,:103).
 __device__ inline uint32_t keep_bits(uint32_t a, uint32_t b, uint32_t rem, uint32_t lb, uint32_t paired) {
     if (a == b) return 0;
-    return ((rem <= lb && (!paired || a <= (b ^ 1u))) ? 1u : 0u) |
+    return ((rem <= lb && (!paired || canonical_pair(a, b ^ 1u, paired))) ? 1u : 0u) |
            ((rem >= lb && (!paired || (a & 1u) == 0u)) ? 2u : 0u);
 }
 
@@ -998,8 +1020,8 @@ __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
     }
 }
 
-// selfrep for reads OUTSIDE the a-side shard of this call (multi-GPU / sharded calls): the COUNT
-// pass only visits the shard's reads, but the select step needs selfrep[b] for every b.
+// selfrep for the wide index, whose scan does not look for prefix recurrences (the narrow COUNT pass finds
+// them as a side effect): one pass over every tile outside [skip_begin, skip_end).
 template <int BITS>
 __global__ __launch_bounds__(256) void k_selfrep(const uint64_t* __restrict__ words, const TileRec* __restrict__ tiles,
                                                  uint32_t n_tiles, uint32_t skip_begin, uint32_t skip_end, uint32_t m,
@@ -1075,7 +1097,9 @@ constexpr int VER_BLOCK = 256;
 #endif
 constexpr int VER_BLOCKS = PO_VER_BLOCKS;  // 256-byte blocks per group per step after the first step
 
-template <int BITS>
+// SCRAMBLED: the canonical-pair order of sharded calls (keep_bits); a compile-time choice here because the
+// extra rank arithmetic sits on the per-candidate setup path (index order: 1.32 ms, run-time select: 1.37 ms).
+template <int BITS, bool SCRAMBLED>
 __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
                                                          const uint32_t* __restrict__ len,
                                                          const uint32_t* __restrict__ read_tile0,
@@ -1143,7 +1167,7 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
         const uint32_t rem = la - p;
         cur_p = p;
         cur_b = b;
-        keep = keep_bits(a, b, rem, lb, paired);
+        keep = keep_bits(a, b, rem, lb, SCRAMBLED ? 2u : (paired ? 1u : 0u));
         const uint32_t n = rem < lb ? rem : lb;
         nbits = keep ? n * BITS : 0;
         const uint64_t bitpos = (uint64_t)p * BITS;
@@ -1234,12 +1258,21 @@ __device__ inline uint32_t pair_slot(uint32_t a, uint32_t b, uint32_t tbits) {
     return (h1 ^ (h2 >> 3)) >> (32 - tbits);
 }
 
-__global__ void k_count_suspects(const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type, uint32_t n_cand,
-                                 const uint32_t* __restrict__ selfrep, uint32_t* __restrict__ n_suspect) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool sus = i < n_cand && (type[i] & 1u) && selfrep[cand_b[i]] != NO_SELFREP;
-    const uint64_t bal = __ballot(sus);
-    if (lane_id() == 0 && bal) atomicAdd(n_suspect, (uint32_t)__popcll(bal));
+__global__ __launch_bounds__(256) void k_count_suspects(const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,
+                                                        uint32_t n_cand, const uint32_t* __restrict__ selfrep,
+                                                        uint32_t* __restrict__ n_suspect) {
+    __shared__ uint32_t s_part[256 / WAVE];
+    uint32_t n = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cand; i += gridDim.x * blockDim.x)
+        n += ((type[i] & 1u) && selfrep[cand_b[i]] != NO_SELFREP) ? 1u : 0u;
+    n = (uint32_t)wave_sum64(n);
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 256 / WAVE; ++w) t += s_part[w];
+        if (t) atomicAdd(n_suspect, t);  // one atomic per workgroup
+    }
 }
 
 __global__ void k_select_mark(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_b,

@@ -6,7 +6,9 @@ naturally on the *a-side*: every rank holds the whole packed read set and anchor
 and scans a contiguous range of reads balanced by base count.  All row rules are local to ``a``
 (longest-only per (a,b), every containment occurrence), so the only exchange is merging the
 per-rank results: one RCCL all-gather over xGMI (``torch.distributed`` backend "nccl" is RCCL on
-ROCm).  Rank order = read order, so the merged result is row-for-row the single-GPU result.
+ROCm).  Rank order = read order: the merged result is the same array for every rank count and the same
+multiset of rows as the single-GPU result (sharded calls pick the canonical member of a strand-mirror pair
+by a scrambled read order, which balances the shards' verify work).
 
 What travels is the compact form, not the rows: each rank's *verified candidates*
 (``po_candidates_shard``: 16 bytes each and, in paired-strand mode, one per strand-mirror pair --

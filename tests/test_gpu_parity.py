@@ -162,7 +162,9 @@ def test_long_chain_many_identical_reads():
 @pytest.mark.parametrize("nshards", [1, 2, 5])
 def test_compact_candidates_then_expand_equals_rows(nshards):
     """The multi-GPU exchange form: per-shard verified candidates (16 B), concatenated in shard
-    order, expanded by po_expand -> exactly the po_overlaps rows, in the same order."""
+    order, expanded by po_expand -> exactly the po_overlaps rows as a multiset, and the very same row array
+    for every shard count (sharded calls pick the canonical member of a strand-mirror pair by a scrambled
+    read order, whole-set calls by index order: same rows, different emission order)."""
     import torch
     from phasm_amd.dist import _result_to_tensor
     for case in ("ladder_varlen", "ladder_cfg2_mini"):
@@ -172,18 +174,26 @@ def test_compact_candidates_then_expand_equals_rows(nshards):
             ov.add_sequence("r%d" % i, s)
         whole = ov.overlaps_array(m)
         dev = torch.device("cuda", 0)
-        parts = []
-        for k in range(nshards):
-            res = ov.candidates_result(m, k, nshards)
-            parts.append(_result_to_tensor(res, 4, dev))
+
+        def expanded(ns):
+            parts = []
+            for k in range(ns):
+                res = ov.candidates_result(m, k, ns)
+                parts.append(_result_to_tensor(res, 4, dev))
+                res.free()
+            merged = torch.cat(parts, dim=0).contiguous()
+            res = ov.expand_result(merged.data_ptr(), merged.shape[0])
+            rows = res.rows()
             res.free()
-        merged = torch.cat(parts, dim=0).contiguous()
+            return merged, rows
+
+        merged, got = expanded(nshards)
         assert merged.shape[0] < len(whole)          # paired mode: one candidate per mirror pair
-        res = ov.expand_result(merged.data_ptr(), merged.shape[0])
-        got = res.rows()
-        res.free()
-        assert np.array_equal(got, whole)
+        assert np.array_equal(oo.sort_rows(oo.struct_to_rows(got)), oo.sort_rows(oo.struct_to_rows(whole)))
         assert np.array_equal(oo.sort_rows(oo.struct_to_rows(got)), want)
+        if nshards > 1:
+            _, other = expanded(5)
+            assert np.array_equal(got, other)        # row for row, whatever the shard count
         # garbage in -> loud failure, not garbage rows
         bad = merged.clone()
         bad[0, 0] = 10 ** 9
