@@ -715,20 +715,22 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                                    h->d_type.as<uint8_t>(), n_cand, selfrep, pkey, pmin, pbits);
             }
         }
+        if (want_cands) PO_TRY(ensure(h, h->d_flag, (size_t)n_cand));
         hipLaunchKernelGGL(po::k_select, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_b,
-                           h->d_type.as<uint8_t>(), n_cand, selfrep, pkey, pmin, pbits, paired, h->d_rowcnt.as<uint8_t>());
+                           h->d_type.as<uint8_t>(), n_cand, selfrep, pkey, pmin, pbits, paired, h->d_rowcnt.as<uint8_t>(),
+                           want_cands ? h->d_flag.as<uint8_t>() : nullptr);
         HIP_TRY(h, hipGetLastError());
-        PO_TRY(prefix_sum<uint8_t>(h, h->d_rowcnt.as<uint8_t>(), n_cand, h->d_row_off.as<uint32_t>(), &h->pinned[2]));
-        HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
-        HIP_TRY(h, hipStreamSynchronize(st));
-        n_rows64 = h->pinned[2];
-        if (n_rows64 >= 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "row count exceeds one call's capacity (2^32)");
+        if (!want_cands) {
+            PO_TRY(prefix_sum<uint8_t>(h, h->d_rowcnt.as<uint8_t>(), n_cand, h->d_row_off.as<uint32_t>(), &h->pinned[2]));
+            HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
+            HIP_TRY(h, hipStreamSynchronize(st));
+            n_rows64 = h->pinned[2];
+            if (n_rows64 >= 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "row count exceeds one call's capacity (2^32)");
+        }
         if (want_cands) {
             // ---- multi-GPU form: hand out the verified candidates (one per strand-mirror pair), compacted
-            PO_TRY(ensure(h, h->d_flag, (size_t)n_cand));
-            hipLaunchKernelGGL(po::k_flag, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, h->d_rowcnt.as<uint8_t>(), n_cand,
-                               h->d_flag.as<uint8_t>());
             PO_TRY(prefix_sum<uint8_t>(h, h->d_flag.as<uint8_t>(), n_cand, h->d_row_off.as<uint32_t>(), &h->pinned[3]));
+            HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
             HIP_TRY(h, hipStreamSynchronize(st));
             const uint64_t n_ver = h->pinned[3];
             PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_ver * sizeof(po::Cand), 256)));

@@ -1303,12 +1303,13 @@ __device__ inline uint32_t rows_of(uint32_t t, uint32_t a, uint32_t b, uint32_t 
 __global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_b,
                          uint8_t* __restrict__ type, uint32_t n_cand, const uint32_t* __restrict__ selfrep,
                          const unsigned long long* __restrict__ pkey, const uint32_t* __restrict__ pmin, uint32_t tbits,
-                         uint32_t paired, uint8_t* __restrict__ rowcnt) {
+                         uint32_t paired, uint8_t* __restrict__ rowcnt, uint8_t* __restrict__ flag) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_cand) return;
     uint32_t t = type[i];
     if (t == 0) {
-        rowcnt[i] = 0;  // (candidates-only callers read this as "verified" flag: rows > 0 <=> type != 0)
+        rowcnt[i] = 0;
+        if (flag) flag[i] = 0;  // candidates-only callers: flag = "survives" (rows > 0 <=> type != 0)
         return;
     }
     const uint32_t a = cand_a[i], b = cand_b[i];
@@ -1323,6 +1324,7 @@ __global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __
         }
     }
     rowcnt[i] = (uint8_t)rows_of(t, a, b, paired);
+    if (flag) flag[i] = t != 0;
 }
 
 // Write the rows of one verified candidate at rows[off...].  Mirrors (exact

@@ -315,6 +315,9 @@ def test_seeded_fuzz_against_oracle(index, monkeypatch):
         got, st = hip_rows(seqs, m)
         want = oo.oracle_overlaps(seqs, m)
         assert np.array_equal(got, want), (trial, m, len(seqs), st["wide_index"], st["paired"])
+        # the sharded form of the same call (scrambled canonical order, every foreign read a repeat suspect)
+        got3, _ = hip_rows(seqs, m, shard=3)
+        assert np.array_equal(got3, want), (trial, m, len(seqs), "3 shards")
 
 
 def test_sparse_non_acgt_bytes_stay_on_the_2bit_path():
