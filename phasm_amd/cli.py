@@ -64,17 +64,24 @@ def overlap(args) -> int:
     return n
 
 
-def write_stage1_graph(out, g: "layout_mod.AssemblyEdges", lengths) -> int:
-    """The graph after stage 1 in the format of gfa2_write_graph (phasm/io/gfa.py:283-327)."""
-    out.write(gfa.gfa_header())
-    e = g.edges
-    ids = g.ids
+def write_stage1_graph(out, ids, lengths, edges_arr, edges_res=None) -> int:
+    """The graph after stage 1 in the format of gfa2_write_graph (phasm/io/gfa.py:283-327): S lines of the reads
+    that still have an edge, then one ``E * u v weight len(u) 0 overlap_len *`` line per edge (written natively
+    from the device result when ``out`` is a real file)."""
     import numpy as np
+    out.write(gfa.gfa_header())
+    e = edges_arr
     used = np.zeros(len(ids) // 2, dtype=bool)
     used[e["u"] >> 1] = True
     used[e["v"] >> 1] = True
     for i in np.flatnonzero(used).tolist():
         out.write(gfa.gfa_line("S", ids[2 * i][:-1], int(lengths[2 * i]), "*"))
+    if edges_res is not None:
+        try:
+            out.fileno()
+            return edges_res.write_gfa_edges(out)
+        except (AttributeError, OSError, ValueError):
+            pass
     lu = np.asarray(lengths)[e["u"]]
     chunk = 1 << 18
     for lo in range(0, len(e), chunk):
@@ -91,14 +98,17 @@ def layout_edges(args) -> int:
         nseg, rows = ov.add_gfa(args.gfa_file)
         logger.info("Read %d reads and %d local alignments from the GFA2 file.", nseg, len(rows))
         try:
-            g = layout_mod.build_assembly_graph(ov, rows, args.min_read_length, args.min_overlap_length,
-                                                args.max_overhang_abs, args.max_overhang_rel)
+            edges, _removed = ov.layout_edges(rows, args.min_read_length, args.min_overlap_length,
+                                              args.max_overhang_abs, args.max_overhang_rel)
         finally:
             rows.free()
-        st = g.stats
+        st = ov.layout_stats()
         logger.info("%d contained reads removed; %d alignments pass the filters; graph has %d edges.",
                     st["n_contained_reads"], st["n_pass"], st["n_edges"])
-        return write_stage1_graph(args.output, g, ov.lengths())
+        try:
+            return write_stage1_graph(args.output, ov.ids(), ov.lengths(), edges.rows(), edges)
+        finally:
+            edges.free()
     finally:
         ov.close()
 

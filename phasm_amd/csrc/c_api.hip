@@ -1342,7 +1342,8 @@ void po_result_free(po_result* r) {
 po_status po_write_gfa_edges(po_result* r, int fd, uint64_t* lines_out) {
     if (!r || fd < 0) return PO_ERR_INVALID;
     po_handle* h = r->h;
-    if (r->elem != sizeof(po_row)) return fail(h, PO_ERR_INVALID, "po_write_gfa_edges needs a row result");
+    const bool graph_edges = r->elem == sizeof(po_edge);  // a po_layout_edges result: gfa2_write_graph's E lines
+    if (r->elem != sizeof(po_row) && !graph_edges) return fail(h, PO_ERR_INVALID, "po_write_gfa_edges needs a row or edge result");
     if (lines_out) *lines_out = 0;
     if (r->count == 0) return PO_OK;
     const po_row* rows = po_result_rows(r);
@@ -1375,7 +1376,15 @@ po_status po_write_gfa_edges(po_result* r, int fd, uint64_t* lines_out) {
             return true;
         };
         for (uint64_t i = 0; i < r->count; ++i) {
-            const po_row& x = rows[i];
+            po_row x;
+            if (graph_edges) {
+                // E * u v weight len(u) 0 overlap_len *   (gfa2_write_graph, phasm/io/gfa.py:315-327)
+                const po_edge& e = reinterpret_cast<const po_edge*>(rows)[i];
+                if (e.u >= h->ids.size() || e.v >= h->ids.size()) return fail(h, PO_ERR_INVALID, "edge names an unknown read");
+                x = po_row{e.u, e.v, e.weight, (int32_t)h->len[e.u], 0, e.overlap_len};
+            } else {
+                x = rows[i];
+            }
             if (x.a_idx >= h->ids.size() || x.b_idx >= h->ids.size()) return fail(h, PO_ERR_INVALID, "row names an unknown read");
             buf.append("E\t*\t");
             buf.append(h->ids[x.a_idx]);
