@@ -161,7 +161,7 @@ def main() -> int:
             res.free()
         else:
             # exchange the compact form (verified candidates, 16 B), expand to rows on every rank
-            merged = merge_row_shards(local_shard_candidates(ov, m, rank, world, merge_device))
+            merged = merge_row_shards(local_shard_candidates(ov, m, rank, world, merge_device), keep_padding=True)
             shard_st = ov.stats()          # stage timings of this rank's shard (before the expansion)
             res = expand_candidates(ov, merged)
             n = len(res)

@@ -127,7 +127,8 @@ po_status po_overlaps_shard(po_handle* h, uint32_t min_length, uint32_t shard, u
  * Read it with po_result_device_rows / po_result_copy_to_device (or po_result_rows cast to po_cand*).
  * po_expand: turn a candidate array on this handle's device -- normally the rank-order concatenation
  * of every shard's candidates -- into rows: exactly the po_overlaps() rows (as a multiset; the emission order
- * follows the candidate array). */
+ * follows the candidate array).  All-zero entries are padding and skipped (RCCL has no all-gatherv: the
+ * shards travel in equal-sized slots); any other entry this library could not have produced is an error. */
 typedef struct {
     uint32_t a_idx, p, b_idx, type; /* type bit0: A row (suffix of a = prefix of b), bit1: B row (b inside a) */
 } po_cand;

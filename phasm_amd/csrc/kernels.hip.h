@@ -1418,7 +1418,11 @@ __global__ void k_cand_rowcnt(const Cand* __restrict__ cands, uint32_t n, uint32
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Cand c = cands[i];
-    if (c.a >= n_reads || c.b >= n_reads || c.type == 0 || c.type > 3) {  // not produced by this library
+    if ((c.a | c.p | c.b | c.type) == 0) {  // all-zero entry: padding of a fixed-size exchange buffer
+        rowcnt[i] = 0;
+        return;
+    }
+    if (c.a >= n_reads || c.b >= n_reads || c.a == c.b || c.type == 0 || c.type > 3) {  // not produced by this library
         rowcnt[i] = 0;
         atomicAdd(n_bad, 1u);
         return;

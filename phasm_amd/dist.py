@@ -29,9 +29,13 @@ import torch.distributed as dist
 from ._lib import CAND_DTYPE, ROW_DTYPE
 
 
-def merge_row_shards(local: torch.Tensor, group=None) -> torch.Tensor:
+def merge_row_shards(local: torch.Tensor, group=None, keep_padding: bool = False) -> torch.Tensor:
     """All-gather variable-length ``int32[n_local, k]`` tensors (k = 6 rows / 4 candidates); every
-    rank gets the concatenation in rank order.  Any backend (RCCL on GPU, gloo on CPU)."""
+    rank gets the concatenation in rank order.  Any backend (RCCL on GPU, gloo on CPU).
+
+    ``keep_padding``: return the gathered buffer as it is -- ``world_size`` equal slots of ``max_n`` entries, each
+    shard followed by all-zero entries -- instead of squeezing the padding out (one copy kernel per rank).
+    ``po_expand`` skips all-zero candidates, so the candidate exchange uses this form."""
     if not (dist.is_available() and dist.is_initialized()):
         return local
     ws = dist.get_world_size(group)
@@ -50,7 +54,7 @@ def merge_row_shards(local: torch.Tensor, group=None) -> torch.Tensor:
         padded[: local.shape[0]] = local
     gathered = torch.empty((ws * max_n, k), dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(gathered, padded.contiguous(), group=group)
-    if all(c == max_n for c in counts_h):
+    if keep_padding or all(c == max_n for c in counts_h):
         return gathered
     return torch.cat([gathered[r * max_n: r * max_n + c] for r, c in enumerate(counts_h)], dim=0)
 
@@ -104,7 +108,7 @@ def sharded_overlaps(ov, min_length: int, group=None, device: Optional[torch.dev
         rank, ws = 0, 1
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    merged = merge_row_shards(local_shard_candidates(ov, min_length, rank, ws, device), group)
+    merged = merge_row_shards(local_shard_candidates(ov, min_length, rank, ws, device), group, keep_padding=True)
     res = expand_candidates(ov, merged)
     try:
         return _result_to_tensor(res, 6, device)

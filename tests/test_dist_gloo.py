@@ -41,6 +41,11 @@ def _worker(rank, world, port, case, q):
         merged = merge_row_shards(local)
         got = rows_tensor_to_struct(merged)
         ok = np.array_equal(got, whole) and np.array_equal(oo.sort_rows(oo.struct_to_rows(got)), want_sorted)
+        # the fixed-slot form the candidate exchange uses: every shard followed by all-zero padding
+        padded = merge_row_shards(local, keep_padding=True)
+        counts = [int(((whole["a_idx"] >= a) & (whole["a_idx"] < b)).sum()) for a, b in (ov.shard_range(r, world) for r in range(world))]
+        ok = ok and padded.shape[0] == world * max(counts)
+        ok = ok and torch.equal(padded[padded.abs().sum(dim=1) != 0], merged)
         q.put((rank, bool(ok), int(len(mine)), int(len(got))))
         ov.close()
     finally:

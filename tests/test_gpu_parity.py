@@ -392,3 +392,31 @@ def test_tandem_repeats_many_hits_per_pair():
         want = oo.oracle_overlaps(seqs, m)
         assert st["n_candidates"] > 20 * len(want) > 0      # far more hits than rows
         assert np.array_equal(got, want), m
+
+
+def test_expand_skips_all_zero_padding():
+    """The candidate exchange travels in equal-sized slots (no all-gatherv in RCCL): po_expand ignores
+    all-zero entries anywhere in the array and still rejects every other impossible entry."""
+    import torch
+    from phasm_amd.dist import _result_to_tensor
+    _, seqs, m, want = gu.ladder_case("ladder_varlen")
+    ov = ExactOverlapper()
+    for i, s in enumerate(seqs):
+        ov.add_sequence("r%d" % i, s)
+    dev = torch.device("cuda", 0)
+    parts = []
+    for k in range(3):
+        res = ov.candidates_result(m, k, 3)
+        t = _result_to_tensor(res, 4, dev)
+        res.free()
+        parts += [t, torch.zeros((17 * (k + 1), 4), dtype=torch.int32, device=dev)]
+    merged = torch.cat(parts).contiguous()
+    res = ov.expand_result(merged.data_ptr(), merged.shape[0])
+    got = oo.sort_rows(oo.struct_to_rows(res.rows()))
+    res.free()
+    assert np.array_equal(got, want)
+    bad = merged.clone()
+    bad[-1, 3] = 1                      # a = b = 0 with a type: not padding, not possible
+    with pytest.raises(ValueError):
+        ov.expand_result(bad.data_ptr(), bad.shape[0])
+    ov.close()
