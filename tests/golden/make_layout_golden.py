@@ -18,7 +18,8 @@ uses the 1.x ``add_edge(u, v, attr_dict)`` signature), so no edge attributes are
 Case sources: (1) the rows of the committed overlap goldens (outputs of the compiled reference
 overlapper), in stored and in shuffled order; (2) seeded random alignments that reach every branch
 (all four types, non-zero bstart, `$` positions, both strands, repeated read pairs, short reads,
-thresholds where ``ratio * overlap`` is not an integer).
+thresholds where ``ratio * overlap`` is not an integer); (3) GFA text in the form the reference's other producer
+of this wire format writes (daligner2gfa: TS header tag, `$` ends, trace-point lists, b on either strand).
 """
 import hashlib
 import io
@@ -135,6 +136,45 @@ def random_case(seed):
     return "random_%d" % seed, names, lengths, rows, params
 
 
+def daligner_form_case(seed):
+    """E lines the way the other producer of this wire format writes them (daligner2gfa,
+    /root/reference/phasm/cli/convert.py:104-131): a always on '+', b on either strand, a `$` after an end
+    position that equals the read length, a comma-separated trace-point list in the alignment field, and the
+    TS tag in the header (:78).  Returned as ready GFA text."""
+    rng = random.Random(seed)
+    n = rng.randint(4, 10)
+    names = ["m%d/%d/0_%d" % (seed, i, 100 + i) for i in range(n)]
+    lengths = [rng.randint(80, 600) for _ in range(n)]
+    out = ["H\tVN:z:2.0\tTS:i:100\n"]
+    for nm, l in zip(names, lengths):
+        out.append("S\t%s\t%d\t*\n" % (nm, l))
+    n_rows = 0
+    for _ in range(rng.randint(10, 50)):
+        a, b = rng.randrange(n), rng.randrange(n)
+        la, lb = lengths[a], lengths[b]
+        if rng.random() < 0.6:      # dovetail, a's end on b's start, a few bases of overhang
+            l = rng.randint(20, min(la, lb))
+            oh = rng.choice([0, 0, 1, 4, 15])
+            s, e, bs, be = max(la - l - oh, 0), la - oh if la - oh > 0 else la, min(oh, lb - 1), min(lb, oh + l)
+            if e <= s:
+                e = la
+            if be <= bs:
+                be = lb
+        else:
+            s = rng.randint(0, la - 1)
+            e = rng.randint(s + 1, la)
+            bs = rng.randint(0, lb - 1)
+            be = rng.randint(bs + 1, lb)
+        es = "%d$" % e if e == la else "%d" % e
+        bes = "%d$" % be if be == lb else "%d" % be
+        tp = ",".join(str(rng.randint(0, 9)) for _ in range(rng.randint(1, 6)))
+        out.append("E\t*\t%s+\t%s%s\t%d\t%s\t%d\t%s\t%s\n" % (names[a], names[b], rng.choice("+-"), s, es, bs, bes, tp))
+        n_rows += 1
+    params = {"min_read_length": rng.choice([0, 150]), "min_overlap_length": rng.choice([0, 40]),
+              "max_overhang_abs": rng.choice([1000, 10]), "max_overhang_rel": rng.choice([0.8, 0.2])}
+    return "daligner_form_%d" % seed, "".join(out), n_rows, params
+
+
 def main():
     default = {"min_read_length": 0, "min_overlap_length": 0, "max_overhang_abs": 1000, "max_overhang_rel": 0.8}
     cases = []
@@ -168,6 +208,9 @@ def main():
                                    "passed_sha256": digest(exp["passed"]), "filters": exp["filters"]}})
         else:
             out.append({"name": name, "gfa": text, "params": params, "n_rows": len(rows), "expect": exp})
+    for seed in range(8):
+        name, text, n_rows, params = daligner_form_case(2000 + seed)
+        out.append({"name": name, "gfa": text, "params": params, "n_rows": n_rows, "expect": run_reference(text, params)})
     path = os.path.join(HERE, "layout_cases.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=0)
