@@ -684,6 +684,19 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                                h->d_exc_byte.as<uint8_t>(), h->d_type.as<uint8_t>());
         }
         HIP_TRY(h, hipGetLastError());
+#ifdef PO_VSTAMPS
+        {
+            unsigned long long v[64 * 8], z[64 * 8] = {};
+            HIP_TRY(h, hipStreamSynchronize(st));
+            HIP_TRY(h, hipMemcpyFromSymbol(v, HIP_SYMBOL(po::g_vstamps), sizeof(v)));
+            HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(po::g_vstamps), z, sizeof(z)));
+            double sum[8] = {};
+            for (int i = 0; i < 64; ++i) for (int k = 0; k < 8; ++k) sum[k] += (double)v[i * 8 + k];
+            if (sum[6] > 0)
+                std::fprintf(stderr, "[vstamps] per wave (shader clocks): setup %.0f  wait_b %.0f  lds+cmp %.0f  book+init %.0f  life %.0f | iterations %.1f  group-steps/iteration %.2f  waves %.0f\n",
+                             sum[0] / sum[6], sum[1] / sum[6], sum[2] / sum[6], sum[3] / sum[6], sum[4] / sum[6], sum[5] / sum[6], sum[7] / sum[5], sum[6]);
+        }
+#endif
         HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
         // ---- select + row offsets
         unsigned long long* pkey = nullptr;

@@ -1091,7 +1091,10 @@ __device__ inline bool exceptions_equal(const uint32_t* __restrict__ exc_off, co
 }
 
 constexpr int VER_GROUP = 16;
-constexpr int VER_BLOCK = 256;
+#ifndef PO_VER_BLOCK
+#define PO_VER_BLOCK 256
+#endif
+constexpr int VER_BLOCK = PO_VER_BLOCK;  // threads per verify workgroup (one a-side read); 128 and 256 measure the same, 64 and 512 worse
 #ifndef PO_VER_BLOCKS
 #define PO_VER_BLOCKS 3
 #endif
@@ -1099,6 +1102,17 @@ constexpr int VER_BLOCKS = PO_VER_BLOCKS;  // 256-byte blocks per group per step
 
 // SCRAMBLED: the canonical-pair order of sharded calls (keep_bits); a compile-time choice here because the
 // extra rank arithmetic sits on the per-candidate setup path (index order: 1.32 ms, run-time select: 1.37 ms).
+#ifdef PO_VSTAMPS
+// diagnostic build (-DPO_VSTAMPS): where a verify wave spends its cycles (s_memtime = shader clock).
+// [0] workgroup start -> first compare iteration (read geometry, staging of a, first metadata), [1] waiting
+// for the b loads of an iteration, [2] LDS reads + compare, [3] ballot + bookkeeping + start of the next
+// candidate, [4] wave lifetime, [5] iterations, [6] waves, [7] group-steps with work
+__device__ unsigned long long g_vstamps[64 * 8];
+#define VST(...) __VA_ARGS__
+#else
+#define VST(...)
+#endif
+
 template <int BITS, bool SCRAMBLED>
 __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
                                                          const uint32_t* __restrict__ len,
@@ -1113,6 +1127,7 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
                                                          uint8_t* __restrict__ type) {
     constexpr int W = 64 / BITS;
     extern __shared__ uint64_t s_a64[];
+    VST(const unsigned long long vt_start = __builtin_amdgcn_s_memtime(); unsigned long long vt[8] = {};)
     const uint32_t a = r_begin + blockIdx.x;
     const uint32_t seg0 = tile_off[read_tile0[a]], seg1 = tile_off[read_tile0[a + 1]];
     if (seg0 == seg1) return;
@@ -1209,18 +1224,22 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
     };
     constexpr uint32_t BLK = 4 * VER_GROUP;  // dwords per 256-byte block
     if (have) init();
+    VST(unsigned long long vt_prev = __builtin_amdgcn_s_memtime(); vt[0] = vt_prev - vt_start;)
     while (__any(have)) {
         uint32_t diff = 0;
+        VST(vt[5] += 1; vt[7] += __popcll(__ballot(have && sub == 0));)
         if (have) {
             u32x4 bv[VER_BLOCKS];
 #pragma unroll
             for (int j = 0; j < VER_BLOCKS; ++j)  // b starts 16-byte aligned
                 if ((uint32_t)j < nblk && (d + j * BLK) * 32 < nbits) bv[j] = *reinterpret_cast<const u32x4*>(B + d + j * BLK);
+            VST(__builtin_amdgcn_s_waitcnt(0); { const unsigned long long t = __builtin_amdgcn_s_memtime(); vt[1] += t - vt_prev; vt_prev = t; })
 #pragma unroll
             for (int j = 0; j < VER_BLOCKS; ++j)
                 if ((uint32_t)j < nblk && (d + j * BLK) * 32 < nbits) diff |= cmp16(d + j * BLK, bv[j]);
         }
         const uint64_t bal = __ballot(diff != 0);
+        VST({ const unsigned long long t = __builtin_amdgcn_s_memtime(); vt[2] += t - vt_prev; vt_prev = t; })
         if (have) {
             const bool mismatch = ((bal >> gshift) & ((1ull << VER_GROUP) - 1ull)) != 0;
             d += nblk * BLK;
@@ -1239,7 +1258,13 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
                 if (have) init();
             }
         }
+        VST({ const unsigned long long t = __builtin_amdgcn_s_memtime(); vt[3] += t - vt_prev; vt_prev = t; })
     }
+    VST(if (lane_id() == 0) {
+        vt[4] = __builtin_amdgcn_s_memtime() - vt_start;
+        vt[6] = 1;
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_vstamps[(blockIdx.x & 63) * 8 + k], vt[k]);
+    })
 }
 
 // ----------------------------------------------------------------------------------------
