@@ -107,8 +107,24 @@ def test_full_size_cfg2_properties():
     ov = ExactOverlapper(device=0)
     for n, s in oriented:
         ov.add_sequence(n, s)
-    arr = ov.overlaps_array(1000)
+    res = ov.overlaps_result(1000)
+    arr = res.rows()
     st = ov.stats()
+    # the consumer on the same rows, still in HBM: layout stage 1 at full size against the numpy restatement
+    # (cheap enough at 7 M rows) -- every edge, bit for bit; plus the sharded form of the overlap call
+    from oracle import layout_oracle as lo
+    from phasm_amd import layout
+    g = layout.build_assembly_graph(ov, res, min_read_length=0, min_overlap_length=2000)
+    res.free()
+    want_g = lo.layout_vectorised(oo.struct_to_rows(arr), ov.lengths(), min_overlap_length=2000)
+    e = g.edges
+    got_e = np.stack([e["u"], e["v"], e["weight"], e["overlap_len"]], 1).astype(np.int64)
+    got_e = got_e[np.lexsort((got_e[:, 1], got_e[:, 0]))]
+    assert np.array_equal(got_e, want_g["edges"]) and len(got_e) > 5_000_000
+    assert g.contained.tolist() == want_g["contained"].tolist()
+    sharded = np.concatenate([ov.overlaps_shard_array(1000, k, 3) for k in range(3)])
+    assert np.array_equal(oo.sort_rows(oo.struct_to_rows(sharded)), oo.sort_rows(oo.struct_to_rows(arr)))
+    del sharded
     ov.close()
     lens = np.array([len(s) for _, s in oriented], dtype=np.int64)
     a, b = arr["a_idx"].astype(np.int64), arr["b_idx"].astype(np.int64)
