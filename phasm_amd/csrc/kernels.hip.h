@@ -1113,42 +1113,33 @@ __device__ unsigned long long g_vstamps[64 * 8];
 #define VST(...)
 #endif
 
-template <int BITS, bool SCRAMBLED>
-__global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
-                                                         const uint32_t* __restrict__ len,
-                                                         const uint32_t* __restrict__ read_tile0,
-                                                         const uint32_t* __restrict__ tile_off,
-                                                         const uint32_t* __restrict__ cand_p,
-                                                         const uint32_t* __restrict__ cand_b, uint32_t r_begin,
-                                                         uint32_t lds_words, uint32_t paired,
-                                                         const uint32_t* __restrict__ exc_off,
-                                                         const uint32_t* __restrict__ exc_pos,
-                                                         const uint8_t* __restrict__ exc_byte,
-                                                         uint8_t* __restrict__ type) {
+// The compare loop of k_verify_a, compiled once for a in LDS and once for a in global memory (reads too long
+// for LDS).  With one body the compiler folds the two a-pointers into a generic pointer: five flat_load_dword
+// and ten 64-bit address instructions per 256-byte block instead of five ds_read_b32 off one 32-bit address.
+template <int BITS, bool SCRAMBLED, bool IN_LDS>
+__device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
+                                           const uint32_t* __restrict__ len, const uint32_t* __restrict__ cand_p,
+                                           const uint32_t* __restrict__ cand_b, uint32_t paired,
+                                           const uint32_t* __restrict__ exc_off, const uint32_t* __restrict__ exc_pos,
+                                           const uint8_t* __restrict__ exc_byte, uint8_t* __restrict__ type,
+                                           const uint32_t* __restrict__ s_a, const uint32_t* __restrict__ ga32,
+                                           uint32_t* s_next, uint32_t a, uint32_t la, uint32_t seg0, uint32_t seg1
+                                           VST(, unsigned long long vt_start, unsigned long long (&vt)[8])) {
     constexpr int W = 64 / BITS;
-    extern __shared__ uint64_t s_a64[];
-    VST(const unsigned long long vt_start = __builtin_amdgcn_s_memtime(); unsigned long long vt[8] = {};)
-    const uint32_t a = r_begin + blockIdx.x;
-    const uint32_t seg0 = tile_off[read_tile0[a]], seg1 = tile_off[read_tile0[a + 1]];
-    if (seg0 == seg1) return;
-    const uint32_t la = len[a];
-    const uint32_t nwa = (la + W - 1) / W;
-    const uint64_t* __restrict__ ga = words + woff[a];
-    const bool in_lds = nwa + 3 <= lds_words;  // workgroup-uniform
-    if (in_lds) {
-        for (uint32_t i = threadIdx.x; i < nwa + 3; i += VER_BLOCK) s_a64[i] = ga[i];
-        __syncthreads();
-    }
+    (void)W;
     // a is addressed as 32-bit words from here on: the window of a that faces b starts at an
     // arbitrary bit, and v_alignbit_b32 extracts 32 bits at any offset from two adjacent dwords
-    const uint32_t* __restrict__ s_a = reinterpret_cast<const uint32_t*>(s_a64);
-    const uint32_t* __restrict__ ga32 = reinterpret_cast<const uint32_t*>(ga);
     const uint32_t sub = threadIdx.x & (VER_GROUP - 1);
     const uint32_t gshift = (lane_id() / VER_GROUP) * VER_GROUP;
     constexpr uint32_t NGROUPS = VER_BLOCK / VER_GROUP;
 
-    uint32_t c = seg0 + threadIdx.x / VER_GROUP;
-    bool have = c < seg1;
+    // A group works on candidate c while the metadata of its next two (cA, then cB) is on the way.  Which
+    // candidates those are is decided when they are requested -- cB comes from a workgroup-wide counter -- so a
+    // group that drew short candidates (46 % die in their first block) simply draws more often: with a fixed
+    // round-robin share the workgroup waited for the group that happened to get the long ones.
+    uint32_t c = seg0;
+    uint32_t cA = seg0 + threadIdx.x / VER_GROUP, cB = cA + NGROUPS;
+    bool have = cA < seg1;
     // per candidate: nbits = compared bits, q = first dword of a's window, sh = its bit offset,
     // d = this lane's first dword of b in the current step, keep = rows it can give
     uint32_t nbits = 0, sh = 0, q = 0, d = 0, keep = 0, nblk = 1, cur_p = 0, cur_b = 0;
@@ -1160,7 +1151,7 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
     uint32_t m0p, m0b, m0l, m1p, m1b;
     uint64_t m0w;
     {
-        const uint32_t c0 = min(c, c_last), c1 = min(c + NGROUPS, c_last);
+        const uint32_t c0 = min(cA, c_last), c1 = min(cB, c_last);
         m0p = cand_p[c0];
         m0b = cand_b[c0];
         m1p = cand_p[c1];
@@ -1172,11 +1163,16 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
         const uint32_t p = m0p, b = m0b, lb = m0l;
         const uint64_t wo = m0w;
         // advance the look-ahead: requests only, nothing here is needed before the next candidate
+        c = cA;
+        cA = cB;
         m0p = m1p;
         m0b = m1b;
         m0l = len[m1b];
         m0w = woff[m1b];
-        const uint32_t c2 = min(c + 2 * NGROUPS, c_last);
+        uint32_t drawn = 0;
+        if (sub == 0) drawn = atomicAdd(s_next, 1u);
+        cB = __shfl(drawn, (int)gshift);  // lane 0 of the group drew for all 16
+        const uint32_t c2 = min(cB, c_last);
         m1p = cand_p[c2];
         m1b = cand_b[c2];
         const uint32_t rem = la - p;
@@ -1196,7 +1192,7 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
     // compare this lane's 16 bytes of b at dword dd with the facing window of a
     auto cmp16 = [&](uint32_t dd, u32x4 bv) __attribute__((always_inline)) -> uint32_t {
         uint32_t a0, a1, a2, a3, a4;
-        if (in_lds) {
+        if constexpr (IN_LDS) {
             a0 = s_a[q + dd];
             a1 = s_a[q + dd + 1];
             a2 = s_a[q + dd + 2];
@@ -1253,8 +1249,7 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
                     if (t && exc_off && !exceptions_equal(exc_off, exc_pos, exc_byte, a, cur_p, cur_b, nbits / BITS)) t = 0;
                     type[c] = (uint8_t)t;
                 }
-                c += NGROUPS;
-                have = c < seg1;
+                have = cA < seg1;
                 if (have) init();
             }
         }
@@ -1265,6 +1260,44 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
         vt[6] = 1;
         for (int k = 0; k < 8; ++k) atomicAdd(&g_vstamps[(blockIdx.x & 63) * 8 + k], vt[k]);
     })
+}
+
+template <int BITS, bool SCRAMBLED>
+__global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
+                                                         const uint32_t* __restrict__ len,
+                                                         const uint32_t* __restrict__ read_tile0,
+                                                         const uint32_t* __restrict__ tile_off,
+                                                         const uint32_t* __restrict__ cand_p,
+                                                         const uint32_t* __restrict__ cand_b, uint32_t r_begin,
+                                                         uint32_t lds_words, uint32_t paired,
+                                                         const uint32_t* __restrict__ exc_off,
+                                                         const uint32_t* __restrict__ exc_pos,
+                                                         const uint8_t* __restrict__ exc_byte,
+                                                         uint8_t* __restrict__ type) {
+    constexpr int W = 64 / BITS;
+    extern __shared__ uint64_t s_a64[];
+    VST(const unsigned long long vt_start = __builtin_amdgcn_s_memtime(); unsigned long long vt[8] = {};)
+    const uint32_t a = r_begin + blockIdx.x;
+    const uint32_t seg0 = tile_off[read_tile0[a]], seg1 = tile_off[read_tile0[a + 1]];
+    if (seg0 == seg1) return;
+    const uint32_t la = len[a];
+    const uint32_t nwa = (la + W - 1) / W;
+    const uint64_t* __restrict__ ga = words + woff[a];
+    const bool in_lds = nwa + 3 <= lds_words;  // workgroup-uniform
+    // candidates are handed out dynamically: the first two per group by position, the rest from this counter
+    __shared__ uint32_t s_next;
+    if (threadIdx.x == 0) s_next = seg0 + 2 * (VER_BLOCK / VER_GROUP);
+    if (in_lds)
+        for (uint32_t i = threadIdx.x; i < nwa + 3; i += VER_BLOCK) s_a64[i] = ga[i];
+    __syncthreads();
+    const uint32_t* __restrict__ s_a = reinterpret_cast<const uint32_t*>(s_a64);
+    const uint32_t* __restrict__ ga32 = reinterpret_cast<const uint32_t*>(ga);
+    if (in_lds)
+        verify_run<BITS, SCRAMBLED, true>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type, s_a, ga32,
+                                          &s_next, a, la, seg0, seg1 VST(, vt_start, vt));
+    else
+        verify_run<BITS, SCRAMBLED, false>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type, s_a, ga32,
+                                           &s_next, a, la, seg0, seg1 VST(, vt_start, vt));
 }
 
 // ----------------------------------------------------------------------------------------
