@@ -77,6 +77,7 @@ struct po_handle {
     DevBuf d_table, d_slot_cnt, d_slot_cur, d_slot_start, d_read_slot, d_chain, d_chain_tmp, d_long_list;
     DevBuf d_bloom, d_selfrep, d_tile_count, d_tile_off, d_truemask, d_ps_blocks, d_scalars, d_left, d_left_cnt, d_tile_extra;
     DevBuf d_cand_a, d_cand_p, d_cand_b, d_type, d_rowcnt, d_row_off, d_flag, d_pair_key, d_pair_min;
+    DevBuf d_vlabel, d_vrank, d_vperm;  // verify order (k_read_label, k_read_sort, k_read_invert)
     DevBuf spare_rows;
     int live_results = 0;
 
@@ -676,12 +677,40 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             // a's words live in LDS (read length + 3 guard words); reads too long for 64 KB use the global path
             const uint64_t need_words = ((uint64_t)h->max_len + W - 1) / W + 3;
             const uint32_t lds_words = (uint32_t)std::min<uint64_t>(need_words, 8192);
+            // locality order of the a-side reads (k_read_label): worth its ~50 us only when the verify is long
+            const uint32_t n_a = r_end - r_begin;
+            const uint32_t* perm = nullptr;
+            bool use_order = n_cand >= 400000 && n_a >= 4096;
+            if (const char* e = getenv("PHASM_VERIFY_ORDER")) use_order = atoi(e) != 0;
+            if (use_order) {
+                // bins of label >> shift, as many as fit into one workgroup's LDS
+                const uint32_t max_bins = (uint32_t)((std::min<size_t>(h->lds_max, 160 * 1024) - 1024) / 4);
+                uint32_t shift = 0;
+                while (((n / 2 + 1) >> shift) + 1 > max_bins) ++shift;
+                const uint32_t n_bins = ((n / 2 + 1) >> shift) + 1;
+                const size_t sort_lds = ((size_t)n_bins + po::SORT_BLOCK / 64) * 4;
+                PO_TRY(ensure(h, h->d_vlabel, (size_t)n_a * 4));
+                PO_TRY(ensure(h, h->d_vperm, (size_t)n_a * 4));
+                hipLaunchKernelGGL(po::k_read_label, dim3(cdiv((uint64_t)n_a * 16, 256)), dim3(256), 0, st,
+                                   h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_b, r_begin, n_a,
+                                   h->d_vlabel.as<uint32_t>());
+                if (sort_lds > 48 * 1024)
+                    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_read_sort),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+                PO_TRY(ensure(h, h->d_vrank, (size_t)n_a * 4));
+                hipLaunchKernelGGL(po::k_read_sort, dim3(1), dim3(po::SORT_BLOCK), sort_lds, st, h->d_vlabel.as<uint32_t>(), n_a,
+                                   shift, n_bins, h->d_vrank.as<uint32_t>());
+                hipLaunchKernelGGL(po::k_read_invert, dim3(cdiv(n_a, 256)), dim3(256), 0, st, h->d_vrank.as<uint32_t>(), n_a, r_begin,
+                                   h->d_vperm.as<uint32_t>());
+                perm = h->d_vperm.as<uint32_t>();
+            }
+            const uint32_t ver_grid = perm ? 8 * ((n_a + 7) / 8) : n_a;
             auto verify = paired == 2u ? po::k_verify_a<BITS, true> : po::k_verify_a<BITS, false>;
-            hipLaunchKernelGGL(verify, dim3(r_end - r_begin), dim3(po::VER_BLOCK), (size_t)lds_words * 8, st,
+            hipLaunchKernelGGL(verify, dim3(ver_grid), dim3(po::VER_BLOCK), (size_t)lds_words * 8, st,
                                words, woff, len, h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_p,
                                A.cand_b, r_begin, lds_words, paired,
                                h->n_exc_uploaded ? h->d_exc_off.as<uint32_t>() : nullptr, h->d_exc_pos.as<uint32_t>(),
-                               h->d_exc_byte.as<uint8_t>(), h->d_type.as<uint8_t>());
+                               h->d_exc_byte.as<uint8_t>(), h->d_type.as<uint8_t>(), perm, n_a);
         }
         HIP_TRY(h, hipGetLastError());
 #ifdef PO_VSTAMPS
@@ -1084,7 +1113,7 @@ void po_destroy(po_handle* h) {
                           &h->d_chain_tmp, &h->d_long_list, &h->d_bloom, &h->d_selfrep, &h->d_tile_count, &h->d_tile_off,
                           &h->d_ps_blocks, &h->d_scalars, &h->d_cand_a, &h->d_cand_p, &h->d_cand_b, &h->d_type,
                           &h->d_rowcnt, &h->d_row_off, &h->d_flag, &h->d_pair_key, &h->d_pair_min, &h->spare_rows,
-                          &h->d_lay_len, &h->d_lay_cnt, &h->d_rflag, &h->d_removed, &h->d_ekey, &h->d_ecnt,
+                          &h->d_vlabel, &h->d_vrank, &h->d_vperm, &h->d_lay_len, &h->d_lay_cnt, &h->d_rflag, &h->d_removed, &h->d_ekey, &h->d_ecnt,
                           &h->d_ewin, &h->d_eoff};
         for (DevBuf* b : bufs) b->release();
         for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(h->ev[i]);

@@ -1052,6 +1052,92 @@ __global__ __launch_bounds__(256) void k_selfrep(const uint64_t* __restrict__ wo
 }
 
 // ----------------------------------------------------------------------------------------
+// verify order.  Each b is read by ~35 different a's (the reads that overlap it from the left), in an order
+// unrelated to where the reads come from, so every XCD's L2 keeps missing (hit rate 25 %: 9.5 GB of fabric
+// traffic for 375 MB of reads).  Reads that cover the same stretch of the genome have nearly the same
+// candidate list, hence the same highest-numbered read in it: that number is a locality label for free.
+// Sorting the a's by label (counting sort) puts neighbours next to each other; k_verify_a hands XCD x the
+// x-th eighth of the sorted list, so neighbours meet in one L2.
+// ----------------------------------------------------------------------------------------
+// 16 lanes per read: label[i] = max read number (index >> 1) over the candidates of read r_begin + i and itself
+__global__ __launch_bounds__(256) void k_read_label(const uint32_t* __restrict__ read_tile0, const uint32_t* __restrict__ tile_off,
+                                                    const uint32_t* __restrict__ cand_b, uint32_t r_begin, uint32_t n_reads,
+                                                    uint32_t* __restrict__ label) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = t >> 4, sub = t & 15u;
+    if (i >= n_reads) return;  // (whole 16-lane groups leave together)
+    const uint32_t a = r_begin + i;
+    const uint32_t seg0 = tile_off[read_tile0[a]], seg1 = tile_off[read_tile0[a + 1]];
+    uint32_t best = a >> 1;
+    for (uint32_t c = seg0 + sub; c < seg1; c += 16) best = max(best, cand_b[c] >> 1);
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o, 16));
+    if (sub == 0) label[i] = best;
+}
+
+// Counting sort of the reads by label >> shift, in ONE workgroup with the bins in LDS: 100 k device-scope atomics
+// on a few thousand hot addresses cost 35-70 us (histogram and scatter each), the same on LDS a few.  The host
+// picks shift so that the bins fit (neighbouring labels then share a bin: their clusters end up side by side).
+// The workgroup only produces rank[i] = position of read i in bin order (coalesced stores; 100 k scattered
+// stores from a single CU took 48 us); k_read_invert turns that into perm[rank] = read on the whole chip.
+// Order inside a bin is whatever the atomics give: the verify result does not depend on workgroup order.
+constexpr int SORT_BLOCK = 1024;
+__global__ __launch_bounds__(SORT_BLOCK) void k_read_sort(const uint32_t* __restrict__ label, uint32_t n_reads, uint32_t shift,
+                                                          uint32_t n_bins, uint32_t* __restrict__ rank) {
+    extern __shared__ uint32_t s_bin[];          // n_bins counters, then SORT_BLOCK / 64 wave totals
+    uint32_t* s_wave = s_bin + n_bins;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t b = tid; b < n_bins; b += SORT_BLOCK) s_bin[b] = 0;
+    __syncthreads();
+    // (one workgroup has little memory-level parallelism: keep 16 label loads in flight per thread)
+    constexpr uint32_t UN = 16;
+    for (uint32_t base = tid; base < n_reads; base += UN * SORT_BLOCK) {
+        uint32_t v[UN];
+#pragma unroll
+        for (uint32_t k = 0; k < UN; ++k) {
+            const uint32_t i = base + k * SORT_BLOCK;
+            v[k] = i < n_reads ? label[i] : ~0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < UN; ++k)
+            if (v[k] != ~0u) atomicAdd(&s_bin[v[k] >> shift], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the bins: each thread owns a contiguous chunk
+    const uint32_t per = (n_bins + SORT_BLOCK - 1) / SORT_BLOCK;
+    const uint32_t lo = min(tid * per, n_bins), hi = min(lo + per, n_bins);
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; ++b) sum += s_bin[b];
+    const uint32_t incl = wave_incl_scan(sum);
+    if (lane_id() == WAVE - 1) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) run += s_wave[w];
+    for (uint32_t b = lo; b < hi; ++b) {
+        const uint32_t v = s_bin[b];
+        s_bin[b] = run;
+        run += v;
+    }
+    __syncthreads();
+    for (uint32_t base = tid; base < n_reads; base += UN * SORT_BLOCK) {
+        uint32_t v[UN];
+#pragma unroll
+        for (uint32_t k = 0; k < UN; ++k) {
+            const uint32_t i = base + k * SORT_BLOCK;
+            v[k] = i < n_reads ? label[i] : ~0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < UN; ++k)
+            if (v[k] != ~0u) rank[base + k * SORT_BLOCK] = atomicAdd(&s_bin[v[k] >> shift], 1u);
+    }
+}
+
+__global__ void k_read_invert(const uint32_t* __restrict__ rank, uint32_t n_reads, uint32_t r_begin, uint32_t* __restrict__ perm) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_reads) perm[rank[i]] = r_begin + i;
+}
+
+// ----------------------------------------------------------------------------------------
 // verify: packed exact compare of a[p : p+n) against b[0 : n), n = min(la-p, lb)
 // ----------------------------------------------------------------------------------------
 // One workgroup per a-side read: a's packed words are staged in LDS once and every candidate of a
@@ -1273,11 +1359,21 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
                                                          const uint32_t* __restrict__ exc_off,
                                                          const uint32_t* __restrict__ exc_pos,
                                                          const uint8_t* __restrict__ exc_byte,
-                                                         uint8_t* __restrict__ type) {
+                                                         uint8_t* __restrict__ type,
+                                                         const uint32_t* __restrict__ perm, uint32_t n_a) {
     constexpr int W = 64 / BITS;
     extern __shared__ uint64_t s_a64[];
     VST(const unsigned long long vt_start = __builtin_amdgcn_s_memtime(); unsigned long long vt[8] = {};)
-    const uint32_t a = r_begin + blockIdx.x;
+    uint32_t a = r_begin + blockIdx.x;
+    if (perm) {
+        // workgroup i runs on XCD i mod 8: give XCD x the x-th eighth of the locality-sorted read list
+        const uint32_t per = (n_a + 7u) >> 3;
+        const uint32_t k = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+        if (k >= n_a || (blockIdx.x >> 3) >= per) return;
+        a = perm[k];
+    } else if (blockIdx.x >= n_a) {
+        return;
+    }
     const uint32_t seg0 = tile_off[read_tile0[a]], seg1 = tile_off[read_tile0[a + 1]];
     if (seg0 == seg1) return;
     const uint32_t la = len[a];
