@@ -1055,21 +1055,24 @@ __global__ __launch_bounds__(256) void k_selfrep(const uint64_t* __restrict__ wo
 // verify order.  Each b is read by ~35 different a's (the reads that overlap it from the left), in an order
 // unrelated to where the reads come from, so every XCD's L2 keeps missing (hit rate 25 %: 9.5 GB of fabric
 // traffic for 375 MB of reads).  Reads that cover the same stretch of the genome have nearly the same
-// candidate list, hence the same highest-numbered read in it: that number is a locality label for free.
+// candidate list, hence the same top-ranked read in it: that rank is a locality label for free.
 // Sorting the a's by label (counting sort) puts neighbours next to each other; k_verify_a hands XCD x the
 // x-th eighth of the sorted list, so neighbours meet in one L2.
 // ----------------------------------------------------------------------------------------
-// 16 lanes per read: label[i] = max read number (index >> 1) over the candidates of read r_begin + i and itself
+// 16 lanes per read: label[i] = the highest rank among read r_begin + i and the mirrors b ^ 1 of its candidates,
+// in the order that picked the canonical candidates (mirror_rank: the index for whole-set calls, the scrambled
+// rank for sharded calls).  A read keeps exactly the candidates that rank above it, so the top-ranked read of a
+// neighbourhood is on the list of every one of its neighbours: they all get the same label.
 __global__ __launch_bounds__(256) void k_read_label(const uint32_t* __restrict__ read_tile0, const uint32_t* __restrict__ tile_off,
                                                     const uint32_t* __restrict__ cand_b, uint32_t r_begin, uint32_t n_reads,
-                                                    uint32_t* __restrict__ label) {
+                                                    uint32_t paired, uint32_t* __restrict__ label) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = t >> 4, sub = t & 15u;
     if (i >= n_reads) return;  // (whole 16-lane groups leave together)
     const uint32_t a = r_begin + i;
     const uint32_t seg0 = tile_off[read_tile0[a]], seg1 = tile_off[read_tile0[a + 1]];
-    uint32_t best = a >> 1;
-    for (uint32_t c = seg0 + sub; c < seg1; c += 16) best = max(best, cand_b[c] >> 1);
+    uint32_t best = mirror_rank(a, paired);
+    for (uint32_t c = seg0 + sub; c < seg1; c += 16) best = max(best, mirror_rank(cand_b[c] ^ 1u, paired));
 #pragma unroll
     for (int o = 8; o >= 1; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o, 16));
     if (sub == 0) label[i] = best;
@@ -1134,7 +1137,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_read_sort(const uint32_t* __rest
 
 __global__ void k_read_invert(const uint32_t* __restrict__ rank, uint32_t n_reads, uint32_t r_begin, uint32_t* __restrict__ perm) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_reads) perm[rank[i]] = r_begin + i;
+    if (i < n_reads && rank[i] < n_reads) perm[rank[i]] = r_begin + i;
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1371,6 +1374,7 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
         const uint32_t k = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
         if (k >= n_a || (blockIdx.x >> 3) >= per) return;
         a = perm[k];
+        if (a - r_begin >= n_a) return;  // (cannot happen: perm is a permutation of the shard's reads)
     } else if (blockIdx.x >= n_a) {
         return;
     }
