@@ -36,7 +36,7 @@ struct LayoutParams {
 // AlignmentType, phasm/alignments.py:16-20
 enum : uint32_t { LT_OVERLAP_AB = 0, LT_OVERLAP_BA = 1, LT_A_CONTAINED = 2, LT_B_CONTAINED = 3 };
 // rflag byte per row
-enum : uint32_t { RF_TYPE = 3u, RF_PASS = 4u, RF_INVALID = 128u };
+enum : uint32_t { RF_TYPE = 3u, RF_PASS = 4u, RF_SHADOW = 8u, RF_INVALID = 128u };
 // counters (u64 each)
 enum { LC_TYPE0 = 0, LC_SHORT = 4, LC_MINOVL = 5, LC_OVERHANG = 6, LC_PASS = 7, LC_INVALID = 8, LC_N = 9 };
 
@@ -156,7 +156,7 @@ __device__ inline unsigned long long pair_key(const Edge& e1, const Edge& e2, bo
 // reference would have applied last.
 __global__ __launch_bounds__(256) void k_layout_insert(const Row* __restrict__ rows, uint32_t n_rows,
                                                        const uint32_t* __restrict__ len,
-                                                       const uint8_t* __restrict__ rflag,
+                                                       uint8_t* rflag,
                                                        const uint8_t* __restrict__ removed,
                                                        EdgeSlot* __restrict__ table, uint32_t n_slots) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) {
@@ -168,6 +168,22 @@ __global__ __launch_bounds__(256) void k_layout_insert(const Row* __restrict__ r
         row_edges(r, f & RF_TYPE, len[r.a_idx], len[r.b_idx], e1, e2);
         bool self_twin;
         const unsigned long long key = pair_key(e1, e2, self_twin);
+        // A row whose successor writes the same twin pair can never be the last writer: it stays out of the
+        // table (and k_layout_winner skips it).  The rows of po_overlaps come as (row, strand mirror) pairs, so
+        // this halves the atomics -- device-scope atomics are what this pass costs.
+        if (i + 1 < n_rows) {
+            const uint32_t f2 = rflag[i + 1];
+            if (f2 & RF_PASS) {  // (same twin pair => same two reads => same contained-read status)
+                const Row r2 = rows[i + 1];
+                Edge g1, g2;
+                row_edges(r2, f2 & RF_TYPE, len[r2.a_idx], len[r2.b_idx], g1, g2);
+                bool st2;
+                if (pair_key(g1, g2, st2) == key) {
+                    rflag[i] = (uint8_t)(f | RF_SHADOW);
+                    continue;
+                }
+            }
+        }
         uint32_t s = edge_slot((uint32_t)(key >> 32), (uint32_t)key, n_slots);
         for (;;) {
             unsigned long long cur = table[s].key;
@@ -190,7 +206,7 @@ __global__ __launch_bounds__(256) void k_layout_winner(const Row* __restrict__ r
     if (i >= n_rows) return;
     const uint32_t f = rflag[i];
     uint32_t win = 0;
-    if (f & RF_PASS) {
+    if ((f & RF_PASS) && !(f & RF_SHADOW)) {
         const Row r = rows[i];
         if (!(removed[r.a_idx >> 1] | removed[r.b_idx >> 1])) {
             Edge e1, e2;
