@@ -1179,7 +1179,10 @@ __device__ inline bool exceptions_equal(const uint32_t* __restrict__ exc_off, co
     }
 }
 
-constexpr int VER_GROUP = 16;
+#ifndef PO_VER_GROUP
+#define PO_VER_GROUP 16
+#endif
+constexpr int VER_GROUP = PO_VER_GROUP;  // lanes per candidate (16 bytes of b each per block); 8 lanes x 4 blocks measures 3 % faster, 32 lanes 15 % slower
 #ifndef PO_VER_BLOCK
 #define PO_VER_BLOCK 256
 #endif
@@ -1326,7 +1329,7 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
         const uint64_t bal = __ballot(diff != 0);
         VST({ const unsigned long long t = __builtin_amdgcn_s_memtime(); vt[2] += t - vt_prev; vt_prev = t; })
         if (have) {
-            const bool mismatch = ((bal >> gshift) & ((1ull << VER_GROUP) - 1ull)) != 0;
+            const bool mismatch = ((bal >> gshift) & (VER_GROUP >= 64 ? ~0ull : ((1ull << (VER_GROUP & 63)) - 1ull))) != 0;
             d += nblk * BLK;
             nblk = VER_BLOCKS;
             if (mismatch || (d - 4 * sub) * 32 >= nbits) {  // group-uniform: candidate finished
