@@ -132,3 +132,56 @@ def test_result_from_rows_round_trip_and_pairing_check():
     assert [list(map(int, r)) for r in res.rows().tolist()] == rows.tolist()
     res.free()
     ov.close()
+
+
+def test_native_gfa_reader_survives_mangled_files(tmp_path):
+    """Host-side robustness: a few hundred random mutations of a valid file (bytes flipped, fields dropped,
+    lines cut, tabs and dollars sprinkled) must give either the same answer as the Python reading or a clean
+    ValueError -- never a crash and never rows that name a node the handle does not hold."""
+    import random
+    rng = random.Random(99)
+    base = CASES[12]["text"] + CASES[len(CASES) - 1]["text"].replace("H\tVN:z:2.0\tTS:i:100\n", "")
+    p = tmp_path / "m.gfa"
+    ok = bad = 0
+    for trial in range(300):
+        data = bytearray(base.encode())
+        for _ in range(rng.randint(1, 2)):
+            kind = rng.random()
+            pos = rng.randrange(len(data))
+            if kind < 0.3:
+                data[pos] = rng.choice(b"\t\n$+-0123456789ESx *")
+            elif kind < 0.5:
+                del data[pos:pos + rng.randint(1, 12)]
+            elif kind < 0.7:
+                data[pos:pos] = bytes(rng.choice(b"\t\n$+-9E") for _ in range(rng.randint(1, 4)))
+            elif kind < 0.85:
+                cut = data.find(b"\n", pos)
+                if cut > 0:
+                    del data[pos:cut]
+            else:
+                data[pos:pos] = b"E\t*\tnope+\tnope-\t1\t2\t3\t4\t*\n" if rng.random() < 0.5 else b"S\tdup\t7\t*\nS\tdup\t9\t*\n"
+        p.write_bytes(bytes(data))
+        ov = ExactOverlapper()
+        try:
+            nseg, res = ov.add_gfa(str(p))
+        except ValueError:
+            bad += 1
+            ov.close()
+            continue
+        rows = res.rows()
+        n_nodes = len(ov)
+        assert n_nodes == 2 * nseg
+        if len(rows):
+            assert int(rows["a_idx"].max()) < n_nodes and int(rows["b_idx"].max()) < n_nodes
+        try:    # where the Python reading also succeeds it must agree
+            text = bytes(data).decode()
+            names, lengths, prows = gfa.read_gfa2_rows(text.splitlines(True))
+        except Exception:
+            names = None
+        if names is not None and "\r" not in text and "\x0b" not in text and "\x0c" not in text:
+            assert ov.ids() == [n + s for n in names for s in "+-"], trial
+            assert [list(map(int, r)) for r in rows.tolist()] == prows.tolist(), trial
+        res.free()
+        ov.close()
+        ok += 1
+    assert ok > 10 and bad > 10, (ok, bad)
