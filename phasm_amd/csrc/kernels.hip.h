@@ -1707,30 +1707,68 @@ __global__ __launch_bounds__(1024) void k_ps_spine(uint64_t* __restrict__ block_
 template <typename T>
 __global__ __launch_bounds__(PS_BLOCK) void k_ps_down(const T* __restrict__ in, uint64_t n, const uint64_t* __restrict__ block_sums,
                                                       uint32_t* __restrict__ out) {
-    // thread owns PS_ITEMS consecutive items; block-wide scan of the per-thread sums
+    // thread owns PS_ITEMS consecutive items; block-wide scan of the per-thread sums.  Whole, 16-byte aligned
+    // runs are read and written as 16-byte vectors (a u8 input is one load per thread instead of sixteen, the
+    // offsets four stores instead of sixteen 64-byte-strided ones: 38 -> 13 us for 6.5 M items).
+    static_assert(PS_ITEMS == 16, "vector paths assume 16 items per thread");
     __shared__ uint32_t s_wave[PS_BLOCK / WAVE];
     const uint64_t base = (uint64_t)blockIdx.x * PS_TILE + (uint64_t)threadIdx.x * PS_ITEMS;
+    const bool full = base + PS_ITEMS <= n;
     uint32_t v[PS_ITEMS];
+    if (full && (reinterpret_cast<uintptr_t>(in + base) & 15u) == 0) {
+        if constexpr (sizeof(T) == 1) {
+            const u32x4 q = *reinterpret_cast<const u32x4*>(in + base);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < PS_ITEMS; ++k) v[k] = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const u32x4 q = *reinterpret_cast<const u32x4*>(in + base + 4 * g);
+                v[4 * g] = q.x;
+                v[4 * g + 1] = q.y;
+                v[4 * g + 2] = q.z;
+                v[4 * g + 3] = q.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < PS_ITEMS; ++k) {
+            const uint64_t i = base + k;
+            v[k] = i < n ? (uint32_t)in[i] : 0u;
+        }
+    }
     uint32_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < PS_ITEMS; ++k) {
-        const uint64_t i = base + k;
-        v[k] = i < n ? (uint32_t)in[i] : 0u;
-        acc += v[k];
-    }
+    for (int k = 0; k < PS_ITEMS; ++k) acc += v[k];
     const uint32_t incl = wave_incl_scan(acc);
     if (lane_id() == WAVE - 1) s_wave[threadIdx.x >> 6] = incl;
     __syncthreads();
     uint32_t wave_base = 0;
     for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wave_base += s_wave[w];
     uint32_t run = (uint32_t)block_sums[blockIdx.x] + wave_base + incl - acc;
+    uint32_t o[PS_ITEMS];
 #pragma unroll
     for (int k = 0; k < PS_ITEMS; ++k) {
-        const uint64_t i = base + k;
-        if (i < n) out[i] = run;
+        o[k] = run;
         run += v[k];
-        if (i == n - 1) out[n] = run;  // closing sentinel: out has n+1 entries
     }
+    if (full && (reinterpret_cast<uintptr_t>(out + base) & 15u) == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x4 q;
+            q.x = o[4 * g];
+            q.y = o[4 * g + 1];
+            q.z = o[4 * g + 2];
+            q.w = o[4 * g + 3];
+            *reinterpret_cast<u32x4*>(out + base + 4 * g) = q;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < PS_ITEMS; ++k)
+            if (base + k < n) out[base + k] = o[k];
+    }
+    if (base < n && n <= base + PS_ITEMS) out[n] = run;  // closing sentinel (this thread holds item n-1): out has n+1 entries
 }
 
 }  // namespace po
