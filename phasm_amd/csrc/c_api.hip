@@ -624,6 +624,16 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         hipLaunchKernelGGL((po::k_scan_fixup<BITS>), dim3(n_scan_waves), dim3(64), 0, st, A, n_scan_waves);
         hipLaunchKernelGGL(po::k_add_extra, dim3(cdiv(ntiles, 256)), dim3(256), 0, st, A.tile_count, A.tile_extra, tile_begin,
                            tile_end);
+        if (getenv("PHASM_DEBUG_LEFT")) {  // how many positions did the scan waves defer to k_scan_fixup?
+            std::vector<uint32_t> lc(n_scan_waves);
+            HIP_TRY(h, hipMemcpyAsync(lc.data(), h->d_left_cnt.p, (size_t)n_scan_waves * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(h, hipStreamSynchronize(st));
+            uint64_t sum = 0;
+            uint32_t mx = 0;
+            for (uint32_t v : lc) sum += v, mx = std::max(mx, v);
+            std::fprintf(stderr, "[left] %u scan waves deferred %llu positions (max %u per wave, cap %d)\n", n_scan_waves,
+                         (unsigned long long)sum, mx, (int)po::LEFT_CAP);
+        }
     }
     HIP_TRY(h, hipGetLastError());
 #ifdef PO_STAMPS
