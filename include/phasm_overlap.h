@@ -202,7 +202,7 @@ po_status po_result_from_rows(po_handle* h, const po_row* rows, uint64_t n, po_r
  * (gfa2_parse_segments, phasm/io/gfa.py:107-109) into an EMPTY handle via po_add_segment, pass 2 turns
  * every E line into a row (gfa2_parse_edge + gfa2_line_to_la, gfa.py:72-104: ids end in the strand
  * character, positions may carry a trailing `$`).  An E line naming an unknown segment fails, as the
- * reference's dict lookup does. */
+ * reference's dict lookup does.  After a failure the handle may already hold some of the segments: destroy it. */
 po_status po_add_gfa(po_handle* h, const char* path, uint64_t* n_segments, po_result** rows_out);
 
 /* Stage 1 of `phasm layout` on the rows of `rows` (a result of this handle):
