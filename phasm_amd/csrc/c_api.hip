@@ -540,16 +540,14 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         hipLaunchKernelGGL(po::k_wide_finalize<BITS>, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt,
                            slot_start, chain64, len);
     }
+    // Which reads repeat their own prefix K-mer (selfrep: only their A candidates can be non-longest duplicates)?
+    // The narrow whole-set scan finds that as a side effect.  The other cases do not scan every read for it -- a
+    // pass over all positions cost 2.2 ms at config 3 with the wide index, and more than the shard's own scan at 8
+    // shards -- they count every read they did not scan as "may repeat" (0), which sends all verified A candidates
+    // with such a b through the hashed longest-only selection below (a table insert per candidate).
     if (wide) {
-        // the wide scan does not look for prefix recurrences: one pass over all reads finds selfrep
-        const uint32_t blocks = std::min<uint32_t>(cdiv((uint64_t)h->n_tiles * 64, 256), (uint32_t)h->n_cu * 8);
-        hipLaunchKernelGGL(po::k_selfrep<BITS>, dim3(blocks), dim3(256), 0, st, words, h->d_tiles.as<po::TileRec>(),
-                           h->n_tiles, 0u, 0u, m, kmask, selfrep, reinterpret_cast<uint32_t*>(scalars + 2));
+        hipLaunchKernelGGL(po::k_fill_u32, dim3(cdiv(n, 256)), dim3(256), 0, st, selfrep, (uint64_t)n, 0u);
     } else if (nshards > 1) {
-        // sharded call: the scan finds selfrep only for the shard's own reads.  Scanning all the others just
-        // for that costs more than the shard's own scan at 8 shards; instead every read outside the shard
-        // counts as "may repeat its prefix" (0), which sends all verified A candidates with such a b through
-        // the hashed longest-only selection below -- a few hundred thousand table inserts.
         if (r_begin) hipLaunchKernelGGL(po::k_fill_u32, dim3(cdiv(r_begin, 256)), dim3(256), 0, st, selfrep, (uint64_t)r_begin, 0u);
         if (r_end < n)
             hipLaunchKernelGGL(po::k_fill_u32, dim3(cdiv(n - r_end, 256)), dim3(256), 0, st, selfrep + r_end, (uint64_t)(n - r_end), 0u);
@@ -654,7 +652,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     HIP_TRY(h, hipStreamSynchronize(st));
     const uint64_t n_cand64 = h->pinned[1];
     uint32_t n_selfrep_reads = (uint32_t)h->pinned[8];
-    if (nshards > 1 && !wide) n_selfrep_reads |= 1u;  // reads outside the shard are all suspects (see above)
+    if (nshards > 1 || wide) n_selfrep_reads |= 1u;  // reads this call did not scan for self-repeats are all suspects (see above)
     S.n_candidates = n_cand64;
     if (n_cand64 >= 0xFFFFFF00ull)
         return fail(h, PO_ERR_CAPACITY, "candidate count " + std::to_string(n_cand64) + " exceeds one call's capacity (2^32)");
@@ -748,14 +746,13 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
 #endif
         HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
         // ---- select + row offsets
-        unsigned long long* pkey = nullptr;
-        uint32_t* pmin = nullptr;
+        po::PairSlot* ptab = nullptr;
         uint32_t pbits = 0;
         if (n_selfrep_reads) {
             // some read's prefix recurs inside it: A candidates of such b may be non-longest duplicates
             uint32_t n_sus;
-            if (nshards > 1 && !wide) {
-                n_sus = n_cand;  // upper bound, no counting pass and no host round trip (see the index step)
+            if ((nshards > 1 || wide) && n_cand < (4u << 20)) {
+                n_sus = n_cand;  // upper bound: no counting pass, no host round trip (a big call sizes its table exactly)
             } else {
                 uint32_t* n_suspect = reinterpret_cast<uint32_t*>(scalars + 2) + 1;
                 hipLaunchKernelGGL(po::k_count_suspects, dim3(std::min<uint32_t>(cdiv(n_cand, 256), (uint32_t)h->n_cu * 8)), dim3(256), 0,
@@ -767,19 +764,16 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             if (n_sus) {
                 pbits = 4;
                 while ((1ull << pbits) < 2ull * n_sus) ++pbits;
-                PO_TRY(ensure(h, h->d_pair_key, ((size_t)1 << pbits) * 8));
-                PO_TRY(ensure(h, h->d_pair_min, ((size_t)1 << pbits) * 4));
-                HIP_TRY(h, hipMemsetAsync(h->d_pair_key.p, 0xFF, ((size_t)1 << pbits) * 8, st));
-                HIP_TRY(h, hipMemsetAsync(h->d_pair_min.p, 0xFF, ((size_t)1 << pbits) * 4, st));
-                pkey = h->d_pair_key.as<unsigned long long>();
-                pmin = h->d_pair_min.as<uint32_t>();
+                PO_TRY(ensure(h, h->d_pair_key, ((size_t)1 << pbits) * sizeof(po::PairSlot)));
+                HIP_TRY(h, hipMemsetAsync(h->d_pair_key.p, 0xFF, ((size_t)1 << pbits) * sizeof(po::PairSlot), st));
+                ptab = h->d_pair_key.as<po::PairSlot>();
                 hipLaunchKernelGGL(po::k_select_mark, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_b,
-                                   h->d_type.as<uint8_t>(), n_cand, selfrep, pkey, pmin, pbits);
+                                   h->d_type.as<uint8_t>(), n_cand, selfrep, ptab, pbits);
             }
         }
         if (want_cands) PO_TRY(ensure(h, h->d_flag, (size_t)n_cand));
         hipLaunchKernelGGL(po::k_select, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_b,
-                           h->d_type.as<uint8_t>(), n_cand, selfrep, pkey, pmin, pbits, paired, h->d_rowcnt.as<uint8_t>(),
+                           h->d_type.as<uint8_t>(), n_cand, selfrep, ptab, pbits, paired, h->d_rowcnt.as<uint8_t>(),
                            want_cands ? h->d_flag.as<uint8_t>() : nullptr);
         HIP_TRY(h, hipGetLastError());
         if (!want_cands) {

@@ -1020,37 +1020,6 @@ __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
     }
 }
 
-// selfrep for the wide index, whose scan does not look for prefix recurrences (the narrow COUNT pass finds
-// them as a side effect): one pass over every tile outside [skip_begin, skip_end).
-template <int BITS>
-__global__ __launch_bounds__(256) void k_selfrep(const uint64_t* __restrict__ words, const TileRec* __restrict__ tiles,
-                                                 uint32_t n_tiles, uint32_t skip_begin, uint32_t skip_end, uint32_t m,
-                                                 uint64_t kmask, uint32_t* selfrep, uint32_t* n_selfrep) {
-    constexpr int W = 64 / BITS;
-    const uint32_t lane = lane_id();
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < n_tiles; t += nwaves) {
-        if (t >= skip_begin && t < skip_end) continue;
-        const TileRec rec = tiles[t];
-        const uint32_t la = rec.la;
-        if (la < m) continue;
-        const uint32_t pmax = la - m;
-        const uint32_t p0 = (rec.word0 + lane) * W;
-        uint32_t best = NO_SELFREP;
-        if (p0 <= pmax) {
-            const uint64_t key_a = words[rec.wread] & kmask;
-            const uint64_t w0 = words[rec.wabs + lane], w1 = words[rec.wabs + lane + 1];
-#pragma unroll
-            for (int s = W - 1; s >= 0; --s) {
-                const uint64_t kmer = window<BITS>(w0, w1, s) & kmask;
-                const uint32_t p = p0 + s;
-                if (kmer == key_a && p > 0 && p <= pmax) best = p;
-            }
-        }
-        if (best != NO_SELFREP) note_selfrep(selfrep, rec.read, best, n_selfrep);
-    }
-}
-
 // ----------------------------------------------------------------------------------------
 // verify order.  Each b is read by ~35 different a's (the reads that overlap it from the left), in an order
 // unrelated to where the reads come from, so every XCD's L2 keeps missing (hit rate 25 %: 9.5 GB of fabric
@@ -1413,6 +1382,14 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
 // candidates: O(1) per candidate, also for tandem repeats with thousands of hits per pair) and
 // k_select drops every other one.
 // ----------------------------------------------------------------------------------------
+// one slot of the (a, b) -> smallest verified-A candidate table: key and minimum share 16 bytes, so the claim, the
+// atomicMin and k_select's lookup touch one cache line (memset 0xFF = empty key, "infinite" minimum)
+struct __attribute__((aligned(16))) PairSlot {
+    unsigned long long key;
+    uint32_t min_idx;
+    uint32_t pad;
+};
+
 __device__ inline uint32_t pair_slot(uint32_t a, uint32_t b, uint32_t tbits) {
     uint32_t h1, h2;
     kmer_hash(((uint64_t)a << 32) | b, h1, h2);
@@ -1438,7 +1415,7 @@ __global__ __launch_bounds__(256) void k_count_suspects(const uint32_t* __restri
 
 __global__ void k_select_mark(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_b,
                               const uint8_t* __restrict__ type, uint32_t n_cand, const uint32_t* __restrict__ selfrep,
-                              unsigned long long* __restrict__ pkey, uint32_t* __restrict__ pmin, uint32_t tbits) {
+                              PairSlot* __restrict__ ptab, uint32_t tbits) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_cand || !(type[i] & 1u)) return;
     const uint32_t a = cand_a[i], b = cand_b[i];
@@ -1447,11 +1424,12 @@ __global__ void k_select_mark(const uint32_t* __restrict__ cand_a, const uint32_
     const uint32_t tmask = (1u << tbits) - 1u;
     uint32_t s = pair_slot(a, b, tbits);
     for (;;) {
-        const unsigned long long prev = atomicCAS(&pkey[s], ~0ull, key);
+        unsigned long long prev = ptab[s].key;
+        if (prev == ~0ull) prev = atomicCAS(&ptab[s].key, ~0ull, key);
         if (prev == ~0ull || prev == key) break;
         s = (s + 1u) & tmask;
     }
-    atomicMin(&pmin[s], i);
+    atomicMin(&ptab[s].min_idx, i);
 }
 
 // Rows per verified candidate in emission order: A row, [its mirror], B row, [its mirror].
@@ -1460,10 +1438,10 @@ __device__ inline uint32_t rows_of(uint32_t t, uint32_t a, uint32_t b, uint32_t 
     return ((t & 1u) ? (a == (b ^ 1u) ? 1u : 2u) : 0u) + ((t & 2u) ? 2u : 0u);
 }
 
-// pkey == nullptr: no read has a self-repeating prefix, every verified A candidate is the longest
+// ptab == nullptr: no read has a self-repeating prefix, every verified A candidate is the longest
 __global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_b,
                          uint8_t* __restrict__ type, uint32_t n_cand, const uint32_t* __restrict__ selfrep,
-                         const unsigned long long* __restrict__ pkey, const uint32_t* __restrict__ pmin, uint32_t tbits,
+                         const PairSlot* __restrict__ ptab, uint32_t tbits,
                          uint32_t paired, uint8_t* __restrict__ rowcnt, uint8_t* __restrict__ flag) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_cand) return;
@@ -1474,12 +1452,20 @@ __global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __
         return;
     }
     const uint32_t a = cand_a[i], b = cand_b[i];
-    if (pkey && (t & 1u) && selfrep[b] != NO_SELFREP) {
+    if (ptab && (t & 1u) && selfrep[b] != NO_SELFREP) {
         const unsigned long long key = ((unsigned long long)a << 32) | b;
         const uint32_t tmask = (1u << tbits) - 1u;
         uint32_t s = pair_slot(a, b, tbits);
-        while (pkey[s] != key) s = (s + 1u) & tmask;  // k_select_mark inserted it
-        if (pmin[s] != i) {  // a longer overlap of the same pair exists
+        uint32_t first;
+        for (;;) {  // k_select_mark inserted the key
+            const uint4 q = *reinterpret_cast<const uint4*>(&ptab[s]);
+            if ((((unsigned long long)q.y << 32) | q.x) == key) {
+                first = q.z;
+                break;
+            }
+            s = (s + 1u) & tmask;
+        }
+        if (first != i) {  // a longer overlap of the same pair exists
             t &= ~1u;
             type[i] = (uint8_t)t;
         }
