@@ -116,6 +116,8 @@ def main() -> int:
     ap.add_argument("--min-length", type=int, default=1000)
     ap.add_argument("--cpu-sample-reads", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-path", action="store_true",
+                    help="dev: run the N>1 code path (shard + RCCL all-gather + expansion) even with one rank")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearse the N>1 path with several ranks on one GPU (rows merged on the host)")
     args = ap.parse_args()
@@ -132,7 +134,12 @@ def main() -> int:
     torch.cuda.set_device(dev_idx)
     device = torch.device("cuda", dev_idx)
     merge_device = device if args.dist_backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    if world > 1 or args.dist_path:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -155,7 +162,7 @@ def main() -> int:
     last = {}
 
     def step(timed: bool) -> int:
-        if world == 1:
+        if world == 1 and not args.dist_path:
             res = ov.overlaps_result(m)
             n = len(res)
             res.free()
@@ -167,7 +174,7 @@ def main() -> int:
             n = len(res)
             res.free()
         st = ov.stats()
-        if world > 1:
+        if world > 1 or args.dist_path:
             # the expansion saw every rank's candidates: scale its byte counters to this rank's share
             for k in ("verify_bytes_algo", "sum_overlap_bases", "n_rows"):
                 st[k] = st[k] // world
@@ -255,7 +262,7 @@ def main() -> int:
             out["layout_stage1"] = layout_leg(ov, m, not args.no_cpu_baseline)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(m, args.cpu_sample_reads)
-    if world > 1:
+    if world > 1 or args.dist_path:
         dist.barrier()
         dist.destroy_process_group()
     ov.close()
