@@ -122,6 +122,13 @@ def main() -> int:
                     help="gloo: rehearse the N>1 path with several ranks on one GPU (rows merged on the host)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: RCCL prints a version banner on stdout when its first
+    # communicator comes up, and libraries may print what they like -- everything written to descriptor 1 from
+    # here on goes to stderr, the JSON line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -266,8 +273,10 @@ def main() -> int:
         dist.barrier()
         dist.destroy_process_group()
     ov.close()
+    sys.stdout.flush()
     if out is not None:
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     return 0
 
 
