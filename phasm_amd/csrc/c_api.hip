@@ -511,10 +511,12 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
 
     // ---- index: anchor table, chains, Bloom filter
     HIP_TRY(h, hipEventRecord(h->ev[EV_START], st));
-    HIP_TRY(h, hipMemsetAsync(h->d_scalars.p, 0, 64, st));
-    HIP_TRY(h, hipMemsetAsync(bloom, 0, bloom_bytes, st));
-    hipLaunchKernelGGL(po::k_table_init, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt, slot_cur);
-    hipLaunchKernelGGL(po::k_fill_u32, dim3(cdiv(n, 256)), dim3(256), 0, st, selfrep, (uint64_t)n, po::NO_SELFREP);
+    {
+        const uint32_t bloom_words = (uint32_t)(bloom_bytes / 4);
+        const uint32_t init_n = std::max(std::max(nslots, n), std::max(bloom_words, 8u));
+        hipLaunchKernelGGL(po::k_call_init, dim3(cdiv(init_n, 256)), dim3(256), 0, st, table, nslots, slot_cnt, slot_cur, selfrep, n,
+                           bloom, bloom_words, scalars);
+    }
     if (!wide) {
         hipLaunchKernelGGL(po::k_table_insert, dim3(cdiv(n, 256)), dim3(256), 0, st, words, woff, len, n, m, kmask, table,
                            tbits, slot_cnt, read_slot, bloom, bloom_log2, (uint32_t)BITS);

@@ -178,7 +178,10 @@ __device__ inline void table_probe(const Slot* __restrict__ tab, uint32_t tbits,
 // ----------------------------------------------------------------------------------------
 // index build
 // ----------------------------------------------------------------------------------------
-__global__ void k_table_init(Slot* tab, uint32_t nslots, uint32_t* slot_cnt, uint32_t* slot_cur) {
+// Everything a call starts from, in one launch: empty table, zero slot counters, "no self-repeat" for every
+// read, an empty filter and zero scalars (four small launches and memsets cost ~5 us each in a 2.6 ms step).
+__global__ void k_call_init(Slot* tab, uint32_t nslots, uint32_t* slot_cnt, uint32_t* slot_cur, uint32_t* selfrep,
+                            uint32_t n_reads, uint32_t* bloom, uint32_t bloom_words, unsigned long long* scalars) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nslots) {
         tab[i].key = KEY_EMPTY;
@@ -187,6 +190,9 @@ __global__ void k_table_init(Slot* tab, uint32_t nslots, uint32_t* slot_cnt, uin
         slot_cnt[i] = 0;
         slot_cur[i] = 0;
     }
+    if (i < n_reads) selfrep[i] = NO_SELFREP;
+    if (i < bloom_words) bloom[i] = 0;
+    if (i < 8) scalars[i] = 0;
 }
 
 __global__ void k_fill_u32(uint32_t* p, uint64_t n, uint32_t v) {
