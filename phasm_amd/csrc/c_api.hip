@@ -545,15 +545,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     // Which reads repeat their own prefix K-mer (selfrep: only their A candidates can be non-longest duplicates)?
     // The narrow whole-set scan finds that as a side effect.  The other cases do not scan every read for it -- a
     // pass over all positions cost 2.2 ms at config 3 with the wide index, and more than the shard's own scan at 8
-    // shards -- they count every read they did not scan as "may repeat" (0), which sends all verified A candidates
-    // with such a b through the hashed longest-only selection below (a table insert per candidate).
-    if (wide) {
-        hipLaunchKernelGGL(po::k_fill_u32, dim3(cdiv(n, 256)), dim3(256), 0, st, selfrep, (uint64_t)n, 0u);
-    } else if (nshards > 1) {
-        if (r_begin) hipLaunchKernelGGL(po::k_fill_u32, dim3(cdiv(r_begin, 256)), dim3(256), 0, st, selfrep, (uint64_t)r_begin, 0u);
-        if (r_end < n)
-            hipLaunchKernelGGL(po::k_fill_u32, dim3(cdiv(n - r_end, 256)), dim3(256), 0, st, selfrep + r_end, (uint64_t)(n - r_end), 0u);
-    }
+    // shards -- and settle duplicates inside each read's own candidate list instead (k_select_local, below).
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev[EV_INDEX], st));
 
@@ -654,7 +646,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     HIP_TRY(h, hipStreamSynchronize(st));
     const uint64_t n_cand64 = h->pinned[1];
     uint32_t n_selfrep_reads = (uint32_t)h->pinned[8];
-    if (nshards > 1 || wide) n_selfrep_reads |= 1u;  // reads this call did not scan for self-repeats are all suspects (see above)
+    if (nshards > 1 || wide) n_selfrep_reads |= 1u;  // k_select_local may hand repetitive reads to the global selection
     S.n_candidates = n_cand64;
     if (n_cand64 >= 0xFFFFFF00ull)
         return fail(h, PO_ERR_CAPACITY, "candidate count " + std::to_string(n_cand64) + " exceeds one call's capacity (2^32)");
@@ -750,8 +742,15 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         // ---- select + row offsets
         po::PairSlot* ptab = nullptr;
         uint32_t pbits = 0;
+        if (nshards > 1 || wide) {
+            static_assert(po::SEL_CAP == 512, "k_select_local hashes to 9 bits");
+            hipLaunchKernelGGL(po::k_select_local, dim3(cdiv(r_end - r_begin, 256 / po::WAVE)), dim3(256), 0, st,
+                               h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_b, h->d_type.as<uint8_t>(),
+                               r_begin, r_end - r_begin, selfrep);
+        }
         if (n_selfrep_reads) {
-            // some read's prefix recurs inside it: A candidates of such b may be non-longest duplicates
+            // some read's prefix recurs inside it (or a read was too repetitive for k_select_local): A candidates
+            // of such b may be non-longest duplicates
             uint32_t n_sus;
             if ((nshards > 1 || wide) && n_cand < (4u << 20)) {
                 n_sus = n_cand;  // upper bound: no counting pass, no host round trip (a big call sizes its table exactly)

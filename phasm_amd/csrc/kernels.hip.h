@@ -1402,6 +1402,64 @@ __device__ inline uint32_t pair_slot(uint32_t a, uint32_t b, uint32_t tbits) {
     return (h1 ^ (h2 >> 3)) >> (32 - tbits);
 }
 
+// Longest-only selection inside one read's candidate list, in LDS (sharded calls and the wide index, which do
+// not know which reads repeat their prefix): two verified A candidates of one (a, b) pair are necessarily in a's
+// own list, so a wave takes one read, enters its verified A candidates into a small LDS table b -> smallest
+// candidate index, and clears the A bit of every candidate that is not that smallest one.  No global table, no
+// device-scope atomics (9.3 M of them cost 1.3 ms at config 3).  A read with more verified A candidates than the
+// table takes (tandem repeats) marks its b's as suspects instead and leaves them to the global table below.
+constexpr uint32_t SEL_CAP = 512;  // LDS table entries per wave (load <= 1/2)
+__global__ __launch_bounds__(256) void k_select_local(const uint32_t* __restrict__ read_tile0, const uint32_t* __restrict__ tile_off,
+                                                      const uint32_t* __restrict__ cand_b, uint8_t* __restrict__ type,
+                                                      uint32_t r_begin, uint32_t n_reads, uint32_t* __restrict__ selfrep) {
+    __shared__ uint32_t s_key[256 / WAVE][SEL_CAP];  // b + 1, 0 = empty
+    __shared__ uint32_t s_min[256 / WAVE][SEL_CAP];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * (256 / WAVE) + wave;
+    if (i >= n_reads) return;  // whole wave
+    const uint32_t a = r_begin + i;
+    const uint32_t seg0 = tile_off[read_tile0[a]], seg1 = tile_off[read_tile0[a + 1]];
+    if (seg1 - seg0 < 2) return;
+    uint32_t n_a = 0;
+    for (uint32_t c0 = seg0; c0 < seg1; c0 += WAVE) {
+        const uint32_t c = c0 + lane;
+        n_a += (uint32_t)__popcll(__ballot(c < seg1 && (type[c] & 1u)));
+    }
+    if (n_a < 2) return;  // (wave-uniform)
+    if (n_a > SEL_CAP / 2) {
+        for (uint32_t c = seg0 + lane; c < seg1; c += WAVE)
+            if (type[c] & 1u) selfrep[cand_b[c]] = 0;  // "may repeat": the global selection handles this read
+        return;
+    }
+    uint32_t* key = s_key[wave];
+    uint32_t* mn = s_min[wave];
+    for (uint32_t k = lane; k < SEL_CAP; k += WAVE) {
+        key[k] = 0;
+        mn[k] = ~0u;
+    }
+    wave_lds_fence();
+    for (uint32_t c = seg0 + lane; c < seg1; c += WAVE) {
+        if (!(type[c] & 1u)) continue;
+        const uint32_t b = cand_b[c];
+        uint32_t s = (b * 0x9E3779B1u) >> (32 - 9);
+        for (;;) {
+            const uint32_t prev = atomicCAS(&key[s], 0u, b + 1u);
+            if (prev == 0u || prev == b + 1u) break;
+            s = (s + 1u) & (SEL_CAP - 1u);
+        }
+        atomicMin(&mn[s], c);
+    }
+    wave_lds_fence();
+    for (uint32_t c = seg0 + lane; c < seg1; c += WAVE) {
+        const uint32_t t = type[c];
+        if (!(t & 1u)) continue;
+        const uint32_t b = cand_b[c];
+        uint32_t s = (b * 0x9E3779B1u) >> (32 - 9);
+        while (key[s] != b + 1u) s = (s + 1u) & (SEL_CAP - 1u);
+        if (mn[s] != c) type[c] = (uint8_t)(t & ~1u);  // a longer overlap of the same pair exists
+    }
+}
+
 __global__ __launch_bounds__(256) void k_count_suspects(const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,
                                                         uint32_t n_cand, const uint32_t* __restrict__ selfrep,
                                                         uint32_t* __restrict__ n_suspect) {
