@@ -21,6 +21,12 @@ def _have_gpu() -> bool:
 
 
 def pytest_collection_modifyitems(config, items):
+    # a hung kernel or collective must end the run with a traceback, not sit there: per-test wall-clock limit
+    # (pytest-timeout, "thread" method: it can end a process that is stuck inside a native call)
+    if config.pluginmanager.hasplugin("timeout"):
+        for item in items:
+            if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(600, method="thread"))
     if _have_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this process")

@@ -76,8 +76,12 @@ def test_rccl_collectives_one_rank_group():
     very same calls (count all-gather, padded all_gather_into_tensor of int32[n,4], expansion)."""
     import torch.distributed as dist
     from phasm_amd.dist import rows_tensor_to_struct, sharded_overlaps
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    import socket
+    with socket.socket() as sk:          # a port nobody holds, instead of a fixed one
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
     dev = torch.device("cuda", 0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
