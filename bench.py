@@ -63,6 +63,25 @@ def cpu_baseline(min_length: int, sample_reads: int) -> dict:
             "host_cores_available": os.cpu_count()}
 
 
+def measured_hbm_gbs(device) -> float:
+    """What this box's HBM actually delivers: a device-to-device copy of 2 GiB (read + write counted)."""
+    n = 1 << 31
+    src = torch.empty(n, dtype=torch.uint8, device=device)
+    dst = torch.empty(n, dtype=torch.uint8, device=device)
+    src.zero_()
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    del src, dst
+    return 2.0 * n / (ms * 1e-3) / 1e9
+
+
 def layout_leg(ov: ExactOverlapper, m: int, with_cpu: bool) -> dict:
     """Next row of the path: stage 1 of `phasm layout` -- classify, contained-read
     and alignment filters, assembly-graph edges -- on the rows of one step, still resident in HBM."""
@@ -266,6 +285,7 @@ def main() -> int:
             res.free()
             out["pcie_inclusive"] = {"overlaps_per_sec": n_rows / (time.perf_counter() - t1),
                                      "note": "one step + D2H of the 24-byte row array to pageable host memory"}
+            out["roofline"]["hbm_copy_measured"] = measured_hbm_gbs(device)   # GB/s of a d2d copy on this box
             out["layout_stage1"] = layout_leg(ov, m, not args.no_cpu_baseline)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(m, args.cpu_sample_reads)
