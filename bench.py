@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from phasm_amd import synth  # noqa: E402
-from phasm_amd.dist import expand_candidates, local_shard_candidates, merge_row_shards  # noqa: E402
+from phasm_amd.dist import CandidateExchange, expand_candidates  # noqa: E402
 from phasm_amd.overlapper import ExactOverlapper  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
@@ -183,6 +183,7 @@ def main() -> int:
     t_load = time.time() - t_load
     m = args.min_length
 
+    exchange = CandidateExchange(ov, device=merge_device) if (world > 1 or args.dist_path) else None
     stage_keys = ["ms_index", "ms_scan_count", "ms_scan_fill", "ms_verify", "ms_select", "ms_emit", "ms_total"]
     acc = {k: 0.0 for k in stage_keys}
     last = {}
@@ -194,7 +195,7 @@ def main() -> int:
             res.free()
         else:
             # exchange the compact form (verified candidates, 16 B), expand to rows on every rank
-            merged = merge_row_shards(local_shard_candidates(ov, m, rank, world, merge_device), keep_padding=True)
+            merged = exchange.candidates(m)   # shard + one all-gather of fixed slots (phasm_amd/dist.py)
             shard_st = ov.stats()          # stage timings of this rank's shard (before the expansion)
             res = expand_candidates(ov, merged)
             n = len(res)
@@ -254,7 +255,7 @@ def main() -> int:
                                    % (args.config, cfg.n_reads, cfg.read_len, cfg.genome_len, cfg.ploidy,
                                       cfg.snp, cfg.seed, n_oriented, m),
                        "n_reads": cfg.n_reads, "read_len": cfg.read_len, "min_length": m,
-                       "parallelism": "a-side read shards x%d + RCCL all-gather of verified candidates (16 B) + local row expansion" % world if world > 1
+                       "parallelism": "a-side read shards x%d + one RCCL all-gather of verified candidates (16 B, fixed slots) per step + local row expansion" % world if world > 1
                                       else "single GPU"},
             "rows_per_step": int(n_rows),
             "read_pairs_per_sec": n_oriented * (n_oriented - 1) / (dt / K),

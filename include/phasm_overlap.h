@@ -146,6 +146,8 @@ const po_row* po_result_rows(po_result* r);
 const void* po_result_device_rows(const po_result* r);
 /* Copy the rows device->device into dst (>= count*sizeof(po_row) bytes), e.g. a torch tensor. */
 po_status po_result_copy_to_device(po_result* r, void* dst_device);
+/* The same for the first `count` entries only (count <= po_result_count). */
+po_status po_result_copy_prefix_to_device(po_result* r, void* dst_device, uint64_t count);
 void po_result_free(po_result* r);
 
 /* Write one GFA2 edge line per row to the file descriptor, byte-identical to the reference's

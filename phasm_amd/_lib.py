@@ -86,6 +86,7 @@ SYMBOLS = [
     ("po_result_rows", ctypes.c_void_p, [_P]),
     ("po_result_device_rows", ctypes.c_void_p, [_P]),
     ("po_result_copy_to_device", ctypes.c_int, [_P, ctypes.c_void_p]),
+    ("po_result_copy_prefix_to_device", ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64]),
     ("po_result_free", None, [_P]),
     ("po_write_gfa_edges", ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
     ("po_add_segment", ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]),

@@ -78,7 +78,9 @@ struct po_handle {
     DevBuf d_bloom, d_selfrep, d_tile_count, d_tile_off, d_truemask, d_ps_blocks, d_scalars, d_left, d_left_cnt, d_tile_extra;
     DevBuf d_cand_a, d_cand_p, d_cand_b, d_type, d_rowcnt, d_row_off, d_flag, d_pair_key, d_pair_min;
     DevBuf d_vlabel, d_vrank, d_vperm;  // verify order (k_read_label, k_read_sort, k_read_invert)
-    DevBuf spare_rows;
+    DevBuf spare_rows;   // device buffers of freed results, kept for the next call (hipFree / hipMalloc of a
+    DevBuf spare_cands;  // 50-170 MB buffer costs ~0.2 ms each and synchronises the device)
+    DevBuf spare_edges;
     int live_results = 0;
 
     po_stats stats = {};
@@ -96,6 +98,7 @@ struct po_result {
     DevBuf d_rows;          // po_row[count] (elem 24) or po_cand[count] (elem 16)
     uint64_t count = 0;
     size_t elem = sizeof(po_row);
+    bool kind_edges = false;  // po_edge entries (same size as po_cand)
     void* host = nullptr;
 };
 
@@ -790,6 +793,10 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
             HIP_TRY(h, hipStreamSynchronize(st));
             const uint64_t n_ver = h->pinned[3];
+            if (h->spare_cands.p && h->spare_cands.cap >= n_ver * sizeof(po::Cand)) {
+                res->d_rows = h->spare_cands;
+                h->spare_cands = DevBuf();
+            }
             PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_ver * sizeof(po::Cand), 256)));
             hipLaunchKernelGGL(po::k_compact, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_p, A.cand_b,
                                h->d_type.as<uint8_t>(), h->d_flag.as<uint8_t>(), h->d_row_off.as<uint32_t>(), n_cand,
@@ -914,6 +921,7 @@ po_status run_layout(po_handle* h, po_result* rows, const po_layout_params& prm,
     L = po_layout_stats();
     res->count = 0;
     res->elem = sizeof(po_edge);
+    res->kind_edges = true;
     const uint32_t n_nodes = (uint32_t)h->len.size();
     const uint64_t n_rows64 = rows->count;
     if (n_rows64 >= 0x7FFFFFF0ull) return fail(h, PO_ERR_CAPACITY, "po_layout_edges: more than 2^31 rows in one call");
@@ -981,6 +989,10 @@ po_status run_layout(po_handle* h, po_result* rows, const po_layout_params& prm,
         HIP_TRY(h, hipEventRecord(h->ev_lay[2], st));
         HIP_TRY(h, hipStreamSynchronize(st));
         n_edges = h->pinned[2];
+        if (h->spare_edges.p && h->spare_edges.cap >= n_edges * sizeof(po_edge)) {
+            res->d_rows = h->spare_edges;
+            h->spare_edges = DevBuf();
+        }
         PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_edges * sizeof(po_edge), 256)));
         if (n_edges) {
             hipLaunchKernelGGL(po::k_layout_emit, dim3(cdiv(n_rows, 256)), dim3(256), 0, st, d_rows, n_rows, d_len,
@@ -1127,7 +1139,7 @@ void po_destroy(po_handle* h) {
                           &h->d_table, &h->d_slot_cnt, &h->d_slot_cur, &h->d_slot_start, &h->d_read_slot, &h->d_chain,
                           &h->d_chain_tmp, &h->d_long_list, &h->d_bloom, &h->d_selfrep, &h->d_tile_count, &h->d_tile_off,
                           &h->d_ps_blocks, &h->d_scalars, &h->d_cand_a, &h->d_cand_p, &h->d_cand_b, &h->d_type,
-                          &h->d_rowcnt, &h->d_row_off, &h->d_flag, &h->d_pair_key, &h->d_pair_min, &h->spare_rows,
+                          &h->d_rowcnt, &h->d_row_off, &h->d_flag, &h->d_pair_key, &h->d_pair_min, &h->spare_rows, &h->spare_cands, &h->spare_edges,
                           &h->d_vlabel, &h->d_vrank, &h->d_vperm, &h->d_lay_len, &h->d_lay_cnt, &h->d_rflag, &h->d_removed, &h->d_ekey, &h->d_ecnt,
                           &h->d_ewin, &h->d_eoff};
         for (DevBuf* b : bufs) b->release();
@@ -1378,15 +1390,29 @@ po_status po_result_copy_to_device(po_result* r, void* dst_device) {
     return PO_OK;
 }
 
+po_status po_result_copy_prefix_to_device(po_result* r, void* dst_device, uint64_t count) {
+    if (!r || (!dst_device && count)) return PO_ERR_INVALID;
+    if (count > r->count) return fail(r->h, PO_ERR_INVALID, "po_result_copy_prefix_to_device: count exceeds the result");
+    if (count == 0) return PO_OK;
+    po_handle* h = r->h;
+    PO_TRY(init_device(h));
+    PO_TRY(rows_to_device(h, r));
+    HIP_TRY(h, hipMemcpyAsync(dst_device, r->d_rows.p, count * r->elem, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PO_OK;
+}
+
 void po_result_free(po_result* r) {
     if (!r) return;
     po_handle* h = r->h;
     std::free(r->host);
     if (h) {
         --h->live_results;
-        if (r->elem == sizeof(po_row) && r->d_rows.p && r->d_rows.cap > h->spare_rows.cap) {  // keep the larger buffer for the next call
-            h->spare_rows.release();
-            h->spare_rows = r->d_rows;
+        // keep the larger buffer for the next call
+        DevBuf* spare = r->elem == sizeof(po_row) ? &h->spare_rows : (r->kind_edges ? &h->spare_edges : &h->spare_cands);
+        if (r->d_rows.p && r->d_rows.cap > spare->cap) {
+            spare->release();
+            *spare = r->d_rows;
             r->d_rows = DevBuf();
         }
     }

@@ -16,7 +16,8 @@ What travels is the compact form, not the rows: each rank's *verified candidates
 into rows locally (``po_expand``, ~0.1 ms).  xGMI is point-to-point, so an all-gather is bound
 by the per-link rate: shrinking the payload is what scales.
 
-RCCL has no all-gatherv: counts are gathered first, then one padded ``all_gather_into_tensor``.
+RCCL has no all-gatherv: ``merge_row_shards`` gathers counts first, then one padded ``all_gather_into_tensor``;
+``CandidateExchange`` is the steady-state form with fixed slots and a single collective per step.
 """
 from __future__ import annotations
 
@@ -100,6 +101,96 @@ def expand_candidates(ov, cands: torch.Tensor):
     return res
 
 
+class CandidateExchange:
+    """The steady-state form of the N>1 step: shard -> ONE all-gather -> expansion.
+
+    ``merge_row_shards`` needs two collectives per step (counts, then padded data) and a host round trip in
+    between.  Here every rank sends a fixed-size slot -- entry 0 is a header that carries its candidate count,
+    then its candidates, then zeros -- whose size all ranks derive from the previous step's gathered headers
+    (so they always agree on it).  If a shard outgrows the slot the headers say so on every rank at once and the
+    step is repeated with a bigger slot.  The first step sizes the slot with a count all-gather."""
+
+    def __init__(self, ov, group=None, device: Optional[torch.device] = None, slack: float = 1.25):
+        self.ov = ov
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.ws = dist.get_world_size(group) if self.on else 1
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.slack = slack
+        self.slot = 0          # entries per rank, header included
+        self.local = None      # int32[slot, 4]
+        self.gathered = None   # int32[ws * slot, 4]
+        self.hdr_host = None
+        self.filled = 0
+        self.n_collectives = 0  # (tests look at this)
+
+    def _resize(self, need: int) -> None:
+        self.slot = int(need * self.slack) + 64
+        self.local = torch.zeros((self.slot, 4), dtype=torch.int32, device=self.device)
+        self.filled = 0        # entries of self.local[1:] the last step wrote
+        self.gathered = torch.empty((self.ws * self.slot, 4), dtype=torch.int32, device=self.device)
+        pin = self.device.type == "cuda"
+        self.hdr_host = torch.empty(self.ws, dtype=torch.int32, pin_memory=pin)
+
+    def candidates(self, min_length: int) -> torch.Tensor:
+        """All ranks' verified candidates of one step as ``int32[ws * slot, 4]`` (padding and neutralised headers
+        are all-zero entries, which ``po_expand`` skips)."""
+        res = self.ov.candidates_result(min_length, self.rank, self.ws)
+        try:
+            if not self.on:
+                return _result_to_tensor(res, 4, self.device)
+
+            def fill(dst: torch.Tensor, take: int) -> None:
+                if self.device.type == "cuda":
+                    # device-to-device on the library's stream (synchronised on return); the torch ops of
+                    # _exchange touch other rows of the buffer
+                    res.copy_to_device(dst.data_ptr(), take)
+                else:
+                    dst[:take].copy_(torch.from_numpy(res.rows()[:take].view(np.int32).reshape(-1, 4)))
+
+            return self._exchange(len(res), fill)
+        finally:
+            res.free()
+
+    def exchange_tensor(self, local: torch.Tensor) -> torch.Tensor:
+        """The same exchange for candidates that already sit in a tensor ``int32[n, 4]`` on ``self.device``."""
+        if not self.on:
+            return local
+        return self._exchange(local.shape[0], lambda dst, take: dst[:take].copy_(local[:take]))
+
+    def _exchange(self, n: int, fill) -> torch.Tensor:
+        if self.slot == 0:      # first step: agree on a slot size
+            n_local = torch.tensor([n], dtype=torch.int64, device=self.device)
+            counts = torch.empty(self.ws, dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(counts, n_local, group=self.group)
+            self.n_collectives += 1
+            self._resize(int(counts.max().item()) + 1)
+        while True:
+            take = min(n, self.slot - 1)
+            if take:
+                fill(self.local[1:], take)
+            if take < self.filled:    # the buffer starts out zero: only what the last step wrote beyond has to go
+                self.local[1 + take:1 + self.filled].zero_()
+            self.filled = take
+            self.local[0, 0] = n      # header: how many this rank HAS (may exceed what fits); the other fields stay 0
+            dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
+            self.n_collectives += 1
+            slots = self.gathered.view(self.ws, self.slot, 4)
+            self.hdr_host.copy_(slots[:, 0, 0], non_blocking=True)
+            slots[:, 0, :] = 0        # headers become padding
+            if self.device.type == "cuda":
+                torch.cuda.current_stream(self.device).synchronize()
+            need = int(self.hdr_host.max().item()) + 1
+            if need <= self.slot:     # same headers on every rank: same decision everywhere
+                return self.gathered
+            self._resize(need)        # a shard outgrew the slot: once more with room
+
+    def rows(self, min_length: int):
+        """One full step: the merged rows as an ``OverlapResult`` resident on this rank's GPU."""
+        return expand_candidates(self.ov, self.candidates(min_length))
+
+
 def sharded_overlaps(ov, min_length: int, group=None, device: Optional[torch.device] = None) -> torch.Tensor:
     """Every rank returns the full merged ``int32[n_rows, 6]`` row tensor (on its GPU)."""
     if dist.is_available() and dist.is_initialized():
@@ -108,8 +199,7 @@ def sharded_overlaps(ov, min_length: int, group=None, device: Optional[torch.dev
         rank, ws = 0, 1
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    merged = merge_row_shards(local_shard_candidates(ov, min_length, rank, ws, device), group, keep_padding=True)
-    res = expand_candidates(ov, merged)
+    res = CandidateExchange(ov, group, device).rows(min_length)   # (callers that repeat the step keep the exchange)
     try:
         return _result_to_tensor(res, 6, device)
     finally:

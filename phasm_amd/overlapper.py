@@ -85,8 +85,12 @@ class OverlapResult:
     def device_ptr(self) -> int:
         return int(self._lib.po_result_device_rows(self._ptr) or 0)
 
-    def copy_to_device(self, dst_ptr: int) -> None:
-        _check(self._owner._h, self._lib.po_result_copy_to_device(self._ptr, ctypes.c_void_p(dst_ptr)))
+    def copy_to_device(self, dst_ptr: int, count: Optional[int] = None) -> None:
+        """Device-to-device copy of the first ``count`` entries (default: all) to ``dst_ptr``."""
+        if count is None or count >= len(self):
+            _check(self._owner._h, self._lib.po_result_copy_to_device(self._ptr, ctypes.c_void_p(dst_ptr)))
+        elif count > 0:
+            _check(self._owner._h, self._lib.po_result_copy_prefix_to_device(self._ptr, ctypes.c_void_p(dst_ptr), int(count)))
 
     def free(self) -> None:
         if self._ptr and self._owner._h:

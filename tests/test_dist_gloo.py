@@ -46,6 +46,27 @@ def _worker(rank, world, port, case, q):
         counts = [int(((whole["a_idx"] >= a) & (whole["a_idx"] < b)).sum()) for a, b in (ov.shard_range(r, world) for r in range(world))]
         ok = ok and padded.shape[0] == world * max(counts)
         ok = ok and torch.equal(padded[padded.abs().sum(dim=1) != 0], merged)
+        # the one-collective steady-state exchange (CandidateExchange) on the same rows reinterpreted as 4-column
+        # entries: step 1 sizes the slot (2 collectives), step 2 reuses it (1), a grown shard forces a resize (2)
+        from phasm_amd.dist import CandidateExchange
+        ex = CandidateExchange(ov, device=torch.device("cpu"), slack=1.0)
+        c4 = torch.from_numpy(np.abs(mine.view(np.int32).reshape(-1, 6)[:, :4]).copy() + 1)   # non-zero entries
+        sizes = []
+        for rep, mult in enumerate((1, 1, 3)):
+            local4 = c4.repeat(mult, 1) if rank == 1 else c4
+            before = ex.n_collectives
+            g = ex.exchange_tensor(local4)
+            sizes.append(ex.n_collectives - before)
+            nz = g[g.abs().sum(dim=1) != 0]
+            n_mine = [None, None]
+            cnt = torch.tensor([local4.shape[0]], dtype=torch.int64)
+            allc = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(allc, cnt)
+            ok = ok and nz.shape[0] == int(sum(int(x) for x in allc))
+            lo_ = 0 if rank == 0 else int(allc[0])
+            ok = ok and torch.equal(nz[lo_:lo_ + local4.shape[0]], local4)
+        big = len(mine) > 0
+        ok = ok and sizes[0] == 2 and sizes[1] == 1 and (sizes[2] == 2 if big else sizes[2] in (1, 2))
         q.put((rank, bool(ok), int(len(mine)), int(len(got))))
         ov.close()
     finally:
