@@ -420,3 +420,20 @@ def test_expand_skips_all_zero_padding():
     with pytest.raises(ValueError):
         ov.expand_result(bad.data_ptr(), bad.shape[0])
     ov.close()
+
+
+@pytest.mark.parametrize("name", ["ladder_small", "ladder_varlen", "ladder_cfg2_mini", "cfg2_1k"])
+def test_verify_locality_order_forced_on_small_sets(name, monkeypatch):
+    """The locality order of the verify grid (label, LDS counting sort, XCD-aware mapping) normally switches on
+    only for big calls; forced on here so that the goldens also cover it -- with both index flavours and with
+    the mirror shortcut off (labels are then plain indices)."""
+    _, seqs, m, want = gu.ladder_case(name)
+    monkeypatch.setenv("PHASM_VERIFY_ORDER", "1")
+    got, _ = hip_rows(seqs, m)
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("PHASM_INDEX", "wide")
+    got, st = hip_rows(seqs, m)
+    assert st["wide_index"] == 1 and np.array_equal(got, want)
+    monkeypatch.setenv("PHASM_NO_MIRROR", "1")
+    got, st = hip_rows(seqs, m)
+    assert st["paired"] == 0 and np.array_equal(got, want)
