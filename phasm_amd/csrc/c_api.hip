@@ -681,7 +681,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         {
             // a's words live in LDS (read length + 3 guard words); reads too long for 64 KB use the global path
             const uint64_t need_words = ((uint64_t)h->max_len + W - 1) / W + 3;
-            const uint32_t lds_words = (uint32_t)std::min<uint64_t>(need_words, 8192);
+            const uint32_t lds_words_raw = (uint32_t)std::min<uint64_t>(need_words, 8192 - 1100);  // (room for the records in 64 KB)
             // locality order of the a-side reads (k_read_label): worth its ~50 us only when the verify is long
             const uint32_t n_a = r_end - r_begin;
             const uint32_t* perm = nullptr;
@@ -720,8 +720,16 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                 perm = h->d_vperm.as<uint32_t>();
             }
             const uint32_t ver_grid = perm ? 8 * ((n_a + 7) / 8) : n_a;
-            auto verify = paired == 2u ? po::k_verify_a<BITS, true> : po::k_verify_a<BITS, false>;
-            hipLaunchKernelGGL(verify, dim3(ver_grid), dim3(po::VER_BLOCK), (size_t)lds_words * 8, st,
+            // candidate records staged in LDS (word offsets must fit 32 bits); PHASM_VERIFY_STAGED=0 switches back
+            bool staged = h->words.size() + 72 < 0xFFFFFFF0ull;
+            if (const char* e = getenv("PHASM_VERIFY_STAGED")) staged = staged && atoi(e) != 0;
+            auto verify = paired == 2u ? (staged ? po::k_verify_a<BITS, true, true> : po::k_verify_a<BITS, true, false>)
+                                       : (staged ? po::k_verify_a<BITS, false, true> : po::k_verify_a<BITS, false, false>);
+            const uint32_t lds_words = (lds_words_raw + 1u) & ~1u;  // even: the records behind a sit on a 16-byte boundary
+            const size_t ver_lds = (size_t)lds_words * 8 + (size_t)po::VREC_CAP * sizeof(po::VRec) + 16;
+            if (ver_lds > 48 * 1024)
+                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(verify), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ver_lds));
+            hipLaunchKernelGGL(verify, dim3(ver_grid), dim3(po::VER_BLOCK), ver_lds, st,
                                words, woff, len, h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_p,
                                A.cand_b, r_begin, lds_words, paired,
                                h->n_exc_uploaded ? h->d_exc_off.as<uint32_t>() : nullptr, h->d_exc_pos.as<uint32_t>(),

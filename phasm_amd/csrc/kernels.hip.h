@@ -1186,14 +1186,24 @@ __device__ unsigned long long g_vstamps[64 * 8];
 // The compare loop of k_verify_a, compiled once for a in LDS and once for a in global memory (reads too long
 // for LDS).  With one body the compiler folds the two a-pointers into a generic pointer: five flat_load_dword
 // and ten 64-bit address instructions per 256-byte block instead of five ds_read_b32 off one 32-bit address.
-template <int BITS, bool SCRAMBLED, bool IN_LDS>
+// STAGED: the records {p, b, len[b], first word of b} of a read's candidates are put into LDS by the whole
+// workgroup while a is staged, so that a group starting a candidate reads one 16-byte record instead of running
+// a two-deep prefetch of four dependent global loads (the start/finish code is half of this kernel's
+// instructions, and the kernel is issue bound).
+constexpr int VREC_CAP = 512;  // records per staging batch (8 KB of LDS)
+struct __attribute__((aligned(16))) VRec {
+    uint32_t p, b, lb, wo;  // wo = first 64-bit word of b in words[] (the host checks that it fits 32 bits)
+};
+
+template <int BITS, bool SCRAMBLED, bool IN_LDS, bool STAGED>
 __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
                                            const uint32_t* __restrict__ len, const uint32_t* __restrict__ cand_p,
                                            const uint32_t* __restrict__ cand_b, uint32_t paired,
                                            const uint32_t* __restrict__ exc_off, const uint32_t* __restrict__ exc_pos,
                                            const uint8_t* __restrict__ exc_byte, uint8_t* __restrict__ type,
                                            const uint32_t* __restrict__ s_a, const uint32_t* __restrict__ ga32,
-                                           uint32_t* s_next, uint32_t a, uint32_t la, uint32_t seg0, uint32_t seg1
+                                           const VRec* __restrict__ s_rec, uint32_t* s_next, uint32_t a, uint32_t la,
+                                           uint32_t seg0, uint32_t seg1
                                            VST(, unsigned long long vt_start, unsigned long long (&vt)[8])) {
     constexpr int W = 64 / BITS;
     (void)W;
@@ -1223,9 +1233,9 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
     // new candidate has (p, b, len[b], woff[b]) in registers already: m0 = the next candidate to
     // start (complete), m1 = the one after (p, b only; its len/woff are requested when it moves up).
     const uint32_t c_last = seg1 - 1;
-    uint32_t m0p, m0b, m0l, m1p, m1b;
-    uint64_t m0w;
-    {
+    uint32_t m0p = 0, m0b = 0, m0l = 0, m1p = 0, m1b = 0;
+    uint64_t m0w = 0;
+    if constexpr (!STAGED) {
         const uint32_t c0 = min(cA, c_last), c1 = min(cB, c_last);
         m0p = cand_p[c0];
         m0b = cand_b[c0];
@@ -1235,21 +1245,38 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
         m0w = woff[m0b];
     }
     auto init = [&]() __attribute__((always_inline)) {
-        const uint32_t p = m0p, b = m0b, lb = m0l;
-        const uint64_t wo = m0w;
-        // advance the look-ahead: requests only, nothing here is needed before the next candidate
-        c = cA;
-        cA = cB;
-        m0p = m1p;
-        m0b = m1b;
-        m0l = len[m1b];
-        m0w = woff[m1b];
-        uint32_t drawn = 0;
-        if (sub == 0) drawn = atomicAdd(s_next, 1u);
-        cB = __shfl(drawn, (int)gshift);  // lane 0 of the group drew for all 16
-        const uint32_t c2 = min(cB, c_last);
-        m1p = cand_p[c2];
-        m1b = cand_b[c2];
+        uint32_t p, b, lb;
+        uint64_t wo;
+        if constexpr (STAGED) {
+            // (seg0 .. seg1 is the staged batch; s_next hands out absolute candidate indices)
+            c = cA;
+            const VRec r = s_rec[c - seg0];
+            p = r.p;
+            b = r.b;
+            lb = r.lb;
+            wo = r.wo;
+            uint32_t drawn = 0;
+            if (sub == 0) drawn = atomicAdd(s_next, 1u);
+            cA = __shfl(drawn, (int)gshift);  // lane 0 of the group drew for all 16
+        } else {
+            p = m0p;
+            b = m0b;
+            lb = m0l;
+            wo = m0w;
+            // advance the look-ahead: requests only, nothing here is needed before the next candidate
+            c = cA;
+            cA = cB;
+            m0p = m1p;
+            m0b = m1b;
+            m0l = len[m1b];
+            m0w = woff[m1b];
+            uint32_t drawn = 0;
+            if (sub == 0) drawn = atomicAdd(s_next, 1u);
+            cB = __shfl(drawn, (int)gshift);  // lane 0 of the group drew for all 16
+            const uint32_t c2 = min(cB, c_last);
+            m1p = cand_p[c2];
+            m1b = cand_b[c2];
+        }
         const uint32_t rem = la - p;
         cur_p = p;
         cur_b = b;
@@ -1337,7 +1364,7 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
     })
 }
 
-template <int BITS, bool SCRAMBLED>
+template <int BITS, bool SCRAMBLED, bool STAGED>
 __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
                                                          const uint32_t* __restrict__ len,
                                                          const uint32_t* __restrict__ read_tile0,
@@ -1351,7 +1378,7 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
                                                          uint8_t* __restrict__ type,
                                                          const uint32_t* __restrict__ perm, uint32_t n_a) {
     constexpr int W = 64 / BITS;
-    extern __shared__ uint64_t s_a64[];
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_a64[];
     VST(const unsigned long long vt_start = __builtin_amdgcn_s_memtime(); unsigned long long vt[8] = {};)
     uint32_t a = r_begin + blockIdx.x;
     if (perm) {
@@ -1370,20 +1397,43 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
     const uint32_t nwa = (la + W - 1) / W;
     const uint64_t* __restrict__ ga = words + woff[a];
     const bool in_lds = nwa + 3 <= lds_words;  // workgroup-uniform
-    // candidates are handed out dynamically: the first two per group by position, the rest from this counter
-    __shared__ uint32_t s_next;
-    if (threadIdx.x == 0) s_next = seg0 + 2 * (VER_BLOCK / VER_GROUP);
+    // dynamic LDS only (a static variable would move its base off the 16-byte boundary the records need):
+    // lds_words (even) words of a, VREC_CAP candidate records, the draw counter
+    VRec* s_rec = reinterpret_cast<VRec*>(s_a64 + lds_words);
+    uint32_t* s_next = reinterpret_cast<uint32_t*>(s_rec + VREC_CAP);
+    constexpr uint32_t NGROUPS = VER_BLOCK / VER_GROUP;
     if (in_lds)
         for (uint32_t i = threadIdx.x; i < nwa + 3; i += VER_BLOCK) s_a64[i] = ga[i];
-    __syncthreads();
     const uint32_t* __restrict__ s_a = reinterpret_cast<const uint32_t*>(s_a64);
     const uint32_t* __restrict__ ga32 = reinterpret_cast<const uint32_t*>(ga);
-    if (in_lds)
-        verify_run<BITS, SCRAMBLED, true>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type, s_a, ga32,
-                                          &s_next, a, la, seg0, seg1 VST(, vt_start, vt));
-    else
-        verify_run<BITS, SCRAMBLED, false>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type, s_a, ga32,
-                                           &s_next, a, la, seg0, seg1 VST(, vt_start, vt));
+    if constexpr (STAGED) {
+        for (uint32_t batch0 = seg0; batch0 < seg1; batch0 += VREC_CAP) {
+            const uint32_t nb = min((uint32_t)VREC_CAP, seg1 - batch0);
+            if (batch0 != seg0) __syncthreads();  // every group is done with the previous batch's records
+            for (uint32_t i = threadIdx.x; i < nb; i += VER_BLOCK) {
+                const uint32_t p = cand_p[batch0 + i], b = cand_b[batch0 + i];
+                s_rec[i] = VRec{p, b, len[b], (uint32_t)woff[b]};
+            }
+            if (threadIdx.x == 0) *s_next = batch0 + NGROUPS;  // the first candidate of every group is its position
+            __syncthreads();
+            if (in_lds)
+                verify_run<BITS, SCRAMBLED, true, true>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type,
+                                                        s_a, ga32, s_rec, s_next, a, la, batch0, batch0 + nb VST(, vt_start, vt));
+            else
+                verify_run<BITS, SCRAMBLED, false, true>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type,
+                                                         s_a, ga32, s_rec, s_next, a, la, batch0, batch0 + nb VST(, vt_start, vt));
+        }
+    } else {
+        // candidates are handed out dynamically: the first two per group by position, the rest from this counter
+        if (threadIdx.x == 0) *s_next = seg0 + 2 * NGROUPS;
+        __syncthreads();
+        if (in_lds)
+            verify_run<BITS, SCRAMBLED, true, false>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type,
+                                                     s_a, ga32, s_rec, s_next, a, la, seg0, seg1 VST(, vt_start, vt));
+        else
+            verify_run<BITS, SCRAMBLED, false, false>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type,
+                                                      s_a, ga32, s_rec, s_next, a, la, seg0, seg1 VST(, vt_start, vt));
+    }
 }
 
 // ----------------------------------------------------------------------------------------
