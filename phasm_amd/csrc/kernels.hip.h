@@ -1192,7 +1192,10 @@ __device__ unsigned long long g_vstamps[64 * 8];
 // instructions, and the kernel is issue bound).
 constexpr int VREC_CAP = 512;  // records per staging batch (8 KB of LDS)
 struct __attribute__((aligned(16))) VRec {
-    uint32_t p, b, lb, wo;  // wo = first 64-bit word of b in words[] (the host checks that it fits 32 bits)
+    uint32_t pk;  // p | (keep & 1) << 31        p, n < 2^31: the top bits carry `keep` (which rows the candidate can
+    uint32_t b;   //                             give, keep_bits) -- worked out once by the staging thread instead of by
+    uint32_t nk;  // n | (keep >> 1) << 31       every wave whose group starts the candidate; n = min(la - p, len[b])
+    uint32_t wo;  // first 64-bit word of b in words[] (the host checks that it fits 32 bits)
 };
 
 template <int BITS, bool SCRAMBLED, bool IN_LDS, bool STAGED>
@@ -1251,9 +1254,9 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
             // (seg0 .. seg1 is the staged batch; s_next hands out absolute candidate indices)
             c = cA;
             const VRec r = s_rec[c - seg0];
-            p = r.p;
+            p = r.pk;   // (packed: see VRec)
             b = r.b;
-            lb = r.lb;
+            lb = r.nk;
             wo = r.wo;
             uint32_t drawn = 0;
             if (sub == 0) drawn = atomicAdd(s_next, 1u);
@@ -1277,12 +1280,18 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
             m1p = cand_p[c2];
             m1b = cand_b[c2];
         }
-        const uint32_t rem = la - p;
+        if constexpr (STAGED) {
+            keep = (p >> 31) | ((lb >> 31) << 1);
+            p &= 0x7FFFFFFFu;
+            nbits = (lb & 0x7FFFFFFFu) * BITS;
+        } else {
+            const uint32_t rem = la - p;
+            keep = keep_bits(a, b, rem, lb, SCRAMBLED ? 2u : (paired ? 1u : 0u));
+            const uint32_t n = rem < lb ? rem : lb;
+            nbits = keep ? n * BITS : 0;
+        }
         cur_p = p;
         cur_b = b;
-        keep = keep_bits(a, b, rem, lb, SCRAMBLED ? 2u : (paired ? 1u : 0u));
-        const uint32_t n = rem < lb ? rem : lb;
-        nbits = keep ? n * BITS : 0;
         const uint64_t bitpos = (uint64_t)p * BITS;
         q = (uint32_t)(bitpos >> 5);
         sh = (uint32_t)(bitpos & 31);
@@ -1412,7 +1421,10 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
             if (batch0 != seg0) __syncthreads();  // every group is done with the previous batch's records
             for (uint32_t i = threadIdx.x; i < nb; i += VER_BLOCK) {
                 const uint32_t p = cand_p[batch0 + i], b = cand_b[batch0 + i];
-                s_rec[i] = VRec{p, b, len[b], (uint32_t)woff[b]};
+                const uint32_t lb = len[b], rem = la - p;
+                const uint32_t keep = keep_bits(a, b, rem, lb, SCRAMBLED ? 2u : (paired ? 1u : 0u));
+                const uint32_t n = rem < lb ? rem : lb;
+                s_rec[i] = VRec{p | ((keep & 1u) << 31), b, keep ? (n | ((keep >> 1) << 31)) : 0u, (uint32_t)woff[b]};
             }
             if (threadIdx.x == 0) *s_next = batch0 + NGROUPS;  // the first candidate of every group is its position
             __syncthreads();
