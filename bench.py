@@ -184,7 +184,7 @@ def main() -> int:
     m = args.min_length
 
     exchange = CandidateExchange(ov, device=merge_device) if (world > 1 or args.dist_path) else None
-    stage_keys = ["ms_index", "ms_scan_count", "ms_scan_fill", "ms_verify", "ms_select", "ms_emit", "ms_total"]
+    stage_keys = ["ms_index", "ms_scan_count", "ms_scan_fill", "ms_verify", "ms_select", "ms_emit", "ms_total", "ms_scan_probe"]
     acc = {k: 0.0 for k in stage_keys}
     last = {}
 
@@ -262,20 +262,50 @@ def main() -> int:
             "candidates_per_step": int(last["n_candidates"]),
             "stage_ms": {k: round(v, 4) for k, v in avg.items()},
             "load_seconds": round(t_load, 1),
-            "roofline": {"bound": "hbm", "kernel": "k_verify_a<%d, %s>" % (last["bits_per_base"], "true" if world > 1 else "false"),
-                         "achieved": ver_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ver_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": int(ver_bytes),
-                         "avg_launch_ms": avg["ms_verify"],
-                         "job_achieved": job_gbs, "job_frac": job_gbs / HBM_PEAK_GBS,
-                         "job_algorithmic_bytes": int(job_bytes)},
         }
-        # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes on the same
-        # workload (profiles/r01_v2_pmc.md); it cannot be read from inside this process
+        # The two kernels that make up three quarters of a step, each against the HBM roofline with its share of
+        # SURVEY.md section 8d's algorithmic bytes: the scan streams the packed reads once (B * bits / 8), the verify
+        # carries both sides of every emitted overlap (sum 2 * ceil(l * bits / 8)).  `roofline` itself is the one with
+        # the longer launch, as the contract asks; both are VALU-issue bound, not HBM bound.
+        bits = last["bits_per_base"]
+        scan_bytes = last["shard_bases"] * bits // 8
+        sharded = "true" if world > 1 else "false"
+        kern = {
+            ("k_wide_scan<%d, false>" % bits) if last["wide_index"] else ("k_scan_probe<%d, true>" % bits): {
+                "algorithmic_bytes_per_launch": int(scan_bytes), "avg_launch_ms": avg["ms_scan_probe"]},
+            "k_verify_a<%d, %s, true>" % (bits, sharded): {
+                "algorithmic_bytes_per_launch": int(ver_bytes), "avg_launch_ms": avg["ms_verify"],
+                "note": "stage time: the kernel plus ~0.04 ms of ordering kernels (label, sort, invert)"},
+        }
+        for v in kern.values():
+            v["achieved"] = v["algorithmic_bytes_per_launch"] / (v["avg_launch_ms"] * 1e-3) / 1e9 if v["avg_launch_ms"] > 0 else 0.0
+            v["frac"] = v["achieved"] / HBM_PEAK_GBS
+            v["traffic"] = None
+        dom = max(kern, key=lambda k: kern[k]["avg_launch_ms"])
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": kern[dom]["frac"], "traffic": None,
+                           "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes_per_launch"],
+                           "avg_launch_ms": kern[dom]["avg_launch_ms"],
+                           "actual_bound": "VALU issue (integer compare / bit tests), see DESIGN.md 3.3 and 3.5",
+                           "kernels": kern,
+                           "job_achieved": job_gbs, "job_frac": job_gbs / HBM_PEAK_GBS,
+                           "job_algorithmic_bytes": int(job_bytes)}
+        # HBM-side traffic comes from separate rocprofv3 --pmc passes on the same workload (profiles/r01_v6_pmc.md,
+        # profiles/traffic.json); it cannot be read from inside this process
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 tr = json.load(f).get(args.config, {}) if not args.reads and world == 1 else {}
-            out["roofline"]["traffic"] = tr.get("k_verify_a<%d, false>" % last["bits_per_base"])
+            for k, v in kern.items():
+                v["traffic"] = tr.get(k)
+            out["roofline"]["traffic"] = kern[dom]["traffic"]
+            # issue-side view of the same kernels: VALU instructions (SQ counters, same passes) x 4 cycles on a
+            # 16-lane SIMD, against 1024 SIMDs x 2.4 GHz over the launch measured here
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                vi = json.load(f).get(args.config + "_valu_wave_insts", {}) if not args.reads and world == 1 else {}
+            for k, v in kern.items():
+                if k in vi and v["avg_launch_ms"] > 0:
+                    v["valu_utilisation"] = vi[k] * 4.0 / (1024 * 2.4e9 * v["avg_launch_ms"] * 1e-3)
+            out["roofline"]["valu_utilisation"] = kern[dom].get("valu_utilisation")
         except (OSError, ValueError):
             pass
         if world == 1:

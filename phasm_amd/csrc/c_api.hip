@@ -35,7 +35,7 @@ struct DevBuf {
     }
 };
 
-enum { EV_START = 0, EV_INDEX, EV_COUNT, EV_FILL, EV_VERIFY, EV_SELECT, EV_EMIT, EV_N };
+enum { EV_START = 0, EV_INDEX, EV_COUNT, EV_FILL, EV_VERIFY, EV_SELECT, EV_EMIT, EV_PROBE0, EV_PROBE1, EV_N };
 
 }  // namespace
 
@@ -595,7 +595,9 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     WA.lane_slot = A.truemask;
     WA.tile_off = A.tile_off;
     if (wide) {
+        HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE0], st));
         hipLaunchKernelGGL((po::k_wide_scan<BITS, false>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA);
+        HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
     } else {
         const size_t scan_lds = (size_t)scan_waves * po::SCAN_LDS_PER_WAVE + bloom_bytes;
         if (scan_lds > h->lds_max) return fail(h, PO_ERR_HIP, "device LDS too small for the scan kernel");
@@ -612,10 +614,12 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         A.left = h->d_left.as<uint2>();
         A.left_cnt = h->d_left_cnt.as<uint32_t>();
         A.tile_extra = h->d_tile_extra.as<uint32_t>();
+        HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE0], st));
         if (K == W)
             hipLaunchKernelGGL((po::k_scan_probe<BITS, true>), dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
         else
             hipLaunchKernelGGL((po::k_scan_probe<BITS, false>), dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
+        HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
         hipLaunchKernelGGL((po::k_scan_fixup<BITS>), dim3(n_scan_waves), dim3(64), 0, st, A, n_scan_waves);
         hipLaunchKernelGGL(po::k_add_extra, dim3(cdiv(ntiles, 256)), dim3(256), 0, st, A.tile_count, A.tile_extra, tile_begin,
                            tile_end);
@@ -847,6 +851,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     (void)hipEventElapsedTime(&S.ms_select, h->ev[EV_VERIFY], h->ev[EV_SELECT]);
     (void)hipEventElapsedTime(&S.ms_emit, h->ev[EV_SELECT], h->ev[EV_EMIT]);
     (void)hipEventElapsedTime(&S.ms_total, h->ev[EV_START], h->ev[EV_EMIT]);
+    (void)hipEventElapsedTime(&S.ms_scan_probe, h->ev[EV_PROBE0], h->ev[EV_PROBE1]);
     return PO_OK;
 }
 
