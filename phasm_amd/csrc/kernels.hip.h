@@ -584,7 +584,12 @@ __device__ inline uint32_t filter_tile(const uint32_t* __restrict__ s_bloom, uin
         for (int s = 0; s < 32; ++s) {
             const uint32_t t1 = T[s] & klo, t2 = T[s + 16] & khi;
             // byte offset of the block = ((t1 >> 5) & bmask) * 8; the filter sits at LDS offset 0
-            const uint2 blk = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_bloom) + ((t1 >> 2) & amask));
+            // the filter is the first thing in the kernel's LDS (offset 0, no static LDS in k_scan_probe): the byte
+            // offset IS the LDS address -- spelled as an address-space-3 pointer so that the compiler does not add
+            // the (relocatable, zero) base to it, one VALU instruction per position
+            typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+            typedef const u32x2 __attribute__((address_space(3))) lds_u32x2;
+            const u32x2 blk = *reinterpret_cast<lds_u32x2*>((uintptr_t)((t1 >> 2) & amask));
             hitmask |= ((blk.x >> (t1 & 31)) & (blk.x >> ((t1 >> 19) & 31)) & (blk.y >> (t2 & 31)) & 1u) << s;
         }
     } else {
