@@ -945,7 +945,10 @@ __global__ void k_add_extra(uint32_t* __restrict__ tile_count, const uint32_t* _
 // candidate ranges (tile_off is a running sum), so the wave writes one contiguous range starting at
 // tile_off[first tile]; pooling the hits of several tiles fills the 64-entry probe rounds and turns
 // four short latency chains into one.
-constexpr int FILL_TILES = 4;
+#ifndef PO_FILL_TILES
+#define PO_FILL_TILES 4
+#endif
+constexpr int FILL_TILES = PO_FILL_TILES;
 
 template <int BITS>
 __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
