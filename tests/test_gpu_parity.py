@@ -437,3 +437,21 @@ def test_verify_locality_order_forced_on_small_sets(name, monkeypatch):
     monkeypatch.setenv("PHASM_NO_MIRROR", "1")
     got, st = hip_rows(seqs, m)
     assert st["paired"] == 0 and np.array_equal(got, want)
+
+
+@pytest.mark.skipif(not oo.have_reference(), reason="oracle/_ref/ref_overlapper not built (make -C oracle ref)")
+def test_live_against_the_reference_binary_on_fresh_data():
+    """Beyond the committed goldens: the compiled reference itself (oracle/_ref, it travels with the repository
+    snapshot) on read sets it has not been run on before -- config-2 density and a variable-length diploid set
+    with containments -- against the HIP rows, whole-set and as three shards."""
+    cases = [(synth.SynthConfig(**{**synth.scaled(synth.CONFIGS["cfg2"], 700).__dict__, "seed": 4242}), 1000),
+             (synth.SynthConfig(n_reads=500, read_len=6000, genome_len=150_000, ploidy=2, snp=0.004, seed=909,
+                                len_sd=2500.0, len_min=800, len_max=15000), 600)]
+    for cfg, m in cases:
+        seqs = [s for _, s in synth.oriented(synth.generate_reads(cfg))]
+        want, secs, nrows = oo.reference_overlaps(seqs, m)
+        assert nrows == len(want) > 1000
+        got, st = hip_rows(seqs, m)
+        assert np.array_equal(got, want)
+        got3, _ = hip_rows(seqs, m, shard=3)
+        assert np.array_equal(got3, want)
