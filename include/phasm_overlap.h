@@ -136,6 +136,11 @@ typedef struct {
 } po_cand;
 po_status po_candidates_shard(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, po_result** out);
 po_status po_expand(po_handle* h, const void* candidates_device, uint64_t n_candidates, po_result** out);
+/* po_candidates_shard with the destination supplied: when the shard's candidates fit `capacity` entries they are
+ * written straight to dst_device (e.g. this rank's slot of the exchange buffer; *written = 1, the result carries
+ * the count and points at dst_device); otherwise *written = 0 and the result holds them as usual. */
+po_status po_candidates_shard_into(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards,
+                                   void* dst_device, uint64_t capacity, int* written, po_result** out);
 
 /* The read-index range [*r_begin, *r_end) that po_overlaps_shard(shard, nshards) scans on the
  * a-side.  Pure host logic (no GPU needed). */

@@ -82,6 +82,8 @@ SYMBOLS = [
     ("po_overlaps_shard", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_candidates_shard", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_expand", ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(_P)]),
+    ("po_candidates_shard_into", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                               ctypes.c_uint64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_P)]),
     ("po_shard_range", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
     ("po_result_count", ctypes.c_uint64, [_P]),
     ("po_result_rows", ctypes.c_void_p, [_P]),

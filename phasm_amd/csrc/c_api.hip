@@ -100,6 +100,10 @@ struct po_result {
     size_t elem = sizeof(po_row);
     bool kind_edges = false;  // po_edge entries (same size as po_cand)
     void* host = nullptr;
+    // po_candidates_shard_into: the caller's buffer the candidates go to when they fit
+    void* ext_dst = nullptr;
+    uint64_t ext_cap = 0;
+    bool wrote_ext = false;
 };
 
 namespace {
@@ -805,14 +809,20 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
             HIP_TRY(h, hipStreamSynchronize(st));
             const uint64_t n_ver = h->pinned[3];
-            if (h->spare_cands.p && h->spare_cands.cap >= n_ver * sizeof(po::Cand)) {
-                res->d_rows = h->spare_cands;
-                h->spare_cands = DevBuf();
+            po::Cand* dst;
+            if (res->ext_dst && n_ver <= res->ext_cap) {
+                dst = static_cast<po::Cand*>(res->ext_dst);  // straight into the caller's exchange buffer
+                res->wrote_ext = true;
+            } else {
+                if (h->spare_cands.p && h->spare_cands.cap >= n_ver * sizeof(po::Cand)) {
+                    res->d_rows = h->spare_cands;
+                    h->spare_cands = DevBuf();
+                }
+                PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_ver * sizeof(po::Cand), 256)));
+                dst = res->d_rows.as<po::Cand>();
             }
-            PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_ver * sizeof(po::Cand), 256)));
             hipLaunchKernelGGL(po::k_compact, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_p, A.cand_b,
-                               h->d_type.as<uint8_t>(), h->d_flag.as<uint8_t>(), h->d_row_off.as<uint32_t>(), n_cand,
-                               res->d_rows.as<po::Cand>());
+                               h->d_type.as<uint8_t>(), h->d_flag.as<uint8_t>(), h->d_row_off.as<uint32_t>(), n_cand, dst);
             HIP_TRY(h, hipGetLastError());
             res->elem = sizeof(po::Cand);
             n_rows64 = n_ver;
@@ -1294,7 +1304,7 @@ po_status po_upload(po_handle* h) {
 }
 
 static po_status overlaps_common(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, bool want_cands,
-                                 po_result** out) {
+                                 po_result** out, void* ext_dst = nullptr, uint64_t ext_cap = 0) {
     if (!h || !out) return PO_ERR_INVALID;
     *out = nullptr;
     if (nshards == 0 || shard >= nshards) return fail(h, PO_ERR_INVALID, "shard must be < nshards");
@@ -1302,6 +1312,8 @@ static po_status overlaps_common(po_handle* h, uint32_t min_length, uint32_t sha
     po_result* r = new (std::nothrow) po_result();
     if (!r) return fail(h, PO_ERR_NOMEM, "out of host memory");
     r->h = h;
+    r->ext_dst = ext_dst;
+    r->ext_cap = ext_cap;
     po_status st;
     try {
         st = upload(h);
@@ -1327,6 +1339,15 @@ po_status po_overlaps_shard(po_handle* h, uint32_t min_length, uint32_t shard, u
 
 po_status po_candidates_shard(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, po_result** out) {
     return overlaps_common(h, min_length, shard, nshards, true, out);
+}
+
+po_status po_candidates_shard_into(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, void* dst_device,
+                                   uint64_t capacity, int* written, po_result** out) {
+    if (written) *written = 0;
+    if (!dst_device && capacity) return PO_ERR_INVALID;
+    const po_status st = overlaps_common(h, min_length, shard, nshards, true, out, dst_device, capacity);
+    if (st == PO_OK && written) *written = (*out)->wrote_ext ? 1 : 0;
+    return st;
 }
 
 po_status po_expand(po_handle* h, const void* candidates_device, uint64_t n_candidates, po_result** out) {
@@ -1372,6 +1393,20 @@ uint64_t po_result_count(const po_result* r) { return r ? r->count : 0; }
 
 const po_row* po_result_rows(po_result* r) {
     if (!r) return nullptr;
+    if (r->wrote_ext && !r->host) {  // the entries live in the caller's buffer: copy them back from there
+        po_handle* h = r->h;
+        if (r->count == 0) return nullptr;
+        r->host = std::malloc(r->count * r->elem);
+        if (!r->host) return nullptr;
+        (void)hipSetDevice(h->device);
+        hipError_t e = hipMemcpyAsync(r->host, r->ext_dst, r->count * r->elem, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) {
+            std::free(r->host);
+            r->host = nullptr;
+        }
+        return static_cast<const po_row*>(r->host);
+    }
     if (r->host || r->count == 0) return static_cast<const po_row*>(r->host);
     po_handle* h = r->h;
     r->host = std::malloc(r->count * r->elem);
@@ -1390,7 +1425,7 @@ const po_row* po_result_rows(po_result* r) {
     return static_cast<const po_row*>(r->host);
 }
 
-const void* po_result_device_rows(const po_result* r) { return r ? r->d_rows.p : nullptr; }
+const void* po_result_device_rows(const po_result* r) { return r ? (r->wrote_ext ? r->ext_dst : r->d_rows.p) : nullptr; }
 
 po_status po_result_copy_to_device(po_result* r, void* dst_device) {
     if (!r || (!dst_device && r->count)) return PO_ERR_INVALID;

@@ -126,9 +126,14 @@ class CandidateExchange:
         self.n_collectives = 0  # (tests look at this)
 
     def _resize(self, need: int) -> None:
-        self.slot = int(need * self.slack) + 64
+        old, old_filled = self.local, self.filled
+        self.slot = max(int(need * self.slack) + 64, self.slot)
         self.local = torch.zeros((self.slot, 4), dtype=torch.int32, device=self.device)
         self.filled = 0        # entries of self.local[1:] the last step wrote
+        if old is not None and old_filled:
+            # a bigger slot in the middle of a step: what this rank already put into its slot moves along
+            self.local[1:1 + old_filled].copy_(old[1:1 + old_filled])
+            self.filled = old_filled
         self.gathered = torch.empty((self.ws * self.slot, 4), dtype=torch.int32, device=self.device)
         pin = self.device.type == "cuda"
         self.hdr_host = torch.empty(self.ws, dtype=torch.int32, pin_memory=pin)
@@ -136,12 +141,20 @@ class CandidateExchange:
     def candidates(self, min_length: int) -> torch.Tensor:
         """All ranks' verified candidates of one step as ``int32[ws * slot, 4]`` (padding and neutralised headers
         are all-zero entries, which ``po_expand`` skips)."""
-        res = self.ov.candidates_result(min_length, self.rank, self.ws)
+        written = False
+        if self.on and self.slot and self.device.type == "cuda":
+            # steady state: the compaction kernel writes this rank's candidates straight into its slot
+            res, written = self.ov.candidates_result_into(min_length, self.rank, self.ws, self.local.data_ptr() + 16,
+                                                          self.slot - 1)
+        else:
+            res = self.ov.candidates_result(min_length, self.rank, self.ws)
         try:
             if not self.on:
                 return _result_to_tensor(res, 4, self.device)
 
             def fill(dst: torch.Tensor, take: int) -> None:
+                if written:
+                    return
                 if self.device.type == "cuda":
                     # device-to-device on the library's stream (synchronised on return); the torch ops of
                     # _exchange touch other rows of the buffer

@@ -160,6 +160,15 @@ class ExactOverlapper:
         _check(self._h, self._lib.po_candidates_shard(self._h, m, int(shard), int(nshards), ctypes.byref(r)))
         return OverlapResult(self, r, CAND_DTYPE)
 
+    def candidates_result_into(self, min_length: int, shard: int, nshards: int, dst_ptr: int, capacity: int):
+        """``po_candidates_shard_into``: (result, written) -- the candidates go straight to ``dst_ptr`` when they fit."""
+        m = self._min_length(min_length)
+        r = ctypes.c_void_p()
+        w = ctypes.c_int()
+        _check(self._h, self._lib.po_candidates_shard_into(self._h, m, int(shard), int(nshards), ctypes.c_void_p(dst_ptr),
+                                                           int(capacity), ctypes.byref(w), ctypes.byref(r)))
+        return OverlapResult(self, r, CAND_DTYPE), bool(w.value)
+
     def expand_result(self, cand_device_ptr: int, n_candidates: int) -> OverlapResult:
         """Rows from a candidate array resident on this handle's device (``po_expand``)."""
         r = ctypes.c_void_p()

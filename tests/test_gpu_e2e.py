@@ -93,6 +93,18 @@ def test_rccl_collectives_one_rank_group():
         whole = ov.overlaps_array(m)
         assert np.array_equal(rows_tensor_to_struct(t), whole)
         assert np.array_equal(oo.sort_rows(oo.struct_to_rows(whole)), want)
+        # the repeated-step form: first step sizes the slot (a stricter min_length: fewer candidates), the second
+        # outgrows it (slot grows in the middle of the step), the third and fourth write straight into the slot
+        from phasm_amd.dist import CandidateExchange
+        ex = CandidateExchange(ov, device=dev, slack=1.0)
+        r0 = ex.rows(4 * m)
+        assert len(r0) < len(whole)
+        r0.free()
+        for _ in range(3):
+            r = ex.rows(m)
+            assert np.array_equal(r.rows(), whole)
+            r.free()
+        assert ex.n_collectives == 2 + 2 + 1 + 1
         ov.close()
     finally:
         dist.destroy_process_group()
