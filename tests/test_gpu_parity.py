@@ -455,3 +455,36 @@ def test_live_against_the_reference_binary_on_fresh_data():
         assert np.array_equal(got, want)
         got3, _ = hip_rows(seqs, m, shard=3)
         assert np.array_equal(got3, want)
+
+
+def test_many_identical_and_nested_reads():
+    """Chains of many reads behind one prefix K-mer: 60 copies of one read, 40 of another that is a prefix of the
+    first, plus suffix / infix variants -- every ordered pair overlaps or contains, four rows per identical pair
+    (SURVEY.md section 8a-2).  Narrow and wide index, whole-set and sharded, with and without reverse strands."""
+    rng = np.random.default_rng(123)
+    base = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=1500))
+    reads = [base] * 60 + [base[:900]] * 40 + [base[300:]] * 25 + [base[200:1100]] * 25 + [base[:64]] * 10
+    rc = bytes.maketrans(b"ACGT", b"TGCA")
+    both = []
+    for r in reads[::3]:
+        both += [r, r.translate(rc)[::-1]]
+    for seqs in (reads, both):
+        for m in (64, 500):
+            want = oo.oracle_overlaps(seqs, m)
+            assert len(want) > 5000
+            got, st = hip_rows(seqs, m)
+            assert np.array_equal(got, want), (len(seqs), m, "whole")
+            got, _ = hip_rows(seqs, m, shard=4)
+            assert np.array_equal(got, want), (len(seqs), m, "4 shards")
+
+
+def test_many_identical_reads_wide_index(monkeypatch):
+    monkeypatch.setenv("PHASM_INDEX", "wide")
+    rng = np.random.default_rng(321)
+    base = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=1200))
+    seqs = [base] * 50 + [base[:700]] * 30 + [base[400:]] * 30
+    want = oo.oracle_overlaps(seqs, 100)
+    got, st = hip_rows(seqs, 100)
+    assert st["wide_index"] == 1 and np.array_equal(got, want)
+    got, _ = hip_rows(seqs, 100, shard=3)
+    assert np.array_equal(got, want)
