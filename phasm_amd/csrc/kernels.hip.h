@@ -1126,12 +1126,12 @@ __global__ void k_read_invert(const uint32_t* __restrict__ rank, uint32_t n_read
 // ----------------------------------------------------------------------------------------
 // verify: packed exact compare of a[p : p+n) against b[0 : n), n = min(la-p, lb)
 // ----------------------------------------------------------------------------------------
-// One workgroup per a-side read: a's packed words are staged in LDS once and every candidate of a
-// streams only its b side from global memory, 16 bytes per lane per step (global_load_dwordx4).
-// 16 lanes form a group that walks one candidate in 256-byte steps (1024 bases at 2 bit); the four
-// groups of a wave advance independently through a flattened loop, so a finished or mismatching
-// candidate hands its lanes to the group's next candidate at once.  The window of a that faces b is
-// funnel-shifted out of three LDS words.
+// One workgroup per a-side read: a's packed words are staged in LDS once -- together with one 16-byte record per
+// candidate (position, compare length, row mask, where b starts) -- and every candidate of a streams only its b
+// side from global memory, 16 bytes per lane per block (global_load_dwordx4), three 256-byte blocks per step.
+// 16 lanes form a group that walks one candidate; the four groups of a wave advance independently through a
+// flattened loop, and a group whose candidate has finished or mismatched draws the next one from a counter
+// shared by the workgroup.  The window of a that faces b is cut out of adjacent LDS dwords with v_alignbit_b32.
 // type: bit0 = suffix-prefix (A) candidate holds, bit1 = b wholly contained at p (B); 0 = mismatch.
 // Do the exception records of a inside [p, p+n) equal those of b inside [0, n) (same offsets, same
 // bytes)?  Records are sorted by position; they are rare, one lane walks them.
@@ -1240,7 +1240,7 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
     // (sharded calls run without the locality order: their first step stays at one block)
     constexpr bool UNIFORM_STEPS = PO_VER_FIRST == PO_VER_BLOCKS && !SCRAMBLED;
     const uint32_t* B = reinterpret_cast<const uint32_t*>(words);
-    // Candidate metadata runs two candidates ahead of the compare loop, so that a group starting a
+    // (!STAGED only) Candidate metadata runs two candidates ahead of the compare loop, so that a group starting a
     // new candidate has (p, b, len[b], woff[b]) in registers already: m0 = the next candidate to
     // start (complete), m1 = the one after (p, b only; its len/woff are requested when it moves up).
     const uint32_t c_last = seg1 - 1;
