@@ -290,7 +290,7 @@ def main() -> int:
                            "kernels": kern,
                            "job_achieved": job_gbs, "job_frac": job_gbs / HBM_PEAK_GBS,
                            "job_algorithmic_bytes": int(job_bytes)}
-        # HBM-side traffic comes from separate rocprofv3 --pmc passes on the same workload (profiles/r01_v6_pmc.md,
+        # HBM-side traffic comes from separate rocprofv3 --pmc passes on the same workload (profiles/r01_v9_pmc.md,
         # profiles/traffic.json); it cannot be read from inside this process
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
