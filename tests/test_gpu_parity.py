@@ -2,6 +2,8 @@
 golden vectors produced by the compiled reference and against the CPU oracle on fresh seeded
 inputs.  Bit-exact: integer rows compared as sorted multisets (the reference's row order is
 implementation-defined, overlapper.cpp:30,:68)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -280,9 +282,9 @@ def test_seeded_fuzz_against_oracle(index, monkeypatch):
     (31..33, 63..65, 2047..2049 bases), tandem repeats, duplicated and contained reads, both strands or
     not, min_length from 1 up, both index flavours -- HIP rows must equal the CPU oracle's."""
     monkeypatch.setenv("PHASM_INDEX", index)
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(int(os.environ.get("PHASM_FUZZ_SEED", "2024")))
     rc = bytes.maketrans(b"ACGT", b"TGCA")
-    for trial in range(40):
+    for trial in range(int(os.environ.get("PHASM_FUZZ_TRIALS", "40"))):
         glen = int(rng.integers(300, 6000))
         if rng.random() < 0.3:   # low-complexity genome
             unit = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=int(rng.integers(1, 12))))
