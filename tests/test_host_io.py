@@ -79,3 +79,52 @@ def test_native_fasta_ingest_matches_python_reader(tmp_path):
         single.add_fasta(str(tmp_path / "missing.fasta"))
     ov.close()
     single.close()
+
+
+def test_parallel_and_sequential_fasta_ingest_agree(tmp_path, monkeypatch):
+    """po_add_fasta packs pure-ACGT files with several threads from the mapped file and falls back to the
+    record-by-record path for anything else: both must give the same reads (names, lengths -- and, on the GPU,
+    the same overlap file: tests/test_gpu_e2e.py)."""
+    import random
+    from phasm_amd.overlapper import ExactOverlapper
+    rng = random.Random(3)
+    recs = []
+    for i in range(700):
+        n = rng.choice([0, 1, 31, 32, 33, 64, 65, 700, 3000, rng.randint(1, 5000)])
+        recs.append(("read %d len=%d" % (i, n), "".join(rng.choice("ACGT") for _ in range(n))))
+    def write(path, recs, width, crlf=False, blanks=False):
+        eol = "\r\n" if crlf else "\n"
+        with open(path, "w", newline="") as f:
+            f.write("junk before the first header" + eol)
+            for name, seq in recs:
+                f.write(">" + name + eol)
+                for k in range(0, len(seq), width):
+                    f.write(("  " if blanks and k == 0 else "") + seq[k:k + width] + (" \t" if blanks else "") + eol)
+                if blanks:
+                    f.write(eol)
+    for width, crlf, blanks in ((80, False, False), (10 ** 9, False, False), (61, True, True)):
+        p = tmp_path / ("r_%d_%d.fa" % (min(width, 999), crlf))
+        write(str(p), recs, width, crlf, blanks)
+        got = {}
+        for mode in ("parallel", "sequential"):
+            if mode == "sequential":
+                monkeypatch.setenv("PHASM_FASTA_SEQUENTIAL", "1")
+            else:
+                monkeypatch.delenv("PHASM_FASTA_SEQUENTIAL", raising=False)
+            ov = ExactOverlapper()
+            assert ov.add_fasta(str(p)) == len(recs)
+            got[mode] = (ov.ids(), ov.lengths().tolist())
+            ov.close()
+        assert got["parallel"] == got["sequential"]
+        assert got["parallel"][0] == [n + s for n, _ in recs for s in "+-"]
+        assert got["parallel"][1] == [len(q) for _, q in recs for _ in "+-"]
+    # a file with one N: the parallel path steps aside, the result is the sequential one
+    recs2 = recs[:50] + [("with N", "ACGTNACGT" * 20)] + recs[50:80]
+    p = tmp_path / "n.fa"
+    write(str(p), recs2, 70)
+    monkeypatch.delenv("PHASM_FASTA_SEQUENTIAL", raising=False)
+    ov = ExactOverlapper()
+    assert ov.add_fasta(str(p)) == len(recs2)
+    assert ov.ids() == [n + s for n, _ in recs2 for s in "+-"]
+    assert ov.lengths().tolist() == [len(q) for _, q in recs2 for _ in "+-"]
+    ov.close()
