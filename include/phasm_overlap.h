@@ -160,6 +160,9 @@ void po_result_free(po_result* r);
 /* Write one GFA2 edge line per row to the file descriptor, byte-identical to the reference's
  * gfa_line("E", "*", a_id, b_id, astart, aend, bstart, bend, "*")  (assembler.py:46-48, gfa.py:230-231). */
 po_status po_write_gfa_edges(po_result* r, int fd, uint64_t* lines_out);
+/* The segment lines that go before them: `S <name> <length> *` per read pair (assembler.py:38; the handle's reads
+ * must have been added as name+"+" / name+"-" pairs). */
+po_status po_write_gfa_segments(po_handle* h, int fd, uint64_t* lines_out);
 /* (Given a po_layout_edges result instead, the same call writes the graph's edges the way the reference's
  * graph writer does: `E * <u> <v> <weight> <len(u)> 0 <overlap_len> *`, gfa2_write_graph, gfa.py:315-327.) */
 

@@ -92,6 +92,7 @@ SYMBOLS = [
     ("po_result_copy_prefix_to_device", ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64]),
     ("po_result_free", None, [_P]),
     ("po_write_gfa_edges", ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
+    ("po_write_gfa_segments", ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
     ("po_add_segment", ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]),
     ("po_result_from_rows", ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(_P)]),
     ("po_add_gfa", ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(_P)]),

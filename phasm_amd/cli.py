@@ -38,9 +38,13 @@ def overlap(args) -> int:
     if isinstance(args.fasta_input, (str, bytes)) and not getattr(args, "python_ingest", False):
         # native parse + reverse complement + 2-bit pack in one pass (po_add_fasta)
         overlapper.add_fasta(args.fasta_input, both_strands=True)
-        ids, lens = overlapper.ids(), overlapper.lengths()
-        for i in range(0, len(ids), 2):
-            args.output.write(gfa.gfa_line("S", ids[i][:-1], int(lens[i]), "*"))
+        try:
+            args.output.fileno()
+            overlapper.write_gfa_segments(args.output)       # S lines formatted in C, straight to the descriptor
+        except (AttributeError, OSError, ValueError):
+            ids, lens = overlapper.ids(), overlapper.lengths()
+            for i in range(0, len(ids), 2):
+                args.output.write(gfa.gfa_line("S", ids[i][:-1], int(lens[i]), "*"))
     else:
         for name, seq in read_fasta(args.fasta_input):
             args.output.write(gfa.gfa_line("S", name, len(seq), "*"))

@@ -129,6 +129,13 @@ class ExactOverlapper:
         _check(self._h, self._lib.po_add_fasta(self._h, os.fsencode(path), 1 if both_strands else 0, ctypes.byref(n)))
         return int(n.value)
 
+    def write_gfa_segments(self, fileobj) -> int:
+        """``S <name> <length> *`` for every read pair, written natively to a real file (``po_write_gfa_segments``)."""
+        fileobj.flush()
+        n = ctypes.c_uint64()
+        _check(self._h, self._lib.po_write_gfa_segments(self._h, fileobj.fileno(), ctypes.byref(n)))
+        return int(n.value)
+
     def overlaps(self, min_length: int) -> List[OverlapT]:
         arr = self.overlaps_array(min_length)
         ids = self.ids()
