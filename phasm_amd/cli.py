@@ -16,6 +16,13 @@ write the assembly graph as it stands before graph cleaning, in the reference's 
 ``E * u v weight len(u) 0 overlap_len *`` line per edge).
 
     python -m phasm_amd.cli layout-edges overlaps.gfa -o graph.gfa
+
+``daligner2gfa`` is the other producer of the overlap file (``phasm-convert daligner2gfa``,
+/root/reference/phasm/cli/convert.py:65-133, options :146-183): DBdump + LAdump text in, the same GFA2 lines out.
+``layout-edges --las`` takes the two dumps directly and skips the text in between.
+
+    python -m phasm_amd.cli daligner2gfa -o overlaps.gfa reads.dbdump alignments.ladump
+    python -m phasm_amd.cli layout-edges reads.dbdump --las alignments.ladump -o graph.gfa
 """
 from __future__ import annotations
 
@@ -23,7 +30,7 @@ import argparse
 import logging
 import sys
 
-from .io import gfa
+from .io import daligner, gfa
 from .io.fasta import read_fasta, reverse_complement
 from .overlapper import ExactOverlapper
 from . import layout as layout_mod
@@ -96,10 +103,42 @@ def write_stage1_graph(out, ids, lengths, edges_arr, edges_res=None) -> int:
     return len(e)
 
 
+def _load_translations(path):
+    """-T of daligner2gfa (convert.py:69-76): a JSON object {dump id: name}; a missing file is ignored with a
+    warning (the reference's warning line itself fails on an undefined attribute, :75-76)."""
+    import json
+    import os
+    if not path:
+        return None
+    if not os.path.isfile(path):
+        logger.warning("Translations file '%s' does not exist, ignoring.", path)
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def daligner2gfa(args) -> int:
+    las = sys.stdin if args.las_input in (None, "-") else open(args.las_input)
+    try:
+        with open(args.db_input) as db:
+            n_s, n_e = daligner.write_gfa(args.out, db, las, args.with_sequences, args.with_trace_points,
+                                          _load_translations(args.translations))
+    finally:
+        if las is not sys.stdin:
+            las.close()
+    logger.info("Wrote %d reads and %d local alignments.", n_s, n_e)
+    return n_e
+
+
 def layout_edges(args) -> int:
     ov = ExactOverlapper(device=getattr(args, "device", None))
     try:
-        nseg, rows = ov.add_gfa(args.gfa_file)
+        if getattr(args, "las", None):
+            with open(args.gfa_file) as db, open(args.las) as las:
+                rows = layout_mod.load_daligner(ov, db, las, _load_translations(getattr(args, "translations", None)))
+            nseg = len(ov) // 2
+        else:
+            nseg, rows = ov.add_gfa(args.gfa_file)
         logger.info("Read %d reads and %d local alignments from the GFA2 file.", nseg, len(rows))
         try:
             edges, _removed = ov.layout_edges(rows, args.min_read_length, args.min_overlap_length,
@@ -139,8 +178,20 @@ def main(argv=None) -> int:
     q.add_argument("-r", "--max-overhang-rel", type=float, default=0.8)
     q.add_argument("-o", "--output", type=argparse.FileType("w"), default=sys.stdout)
     q.add_argument("--device", type=int, default=None)
+    q.add_argument("--las", default=None, metavar="LADUMP",
+                   help="read the positional file as DBdump text and the alignments from this LAdump text")
+    q.add_argument("-T", "--translations", default=None, help="with --las: JSON map of dump ids to read names")
     q.add_argument("gfa_file", help="GFA2 file with the reads (S lines) and their pairwise alignments (E lines)")
     q.set_defaults(func=layout_edges)
+    # option names of `phasm-convert daligner2gfa`, convert.py:146-183
+    c = sub.add_parser("daligner2gfa", help="Convert DAZZ_DB DBdump and DALIGNER LAdump text to a GFA2 overlap file.")
+    c.add_argument("-s", "--with-sequences", action="store_true", default=False)
+    c.add_argument("-t", "--with-trace-points", type=int, default=None, metavar="SPACING")
+    c.add_argument("-T", "--translations", type=str, default=None, metavar="TRANSLATION_FILE")
+    c.add_argument("-o", "--out", type=argparse.FileType("w"), default=sys.stdout)
+    c.add_argument("db_input", help="DBdump text")
+    c.add_argument("las_input", nargs="?", default=None, help="LAdump text (default: stdin)")
+    c.set_defaults(func=daligner2gfa)
     args = parser.parse_args(argv)
     if not getattr(args, "func", None):
         parser.print_help()

@@ -75,6 +75,29 @@ def layout_from_gfa(path: str, device: Optional[int] = None, **params) -> Assemb
         ov.close()
 
 
+def load_daligner(ov: ExactOverlapper, db_input, las_input, translations=None) -> OverlapResult:
+    """DBdump + LAdump text -> the reads (as segments) and the row result on ``ov``, i.e. the state after
+    ``daligner2gfa`` and ``po_add_gfa`` without the file in between (phasm_amd/io/daligner.py ``to_rows``)."""
+    from .io import daligner
+    names, lengths, rows = daligner.to_rows(db_input, las_input, translations)
+    for name, n in zip(names, lengths.tolist()):
+        ov.add_segment(name, n)
+    return ov.result_from_rows(rows)
+
+
+def layout_from_daligner(db_input, las_input, translations=None, device: Optional[int] = None, **params) -> AssemblyEdges:
+    """``phasm layout`` stage 1 straight from DAZZ_DB / DALIGNER dump text."""
+    ov = ExactOverlapper(device=device)
+    try:
+        rows = load_daligner(ov, db_input, las_input, translations)
+        try:
+            return build_assembly_graph(ov, rows, **{**DEFAULTS, **params})
+        finally:
+            rows.free()
+    finally:
+        ov.close()
+
+
 def layout_from_overlaps(ov: ExactOverlapper, min_length: int, **params) -> AssemblyEdges:
     """Overlap + layout stage 1 without the file in between: the rows never leave HBM."""
     rows = ov.overlaps_result(min_length)

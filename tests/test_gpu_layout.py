@@ -158,3 +158,39 @@ def test_cli_overlap_then_layout_edges_files(tmp_path):
     assert sorted(e_lines) == want_e
     used = sorted({n >> 1 for uv in want["edges"] for n in uv})
     assert s_lines == [gfa.gfa_line("S", names[i], int(lengths[i]), "*") for i in used]
+
+
+def _daligner_cases():
+    import json
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "daligner_cases.json")))
+    return [c for c in d["cases"] if "ok" in c["gfa"] and c["name"] not in ("no_reads", "trace_empty_list")]
+
+
+@pytest.mark.parametrize("case", _daligner_cases(), ids=[c["name"] for c in _daligner_cases()])
+def test_layout_from_daligner_dumps(case, tmp_path):
+    """DBdump + LAdump straight to the device == the reference-formatted GFA2 text read natively == the oracle."""
+    import io
+    from phasm_amd import cli
+    from phasm_amd.io import gfa
+    params = dict(layout.DEFAULTS, max_overhang_abs=20, max_overhang_rel=0.3)
+    direct = layout.layout_from_daligner(io.StringIO(case["db"]), io.StringIO(case["las"]), case["translations"], **params)
+    p = tmp_path / "in.gfa"
+    p.write_text(case["gfa"]["ok"])
+    via_file = layout.layout_from_gfa(str(p), **params)
+    assert direct.ids == via_file.ids
+    assert np.array_equal(edge_array(direct.edges), edge_array(via_file.edges))
+    assert direct.contained.tolist() == via_file.contained.tolist()
+    names, lengths, rows = gfa.read_gfa2_rows(io.StringIO(case["gfa"]["ok"]))
+    want = lo.layout_sequential([tuple(r) for r in rows.tolist()], lu.node_lengths(lengths.tolist()), **params)
+    assert np.array_equal(edge_array(direct.edges), lo.edges_dict_to_array(want["edges"]))
+    # and as a command
+    (tmp_path / "db.txt").write_text(case["db"])
+    (tmp_path / "las.txt").write_text(case["las"])
+    args = ["layout-edges", "-a", "20", "-r", "0.3", str(tmp_path / "db.txt"), "--las", str(tmp_path / "las.txt")]
+    if case["translations"]:
+        import json
+        (tmp_path / "t.json").write_text(json.dumps(case["translations"]))
+        args += ["-T", str(tmp_path / "t.json")]
+    assert cli.main(args + ["-o", str(tmp_path / "g1.gfa")]) == 0
+    assert cli.main(["layout-edges", "-a", "20", "-r", "0.3", str(p), "-o", str(tmp_path / "g2.gfa")]) == 0
+    assert (tmp_path / "g1.gfa").read_bytes() == (tmp_path / "g2.gfa").read_bytes()
