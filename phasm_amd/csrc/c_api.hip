@@ -477,13 +477,15 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     const uint64_t n_keys = wide ? n_elig * W : n_elig;
     // ---- sizes
     uint32_t tbits = 10;
-    // narrow: load factor <= 1/16, so that the two slots fetched up front almost always settle a probe
-    // (a third, synchronous probe stalls the scan pipeline): 1.31 -> 1.17 ms at config 2 vs 4x
-    uint64_t table_mult = wide ? 2 : 16;
-    if (const char* e = getenv("PHASM_TABLE_MULT")) table_mult = std::max(2, atoi(e));
-    while ((1ull << tbits) < table_mult * n_keys) ++tbits;
+    // narrow: 5-10 slots per key, probed in aligned groups of four (kernels.hip.h PROBE_GROUP).  A probe for an
+    // absent key needs more than its group when all four slots are taken: 0.75 % of the groups at 5.2 slots per
+    // key (7 % at 2.6), and those positions go to the leftover list; 8 MB at config 2
+    double table_mult = wide ? 2.0 : 5.0;
+    if (const char* e = getenv("PHASM_TABLE_MULT")) table_mult = std::max(wide ? 2.0 : 1.5, atof(e));
+    while ((double)(1ull << tbits) < table_mult * (double)n_keys) ++tbits;
     if (tbits > 30) return fail(h, PO_ERR_CAPACITY, "too many reads for the anchor table");
-    const uint32_t nslots = (1u << tbits) + 1;
+    // (+1: the slot of the all-ones key; narrow: three more so that a group fetch of that slot stays in bounds)
+    const uint32_t nslots = (1u << tbits) + (wide ? 1u : po::PROBE_GROUP);
     uint32_t bloom_log2 = 13;
     while (bloom_log2 < 20 && (1ull << bloom_log2) < 16 * n_elig) ++bloom_log2;
     const size_t bloom_bytes = (size_t)1 << (bloom_log2 - 3);
@@ -627,7 +629,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         else
             hipLaunchKernelGGL((po::k_scan_probe<BITS, false>), dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
         HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
-        hipLaunchKernelGGL((po::k_scan_fixup<BITS>), dim3(n_scan_waves), dim3(64), 0, st, A, n_scan_waves);
+        hipLaunchKernelGGL((po::k_scan_fixup<BITS>), dim3(n_scan_waves), dim3(256), 0, st, A, n_scan_waves);
         hipLaunchKernelGGL(po::k_add_extra, dim3(cdiv(ntiles, 256)), dim3(256), 0, st, A.tile_count, A.tile_extra, tile_begin,
                            tile_end);
         if (getenv("PHASM_DEBUG_LEFT")) {  // how many positions did the scan waves defer to k_scan_fixup?

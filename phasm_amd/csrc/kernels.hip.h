@@ -27,6 +27,9 @@ constexpr uint32_t NO_SELFREP = 0xFFFFFFFFu;
 constexpr uint64_t KEY_EMPTY = ~0ull;          // slot-claim sentinel; a real all-ones K-mer lives
                                                // in the dedicated extra slot at index 1<<tbits
 constexpr int WAVE = 64;
+#ifndef PO_FILTER_DEPTH
+#define PO_FILTER_DEPTH 6
+#endif
 constexpr int SCAN_BLOCK = 1024;               // 16 waves: one persistent workgroup per CU (<= 128 VGPRs)
 constexpr int TILE_WORDS = 64;                 // one 64-bit word per lane
 
@@ -149,6 +152,16 @@ __device__ inline uint32_t keep_bits(uint32_t a, uint32_t b, uint32_t rem, uint3
            ((rem >= lb && (!paired || (a & 1u) == 0u)) ? 2u : 0u);
 }
 
+// The narrow anchor table is probed in aligned groups of PROBE_GROUP slots (64 bytes: one fetch settles a probe
+// unless the whole group is taken by other keys): a key's home is the first slot of its group, collisions go on
+// linearly from there.  No deletions, so an empty slot anywhere from the home on means "key absent".  At 2.5-5
+// slots per key the table of config 2 is 4 MB and stays in the XCDs' L2s under the streamed reads (16 slots per
+// key and pairs of slots, the earlier layout: 32 MB, every probe a 128-byte line from the fabric, 6 GB per launch).
+constexpr uint32_t PROBE_GROUP = 4;
+__host__ __device__ inline uint32_t narrow_home(uint32_t h1, uint32_t tbits) {
+    return (h1 >> (32 - tbits)) & ~(PROBE_GROUP - 1u);
+}
+
 __device__ inline void table_probe(const Slot* __restrict__ tab, uint32_t tbits, uint64_t kmer,
                                    uint32_t& start, uint32_t& cnt) {
     start = 0;
@@ -162,7 +175,7 @@ __device__ inline void table_probe(const Slot* __restrict__ tab, uint32_t tbits,
     }
     uint32_t h1, h2;
     kmer_hash(kmer, h1, h2);
-    uint32_t i = h1 >> (32 - tbits);
+    uint32_t i = narrow_home(h1, tbits);
     for (;;) {
         const u32x4 s = *reinterpret_cast<const u32x4*>(&tab[i]);
         if (s.w == 0) return;
@@ -221,7 +234,7 @@ __global__ void k_table_insert(const uint64_t* __restrict__ words, const uint64_
     if (key == KEY_EMPTY) {
         i = tmask + 1u;
     } else {
-        i = h1 >> (32 - tbits);
+        i = narrow_home(h1, tbits);
         for (;;) {
             unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[i].key),
                                                 (unsigned long long)KEY_EMPTY, (unsigned long long)key);
@@ -234,10 +247,10 @@ __global__ void k_table_insert(const uint64_t* __restrict__ words, const uint64_
     if (bits == 2) {
         // 2-bit reads: 64-bit blocks addressed by sequence bits themselves (uniform for DNA, no
         // multiply): block = bits 5.. of the first 16 bases, two bits in the block's low word (from
-        // bases 0-2 and 9-11), one in its high word (from bases 16-18).  See filter_tile<2>.
+        // bases 0-2 and 10-12), one in its high word (from bases 16-18).  See filter_tile<2>.
         const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
         const uint32_t blk = (lo >> 5) & ((1u << (bloom_log2 - 6)) - 1u);
-        atomicOr(&bloom[2 * blk], (1u << (lo & 31)) | (1u << ((lo >> 19) & 31)));
+        atomicOr(&bloom[2 * blk], (1u << (lo & 31)) | (1u << ((lo >> 20) & 31)));
         atomicOr(&bloom[2 * blk + 1], 1u << (hi & 31));
     } else {
         uint32_t bword, bmask;
@@ -559,7 +572,7 @@ __device__ inline uint64_t window(uint64_t w0, uint64_t w1, int s) {
 //  BITS == 8: hashed blocked Bloom filter, 32-bit blocks, 3 bits per key (bloom_slot).
 //  BITS == 2: the packed bases are already uniform bits, so no hash: T[s] = the 32 bits of the read
 //  starting at base s; a K-mer's block is T[s] bits 5..18, its three bits are T[s] & 31 and
-//  (T[s] >> 19) & 31 (bases 9-11, clear of the block index) in the block's low word and
+//  (T[s] >> 20) & 31 (bases 10-12, clear of the block index) in the block's low word and
 //  T[s+16] & 31 (bases 16-18) in its high word.  One ds_read_b64 and ~12 VALU ops per position;
 //  T[s+16] is shared between positions s and s+16.  Three bits keep the survivors near 2.6 % of the
 //  positions (1 % are real), so that a lane rarely has more than NPEND of them.
@@ -574,23 +587,43 @@ __device__ inline uint32_t filter_tile(const uint32_t* __restrict__ s_bloom, uin
         const uint32_t klo = FULLK ? ~0u : (uint32_t)kmask, khi = FULLK ? ~0u : (uint32_t)(kmask >> 32);
         const uint32_t bmask = (1u << (bloom_log2 - 6)) - 1u;
         const uint32_t amask = bmask << 3;
+        // T[s] = the 32 bits of the read that start at base s of this lane's word (s < 48), made when first needed
         uint32_t T[48];
-#pragma unroll
-        for (int s = 0; s < 48; ++s) {
+        auto make_T = [&](int s) __attribute__((always_inline)) {
             const int j = (2 * s) >> 5, sh = (2 * s) & 31;
             T[s] = sh ? __builtin_amdgcn_alignbit(x[j + 1], x[j], sh) : x[j];
-        }
+        };
+        typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+        typedef const u32x2 __attribute__((address_space(3))) lds_u32x2;
+        // The filter is the first thing in the kernel's LDS (offset 0, no static LDS in k_scan_probe): the byte offset
+        // of a block IS its LDS address -- spelled as an address-space-3 pointer so that the compiler does not add
+        // the (relocatable, zero) base to it.  T[s + 1] is T[s] >> 2 and T[s + 10] is T[s] >> 20 (with younger bits on
+        // top): with a whole-word anchor the block address and the second bit index cost no shift of their own.
+        auto block_of = [&](int s) __attribute__((always_inline)) -> u32x2 {
+            const uint32_t addr = FULLK ? (T[s + 1] & amask) : (((T[s] & klo) >> 2) & amask);
+            return *reinterpret_cast<lds_u32x2*>((uintptr_t)addr);
+        };
+        // PO_FILTER_DEPTH block reads in flight per lane, kept in this order by a scheduling barrier per position:
+        // the reads are random (about 3.5 lanes of a 32-lane group on one bank pair), and four waves per SIMD do
+        // not cover that latency with two in flight (the order hipcc picks on its own)
+        static_assert(PO_FILTER_DEPTH >= 1 && PO_FILTER_DEPTH <= 16, "the T window below reaches 17 bases ahead");
+        u32x2 blk[PO_FILTER_DEPTH];
+#pragma unroll
+        for (int s = 0; s <= 16; ++s) make_T(s);
+#pragma unroll
+        for (int s = 0; s < PO_FILTER_DEPTH; ++s) blk[s] = block_of(s);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
+            if (s + 17 < 48) make_T(s + 17);
             const uint32_t t1 = T[s] & klo, t2 = T[s + 16] & khi;
-            // byte offset of the block = ((t1 >> 5) & bmask) * 8; the filter sits at LDS offset 0
-            // the filter is the first thing in the kernel's LDS (offset 0, no static LDS in k_scan_probe): the byte
-            // offset IS the LDS address -- spelled as an address-space-3 pointer so that the compiler does not add
-            // the (relocatable, zero) base to it, one VALU instruction per position
-            typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
-            typedef const u32x2 __attribute__((address_space(3))) lds_u32x2;
-            const u32x2 blk = *reinterpret_cast<lds_u32x2*>((uintptr_t)((t1 >> 2) & amask));
-            hitmask |= ((blk.x >> (t1 & 31)) & (blk.x >> ((t1 >> 19) & 31)) & (blk.y >> (t2 & 31)) & 1u) << s;
+            const uint32_t sel2 = FULLK ? T[s + 10] : (t1 >> 20);
+            const u32x2 b = blk[s % PO_FILTER_DEPTH];
+            // only bit 0 of the product enters: v_alignbit shifts it in at the top, after 32 rounds position s is bit s
+            hitmask = __builtin_amdgcn_alignbit((b.x >> (t1 & 31)) & (b.x >> (sel2 & 31)) & (b.y >> (t2 & 31)), hitmask, 1);
+            if (s + PO_FILTER_DEPTH < 32) blk[s % PO_FILTER_DEPTH] = block_of(s + PO_FILTER_DEPTH);
+            asm volatile("" : "+v"(hitmask));   // pins this position's arithmetic in front of the barrier
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
         const uint32_t wshift = 32 - (bloom_log2 - 5);
@@ -637,8 +670,8 @@ __device__ inline void for_each_candidate(const uint32_t* __restrict__ chain, co
 // Positions that cannot be settled from registers (a third table slot, a chain of several reads, a
 // 65th survivor) go to a per-wave leftover list and are settled afterwards by k_scan_fixup.
 // Out: truemask[tile][lane] bit s = position has candidates; tile_count[tile] = their number.
-constexpr uint32_t LEFT_CAP = 512;   // deferred positions per scan wave before it falls back to resolving them in place
-constexpr int SCAN_LDS_PER_WAVE = WAVE * 4 + WAVE * 4;  // queue of positions, result masks
+constexpr uint32_t LEFT_CAP = 2048;   // deferred positions per scan wave before it falls back to resolving them in place
+constexpr int SCAN_LDS_PER_WAVE = 2 * WAVE * 4 + WAVE * 4;  // queue of positions (two rounds), result masks
 #ifdef PO_STAMPS
 #define PO_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -653,8 +686,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t bloom_words = (1u << A.bloom_log2) >> 5;
     uint32_t* s_bloom = reinterpret_cast<uint32_t*>(smem);                      // filter first: its block offsets are LDS addresses
-    uint32_t* qs = s_bloom + bloom_words + wave * WAVE;                         // queue: lane << 8 | s
-    uint32_t* tm = s_bloom + bloom_words + (nwaves + wave) * WAVE;              // result mask per owner lane
+    uint32_t* qs = s_bloom + bloom_words + wave * (2 * WAVE);                   // queue: lane << 8 | s
+    uint32_t* tm = s_bloom + bloom_words + (2 * nwaves + wave) * WAVE;          // result mask per owner lane
     for (uint32_t i = threadIdx.x; i < bloom_words; i += blockDim.x) s_bloom[i] = A.bloom[i];
     tm[lane] = 0;
     __syncthreads();
@@ -675,9 +708,15 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
 
     // the probe in flight: it belongs to the PREVIOUS tile of this wave
     uint64_t pk = 0;
-    u32x4 ps0 = {0, 0, 0, 0}, ps1 = {0, 0, 0, 0};
+    u32x4 ps0 = {0, 0, 0, 0}, ps1 = {0, 0, 0, 0}, ps2 = {0, 0, 0, 0}, ps3 = {0, 0, 0, 0};
     uint32_t pidx = 0, psrc = 0;
     bool pon = false;
+    // second round of the same tile, only issued when it has more than 64 survivors (about every third tile at
+    // config 2; survivors 129.. go to the leftover list)
+    uint64_t pk2 = 0;
+    u32x4 pt0 = {0, 0, 0, 0}, pt1 = {0, 0, 0, 0}, pt2 = {0, 0, 0, 0}, pt3 = {0, 0, 0, 0};
+    uint32_t pidx2 = 0, psrc2 = 0;
+    bool pon2 = false, extra = false;  // extra is wave-uniform
     uint32_t prev_t = 0xFFFFFFFFu, prev_a = 0, prev_la = 0, prev_word0 = 0;
 
     // a found slot -> number of candidates of position p of read a (and the selfrep side effect)
@@ -716,7 +755,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
     // (hipcc falls back to vmcnt(0) at every use here, which would serialise the probes):
     //   R(k+2)  record of tile k+2     2 x dwordx4   issued in pass k, used from pass k+1
     //   W(k+1)  words of tile k+1      1 x dwordx4   issued in pass k, used in pass k+1
-    //   P(k)    table slots of tile k  2 x dwordx4   issued at the end of pass k, used in pass k+1
+    //   P(k)    table slots of tile k  4 x dwordx4   issued at the end of pass k, used in pass k+1
     // vm ops complete in issue order, and vmcnt(N) waits until at most N are outstanding, so a wait
     // needs N <= (ops issued after the one wanted).  Stores and the rare compiler-tracked loads only
     // add younger ops, so the counts below are lower bounds: safe.  Every steady-state load is
@@ -742,6 +781,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
         wa = ld16(&words[rec.wabs + lane]);  // (tail padding keeps every lane in bounds)
         ps0 = ld16(&table[0]);               // dummy probe: same queue shape as the steady state
         ps1 = ld16(&table[1]);
+        ps2 = ld16(&table[2]);
+        ps3 = ld16(&table[3]);
     }
 #ifdef PO_STAMPS
     unsigned long long acc_s[6] = {0, 0, 0, 0, 0, 0};
@@ -753,8 +794,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
         unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0;
         (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)st5;
         PO_STAMP(st0);
-        // ---- R and W of the previous pass have the 2 probe loads behind them
-        asm volatile("s_waitcnt vmcnt(2)" : "+v"(r_lo), "+v"(r_hi), "+v"(wcur) : : "memory");
+        // ---- R and W of the previous pass have the 4 (8 with a second round) probe loads behind them
+        // (ONE asm statement, the choice is made inside it: two statements in the arms of an `if` make hipcc copy
+        // the landing registers in front of the branch -- a read of registers whose loads are still in flight)
+        asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 .Lpo_w4_%=\n\ts_waitcnt vmcnt(8)\n\ts_branch .Lpo_wd_%=\n"
+                     ".Lpo_w4_%=:\n\ts_waitcnt vmcnt(4)\n.Lpo_wd_%=:"
+                     : "+v"(r_lo), "+v"(r_hi), "+v"(wcur) : "s"(extra ? 1u : 0u) : "memory", "scc");
         PO_STAMP(st1);
         TileRec rec1;  // tile k+1
         rec1.wabs = ((uint64_t)__builtin_amdgcn_readfirstlane(r_lo.y) << 32) | __builtin_amdgcn_readfirstlane(r_lo.x);
@@ -779,28 +824,46 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
             if (nvalid < (uint32_t)W) hitmask &= (1u << nvalid) - 1u;
         }
         PO_STAMP(st2);
-        // ---- the previous tile's probe has only this pass's R and W (3 loads) behind it
-        asm volatile("s_waitcnt vmcnt(3)" : "+v"(ps0), "+v"(ps1) : : "memory");
+        // ---- the previous tile's probes have only this pass's R and W (3 loads) behind them
+        // (both rounds at once: the second is consumed right after the first)
+        asm volatile("s_waitcnt vmcnt(3)" : "+v"(ps0), "+v"(ps1), "+v"(ps2), "+v"(ps3), "+v"(pt0), "+v"(pt1), "+v"(pt2), "+v"(pt3)
+                     : : "memory");
         PO_STAMP(st3);
         if (prev_t != 0xFFFFFFFFu) {
-            u32x4 s = ps0;
-            if (pon && pk != KEY_EMPTY && s.w != 0 && (((uint64_t)s.y << 32) | s.x) != pk) s = ps1;  // linear probing
-            const bool settled = s.w == 0 || (((uint64_t)s.y << 32) | s.x) == pk;
-            // needs a third slot, or heads a chain of several reads -> leftover list
-            const bool hard = pon && (!settled || (s.w != 0 && !(s.w & SLOT_SINGLE)));
-            const bool deferred = defer(hard, prev_t, psrc);
-            uint32_t n = 0;
-            if (pon && !deferred) {
-                if (!settled) {  // (leftover list full) resolve in place
-                    uint32_t j = (pidx + 1u) & tmask;
-                    while (s.w != 0 && (((uint64_t)s.y << 32) | s.x) != pk) {
-                        j = (j + 1u) & tmask;
-                        s = *reinterpret_cast<const u32x4*>(&table[j]);
+            // one survivor of the previous tile: linear probing over its group -- the first slot that is empty (key
+            // absent) or holds the key settles it (the all-ones key sits alone in the extra slot: empty or equal,
+            // its first slot always settles).  Every lane of the wave calls this (defer() is a wave operation).
+            auto settle = [&](uint64_t key, uint32_t home, uint32_t src, bool on, const u32x4& q0, const u32x4& q1,
+                              const u32x4& q2, const u32x4& q3) __attribute__((always_inline)) -> uint32_t {
+                const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+                auto stops = [&](const u32x4& q) __attribute__((always_inline)) -> bool {
+                    return q.w == 0 || (q.x == klo && q.y == khi);
+                };
+                const bool h0 = stops(q0), h1 = stops(q1), h2 = stops(q2), h3 = stops(q3);
+                u32x4 s = q3;
+                if (h2) s = q2;
+                if (h1) s = q1;
+                if (h0) s = q0;
+                const bool settled = h0 | h1 | h2 | h3;
+                // needs a slot beyond the group, or heads a chain of several reads -> leftover list
+                const bool hard = on && (!settled || (s.w != 0 && !(s.w & SLOT_SINGLE)));
+                const bool deferred = defer(hard, prev_t, src);
+                uint32_t n = 0;
+                if (on && !deferred) {
+                    if (!settled) {  // (leftover list full) resolve in place
+                        uint32_t j = (home + PROBE_GROUP - 1u) & tmask;
+                        while (s.w != 0 && (((uint64_t)s.y << 32) | s.x) != key) {
+                            j = (j + 1u) & tmask;
+                            s = *reinterpret_cast<const u32x4*>(&table[j]);
+                        }
                     }
+                    if (s.w != 0) n = count_slot(s, prev_a, prev_la, (prev_word0 + (src >> 8)) * W + (src & 255u));
+                    if (n) atomicOr(&tm[src >> 8], 1u << (src & 255u));
                 }
-                if (s.w != 0) n = count_slot(s, prev_a, prev_la, (prev_word0 + (psrc >> 8)) * W + (psrc & 255u));
-                if (n) atomicOr(&tm[psrc >> 8], 1u << (psrc & 255u));
-            }
+                return n;
+            };
+            uint32_t n = settle(pk, pidx, psrc, pon, ps0, ps1, ps2, ps3);
+            if (extra) n += settle(pk2, pidx2, psrc2, pon2, pt0, pt1, pt2, pt3);
             wave_lds_fence();
             truemask[(size_t)prev_t * WAVE + lane] = tm[lane];  // each lane owns the mask of its word
             tm[lane] = 0;
@@ -814,13 +877,13 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
         const uint32_t incl = wave_incl_scan(nh);
         const uint32_t total = read_last_lane(incl);
         uint32_t rank = incl - nh;
-        while (hitmask && rank < (uint32_t)WAVE) {  // the queue only names the position: (lane, s)
+        while (hitmask && rank < 2u * WAVE) {  // the queue only names the position: (lane, s)
             const uint32_t sft = __ffs(hitmask) - 1;
             hitmask &= hitmask - 1;
             qs[rank] = (lane << 8) | sft;
             ++rank;
         }
-        while (__any(hitmask != 0)) {  // survivors beyond the 64th: defer them, one per lane per round
+        while (__any(hitmask != 0)) {  // survivors beyond the 128th: defer them, one per lane per round
             const bool want = hitmask != 0;
             const uint32_t sft = want ? __ffs(hitmask) - 1 : 0;
             const bool ok = defer(want, t, (lane << 8) | sft);  // all lanes take part, every round
@@ -843,24 +906,35 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
             }
         }
         wave_lds_fence();
-        // ---- request the two table slots of this lane's survivor: always 2 loads per lane (lanes
-        // without one read slot 0)
-        pon = lane < total;
-        {
-            psrc = pon ? qs[lane] : 0u;
+        // ---- request the group of table slots of this lane's survivor: always 4 loads per lane (lanes without one
+        // read group 0), and 4 more for survivors 65..128 when the tile has that many
+        auto request = [&](uint32_t src, bool on, uint64_t& key, uint32_t& home, u32x4& q0, u32x4& q1, u32x4& q2,
+                           u32x4& q3) __attribute__((always_inline)) {
             // the K-mer is cut out of the owner lane's two words, fetched across the wave (ds_bpermute)
-            const uint32_t sl = psrc >> 8;
+            const uint32_t sl = src >> 8;
             const uint32_t x0 = __shfl((uint32_t)w0, sl, WAVE), x1 = __shfl((uint32_t)(w0 >> 32), sl, WAVE);
             const uint32_t x2 = __shfl((uint32_t)w1, sl, WAVE), x3 = __shfl((uint32_t)(w1 >> 32), sl, WAVE);
-            const uint64_t kmer = funnel(((uint64_t)x1 << 32) | x0, ((uint64_t)x3 << 32) | x2, (psrc & 255u) * BITS) & kmask;
+            const uint64_t kmer = funnel(((uint64_t)x1 << 32) | x0, ((uint64_t)x3 << 32) | x2, (src & 255u) * BITS) & kmask;
             const uint32_t lo = (uint32_t)kmer, hi = (uint32_t)(kmer >> 32);
-            uint32_t idx = ((lo ^ ((hi << 13) | (hi >> 19))) * 0x9E3779B1u) >> (32 - tbits);
-            if (kmer == KEY_EMPTY) idx = tmask + 1u;  // the all-ones key lives in the extra slot
-            if (!pon) idx = 0;
-            pk = kmer;
-            pidx = idx;
-            ps0 = ld16(&table[idx]);
-            ps1 = ld16(&table[(idx + 1u) & tmask]);
+            uint32_t idx = narrow_home((lo ^ ((hi << 13) | (hi >> 19))) * 0x9E3779B1u, tbits);
+            if (kmer == KEY_EMPTY) idx = tmask + 1u;  // the all-ones key lives in the extra slot (three padding slots follow it)
+            if (!on) idx = 0;
+            key = kmer;
+            home = idx;
+            const Slot* g = &table[idx];
+            q0 = ld16(g);
+            q1 = ld16(g + 1);
+            q2 = ld16(g + 2);
+            q3 = ld16(g + 3);
+        };
+        pon = lane < total;
+        psrc = pon ? qs[lane] : 0u;
+        request(psrc, pon, pk, pidx, ps0, ps1, ps2, ps3);
+        extra = total > (uint32_t)WAVE;
+        if (extra) {
+            pon2 = lane + (uint32_t)WAVE < total;
+            psrc2 = pon2 ? qs[WAVE + lane] : 0u;
+            request(psrc2, pon2, pk2, pidx2, pt0, pt1, pt2, pt3);
         }
         wave_lds_fence();  // queue reads done before the next tile overwrites it
         if (__any(ovf_n != 0)) {  // (leftover list was full) counts resolved in place join the tile later
@@ -902,9 +976,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
 template <int BITS>
 __global__ void k_scan_fixup(const ScanArgs A, uint32_t n_waves) {
     constexpr int W = 64 / BITS;
-    const uint32_t wv = blockIdx.x;  // one workgroup per scan wave's list
+    // one workgroup of 256 threads per scan wave's list: every position is a chain of dependent loads, so the
+    // kernel's time is a latency times the number of rounds (64 threads per list: 16 rounds for a full list;
+    // one thread per slot of every list's capacity: the launch of 32 k mostly empty workgroups cost more than that)
+    const uint32_t wv = blockIdx.x;
     if (wv >= n_waves) return;
-    const uint32_t cnt = A.left_cnt[wv];
+    const uint32_t cnt = min(A.left_cnt[wv], LEFT_CAP);
     const uint2* __restrict__ list = A.left + (size_t)wv * LEFT_CAP;
     for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) {
         const uint2 e = list[k];

@@ -56,3 +56,16 @@ def test_hot_kernels_stay_in_registers(tmp_path):
     # nothing in the library may spill
     spills = {k: v["ScratchSize"] for k, v in usage.items() if v.get("ScratchSize")}
     assert not spills, spills
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_scan_pipeline_never_reads_a_register_whose_load_is_in_flight():
+    """k_scan_probe issues its steady-state loads with inline asm and waits for them with counted s_waitcnt
+    statements; hipcc does not know those registers are pending.  Two asm waits in the arms of an `if` once made
+    it copy the landing registers in FRONT of the wait (stale data, and the parity tests still passed on that
+    build): tools/check_scan_isa.py walks the generated code for exactly that."""
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_scan_isa.py"), "--strict"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    assert "0 problem(s)" in out.stdout

@@ -7,7 +7,7 @@ between its asm load and the asm wait that retires it (hipcc does not know the r
 a stray v_mov would read stale data).  This script compiles the library to assembly, walks every
 k_scan_probe kernel in layout order (main loop walked twice, for the back edge) and reports any read
 of a pending register.  Rule used for retirement (conservative): an asm `s_waitcnt vmcnt(N)` retires
-the wait with N = 8 retires the record/word loads, the wait with N = 3 the probe loads (see the kernel).
+the waits with N = 4 / 8 retire the record/word loads, N = 3 both probe rounds (see the kernel).
 
     python tools/check_scan_isa.py [--strict]
 
@@ -81,18 +81,18 @@ def check_kernel(name, body):
     ins = parse(body)
     n = len(ins)
     label_at = {t[:-1]: k for k, (_, t, _) in enumerate(ins) if t.endswith(":")}
-    # classify asm loads: RW = record/word loads (retired by the counted wait with N = 8),
-    # P = probe loads (retired by the wait with N = 3)
-    cls, last_wait, seen = {}, None, 0
+    # classify asm loads by their place in the layout: the 3 loads after a record/word wait (N = 4, or 8 when
+    # a second probe round is in flight) are RW; the asm loads that follow, up to the next such wait, are the
+    # first probe round (P1, 4 loads) and then the optional second round (P2, 4 loads).  Before the first wait:
+    # 3 RW loads and the 4 dummy probes.
+    cls, since = {}, 0
     for k, (_, t, a) in enumerate(ins):
         if a and t.startswith("s_waitcnt vmcnt"):
-            last_wait = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
+            if int(re.search(r"vmcnt\((\d+)\)", t).group(1)) in (4, 8):
+                since = 0
         elif a and t.startswith("global_load"):
-            if last_wait is None:
-                cls[k] = "RW" if seen < 3 else "P"
-            else:
-                cls[k] = "RW" if last_wait == 8 else "P"
-            seen += 1
+            cls[k] = "RW" if since < 3 else ("P1" if since < 7 else "P2")
+            since += 1
     if not cls:
         return ["%s: no asm loads found (pipeline removed?)" % name]
     dest = {k: frozenset(regs(ins[k][1].split(None, 1)[1].split(",")[0])) for k in cls}
@@ -112,7 +112,9 @@ def check_kernel(name, body):
             nn = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
             if nn == 0:
                 return frozenset()
-            return frozenset(x for x in pend if cls[x] != ("RW" if nn == 8 else "P"))
+            # 4 / 8: record + words done; 3: both probe rounds done
+            done = {4: ("RW",), 8: ("RW",), 3: ("P1", "P2")}.get(nn, ())
+            return frozenset(x for x in pend if cls[x] not in done)
         if k in cls:
             return pend | {k}
         return pend
