@@ -95,19 +95,18 @@ __device__ inline uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
-__device__ inline uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int d = WAVE / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
-    return v;
-}
+__device__ inline uint32_t read_last_lane(uint32_t v) { return __builtin_amdgcn_readlane(v, WAVE - 1); }
+
+// Wave total, the same value in every lane: the DPP scan and one readlane.  (A butterfly of six __shfl_xor is six
+// ds_bpermute round trips through the LDS crossbar, each with its own lgkmcnt(0): over 600 cycles per tile in
+// k_scan_probe's retire step.)
+__device__ inline uint32_t wave_sum(uint32_t v) { return read_last_lane(wave_incl_scan(v)); }
 
 __device__ inline uint64_t wave_sum64(uint64_t v) {
 #pragma unroll
     for (int d = WAVE / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
     return v;
 }
-
-__device__ inline uint32_t read_last_lane(uint32_t v) { return __builtin_amdgcn_readlane(v, WAVE - 1); }
 
 // LDS hand-off between lanes of ONE wave: DS ops of a wave execute in issue order; this only has
 // to stop the compiler from moving accesses across and to drain lgkmcnt.
@@ -176,6 +175,23 @@ __device__ inline void table_probe(const Slot* __restrict__ tab, uint32_t tbits,
     uint32_t h1, h2;
     kmer_hash(kmer, h1, h2);
     uint32_t i = narrow_home(h1, tbits);
+    {
+        // the home group in one go (four independent loads): the first slot that is empty or holds the key settles it
+        const u32x4* g = reinterpret_cast<const u32x4*>(&tab[i]);
+        const u32x4 q0 = g[0], q1 = g[1], q2 = g[2], q3 = g[3];
+        const uint32_t klo = (uint32_t)kmer, khi = (uint32_t)(kmer >> 32);
+        const bool h0 = q0.w == 0 || (q0.x == klo && q0.y == khi), h1s = q1.w == 0 || (q1.x == klo && q1.y == khi);
+        const bool h2 = q2.w == 0 || (q2.x == klo && q2.y == khi), h3 = q3.w == 0 || (q3.x == klo && q3.y == khi);
+        if (h0 | h1s | h2 | h3) {
+            const u32x4 s = h0 ? q0 : h1s ? q1 : h2 ? q2 : q3;
+            if (s.w != 0) {
+                start = s.z;
+                cnt = s.w;
+            }
+            return;
+        }
+        i = (i + PROBE_GROUP) & tmask;
+    }
     for (;;) {
         const u32x4 s = *reinterpret_cast<const u32x4*>(&tab[i]);
         if (s.w == 0) return;
@@ -1040,6 +1056,11 @@ __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
     uint32_t hm[FILL_TILES], rk[FILL_TILES];
 #pragma unroll
     for (int i = 0; i < FILL_TILES; ++i) hm[i] = t0 + i < A.tile_end ? A.truemask[(size_t)(t0 + i) * WAVE + lane] : 0u;
+    // (the kernel is a chain of dependent loads per wave: the tile records do not depend on the masks, so they
+    // are requested with them rather than after the `total == 0` test)
+    TileRec recs[FILL_TILES];
+#pragma unroll
+    for (int i = 0; i < FILL_TILES; ++i) recs[i] = A.tiles[min(t0 + i, A.tile_end - 1)];
     uint32_t total = 0;
 #pragma unroll
     for (int i = 0; i < FILL_TILES; ++i) {
@@ -1053,7 +1074,7 @@ __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
     uint64_t w0[FILL_TILES], w1[FILL_TILES];
 #pragma unroll
     for (int i = 0; i < FILL_TILES; ++i) {
-        const TileRec rec = A.tiles[min(t0 + i, A.tile_end - 1)];
+        const TileRec rec = recs[i];
         t_read[i] = rec.read;
         t_la[i] = rec.la;
         t_word0[i] = rec.word0;
