@@ -80,7 +80,7 @@ typedef struct {
     float ms_total;              /* first kernel start -> last kernel end                   */
     float ms_upload;             /* H2D of the packed read set if this call uploaded it     */
     float ms_scan_probe;         /* the scan kernel alone (k_scan_probe / k_wide_scan count pass), inside ms_scan_count */
-    float reserved0;
+    float ms_verify_kernel;      /* the verify kernel alone (k_verify_a), inside ms_verify; 0 when there was nothing to verify */
 } po_stats;
 
 /* ExactOverlapper()  -- src/overlapper.cpp:19, py::init at src/phasm.cpp:13. */

@@ -58,7 +58,7 @@ class PoStats(ctypes.Structure):
         ("ms_scan_fill", ctypes.c_float), ("ms_verify", ctypes.c_float),
         ("ms_select", ctypes.c_float), ("ms_emit", ctypes.c_float),
         ("ms_total", ctypes.c_float), ("ms_upload", ctypes.c_float),
-        ("ms_scan_probe", ctypes.c_float), ("reserved0", ctypes.c_float),
+        ("ms_scan_probe", ctypes.c_float), ("ms_verify_kernel", ctypes.c_float),
     ]
 
     def as_dict(self) -> dict:

@@ -38,7 +38,7 @@ struct DevBuf {
     }
 };
 
-enum { EV_START = 0, EV_INDEX, EV_COUNT, EV_FILL, EV_VERIFY, EV_SELECT, EV_EMIT, EV_PROBE0, EV_PROBE1, EV_N };
+enum { EV_START = 0, EV_INDEX, EV_COUNT, EV_FILL, EV_VERIFY, EV_SELECT, EV_EMIT, EV_PROBE0, EV_PROBE1, EV_VER0, EV_VER1, EV_N };
 
 }  // namespace
 
@@ -474,6 +474,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         if (!strcmp(e, "narrow")) wide = false;
     }
     S.wide_index = wide ? 1u : 0u;
+    bool ver_timed = false;  // the verify kernel ran (there were candidates): its own events are valid
     const uint64_t n_keys = wide ? n_elig * W : n_elig;
     // ---- sizes
     uint32_t tbits = 10;
@@ -742,11 +743,14 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             const size_t ver_lds = (size_t)lds_words * 8 + (size_t)po::VREC_CAP * sizeof(po::VRec) + 16;
             if (ver_lds > 48 * 1024)
                 HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(verify), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ver_lds));
+            HIP_TRY(h, hipEventRecord(h->ev[EV_VER0], st));
             hipLaunchKernelGGL(verify, dim3(ver_grid), dim3(po::VER_BLOCK), ver_lds, st,
                                words, woff, len, h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_p,
                                A.cand_b, r_begin, lds_words, paired,
                                h->n_exc_uploaded ? h->d_exc_off.as<uint32_t>() : nullptr, h->d_exc_pos.as<uint32_t>(),
                                h->d_exc_byte.as<uint8_t>(), h->d_type.as<uint8_t>(), perm, n_a);
+            HIP_TRY(h, hipEventRecord(h->ev[EV_VER1], st));
+            ver_timed = true;
         }
         HIP_TRY(h, hipGetLastError());
 #ifdef PO_VSTAMPS
@@ -867,6 +871,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     (void)hipEventElapsedTime(&S.ms_emit, h->ev[EV_SELECT], h->ev[EV_EMIT]);
     (void)hipEventElapsedTime(&S.ms_total, h->ev[EV_START], h->ev[EV_EMIT]);
     (void)hipEventElapsedTime(&S.ms_scan_probe, h->ev[EV_PROBE0], h->ev[EV_PROBE1]);
+    S.ms_verify_kernel = 0.f;
+    if (ver_timed) (void)hipEventElapsedTime(&S.ms_verify_kernel, h->ev[EV_VER0], h->ev[EV_VER1]);
     return PO_OK;
 }
 
