@@ -1039,28 +1039,29 @@ __global__ void k_add_extra(uint32_t* __restrict__ tile_count, const uint32_t* _
 // tile_off[first tile]; pooling the hits of several tiles fills the 64-entry probe rounds and turns
 // four short latency chains into one.
 #ifndef PO_FILL_TILES
-#define PO_FILL_TILES 4
+#define PO_FILL_TILES 8
 #endif
 constexpr int FILL_TILES = PO_FILL_TILES;
 
 template <int BITS>
 __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
     constexpr int W = 64 / BITS;
-    __shared__ uint64_t q_kmer[4 * WAVE];
     __shared__ uint32_t q_src[4 * WAVE];
+    __shared__ TileRec q_rec[4 * FILL_TILES];
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    uint64_t* qk = q_kmer + wave * WAVE;
     uint32_t* qs = q_src + wave * WAVE;
+    TileRec* qr = q_rec + wave * FILL_TILES;
     const uint32_t t0 = __builtin_amdgcn_readfirstlane(A.tile_begin + (blockIdx.x * 4 + wave) * FILL_TILES);
     if (t0 >= A.tile_end) return;
+    // The kernel is a chain of dependent loads per wave (SQ_WAIT_ANY: 73 % of its wave-cycles), so its time is the
+    // number of waves per wave slot times the links of that chain.  Masks and tile records do not depend on each
+    // other and are requested together; a hit fetches its own two words (the lanes used to hold the words of
+    // every tile: 4 registers per tile, which capped the tiles per wave at 4).
     uint32_t hm[FILL_TILES], rk[FILL_TILES];
 #pragma unroll
     for (int i = 0; i < FILL_TILES; ++i) hm[i] = t0 + i < A.tile_end ? A.truemask[(size_t)(t0 + i) * WAVE + lane] : 0u;
-    // (the kernel is a chain of dependent loads per wave: the tile records do not depend on the masks, so they
-    // are requested with them rather than after the `total == 0` test)
-    TileRec recs[FILL_TILES];
-#pragma unroll
-    for (int i = 0; i < FILL_TILES; ++i) recs[i] = A.tiles[min(t0 + i, A.tile_end - 1)];
+    if (lane < (uint32_t)FILL_TILES) qr[lane] = A.tiles[min(t0 + lane, A.tile_end - 1)];
+    uint32_t out = A.tile_off[t0];
     uint32_t total = 0;
 #pragma unroll
     for (int i = 0; i < FILL_TILES; ++i) {
@@ -1070,52 +1071,29 @@ __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
         total += read_last_lane(incl);
     }
     if (total == 0) return;
-    uint32_t t_read[FILL_TILES], t_la[FILL_TILES], t_word0[FILL_TILES];
-    uint64_t w0[FILL_TILES], w1[FILL_TILES];
-#pragma unroll
-    for (int i = 0; i < FILL_TILES; ++i) {
-        const TileRec rec = recs[i];
-        t_read[i] = rec.read;
-        t_la[i] = rec.la;
-        t_word0[i] = rec.word0;
-        w0[i] = 0;
-        w1[i] = 0;
-        if (hm[i]) {
-            w0[i] = A.words[rec.wabs + lane];
-            w1[i] = A.words[rec.wabs + lane + 1];
-        }
-    }
-    uint32_t out = A.tile_off[t0];
     for (uint32_t r0 = 0; r0 < total; r0 += WAVE) {
 #pragma unroll
         for (int i = 0; i < FILL_TILES; ++i) {
             while (hm[i] && rk[i] < r0 + WAVE) {
                 const uint32_t sft = __ffs(hm[i]) - 1;
                 hm[i] &= hm[i] - 1;
-                qk[rk[i] - r0] = funnel(w0[i], w1[i], sft * BITS) & A.kmask;
                 qs[rk[i] - r0] = ((uint32_t)i << 16) | (lane << 8) | sft;
                 ++rk[i];
             }
         }
-        wave_lds_fence();
+        wave_lds_fence();  // (also orders the tile records written above before their first use)
         const bool has = r0 + lane < total;
-        const uint64_t kmer = qk[lane];
-        const uint32_t src = qs[lane];
+        const uint32_t src = has ? qs[lane] : 0u;
+        const TileRec rec = qr[src >> 16];
         wave_lds_fence();
+        const uint32_t ln = (src >> 8) & 255u, sft = src & 255u;
         uint32_t z = 0, w = 0;
-        if (has) table_probe(A.table, A.tbits, kmer, z, w);
-        // the entry's tile: read, length, position
-        const uint32_t ti = src >> 16;
-        uint32_t a = t_read[0], la = t_la[0], word0 = t_word0[0];
-#pragma unroll
-        for (int i = 1; i < FILL_TILES; ++i) {
-            if (ti == (uint32_t)i) {
-                a = t_read[i];
-                la = t_la[i];
-                word0 = t_word0[i];
-            }
+        if (has) {
+            const uint64_t w0 = A.words[rec.wabs + ln], w1 = A.words[rec.wabs + ln + 1];
+            table_probe(A.table, A.tbits, funnel(w0, w1, sft * BITS) & A.kmask, z, w);
         }
-        const uint32_t p = (word0 + ((src >> 8) & 255u)) * W + (src & 255u);
+        const uint32_t a = rec.read, la = rec.la;
+        const uint32_t p = (rec.word0 + ln) * W + sft;
         uint32_t n = 0;
         if (w) for_each_candidate(A.chain, A.len, A.paired, z, w, a, la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
         const uint32_t inc = wave_incl_scan(n);
