@@ -686,7 +686,10 @@ __device__ inline void for_each_candidate(const uint32_t* __restrict__ chain, co
 // Positions that cannot be settled from registers (a third table slot, a chain of several reads, a
 // 65th survivor) go to a per-wave leftover list and are settled afterwards by k_scan_fixup.
 // Out: truemask[tile][lane] bit s = position has candidates; tile_count[tile] = their number.
-constexpr uint32_t LEFT_CAP = 2048;   // deferred positions per scan wave before it falls back to resolving them in place
+#ifndef PO_LEFT_CAP
+#define PO_LEFT_CAP 2048
+#endif
+constexpr uint32_t LEFT_CAP = PO_LEFT_CAP;   // deferred positions per scan wave before it falls back to resolving them in place
 constexpr int SCAN_LDS_PER_WAVE = 2 * WAVE * 4 + WAVE * 4;  // queue of positions (two rounds), result masks
 #ifdef PO_STAMPS
 #define PO_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)

@@ -219,6 +219,58 @@ def test_scan_pipeline_many_tiles_per_wave(waves, monkeypatch):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("mult,waves", [("1.5", "16"), ("1.5", "2"), ("40", "16")])
+def test_crowded_and_sparse_anchor_table(mult, waves, monkeypatch, capfd):
+    """The narrow anchor table is probed in aligned groups of four slots; a probe whose group is taken by other
+    keys goes to the leftover list (k_scan_fixup) or, when that is full, is resolved in place.  1.5 slots per key
+    crowds the groups (2000 keys in 4096 slots: about one group in ten is full), 40 leaves them almost empty."""
+    monkeypatch.setenv("PHASM_TABLE_MULT", mult)
+    monkeypatch.setenv("PHASM_SCAN_WAVES", waves)
+    monkeypatch.setenv("PHASM_DEBUG_LEFT", "1")
+    for name in ("cfg2_1k", "cfg1_full"):
+        _, seqs, m, want = gu.ladder_case(name)
+        got, _ = hip_rows(seqs, m)
+        assert np.array_equal(got, want)
+    err = capfd.readouterr().err
+    deferred = [int(ln.split("deferred")[1].split()[0]) for ln in err.splitlines() if ln.startswith("[left]")]
+    assert deferred, "PHASM_DEBUG_LEFT printed nothing"
+    if mult == "1.5":
+        assert max(deferred) > 0      # the crowded table did exercise the leftover path
+
+
+def test_full_leftover_list_resolves_in_place(tmp_path):
+    """A scan wave whose leftover list is full settles hard positions on the spot (synchronous probes inside the
+    pipeline).  The list holds 2048 entries per wave, which no test input fills: build the library with room for 8
+    (hipcc is on the GPU box) and run two goldens through it in a child process."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = str(tmp_path / "libphasm_overlap_cap8.so")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DPO_LEFT_CAP=8", "-o", lib,
+                    os.path.join(root, "phasm_amd", "csrc", "c_api.hip")], check=True, timeout=900,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import golden_utils as gu\n"
+        "from test_gpu_parity import hip_rows\n"
+        "for name in ('cfg2_1k', 'ladder_cfg2_mini', 'cfg1_full'):\n"
+        "    _, seqs, m, want = gu.ladder_case(name)\n"
+        "    got, _ = hip_rows(seqs, m)\n"
+        "    assert np.array_equal(got, want), name\n"
+        "print('CAP8 OK')\n" % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, PHASM_LIB=lib, PHASM_TABLE_MULT="1.5", PHASM_SCAN_WAVES="2", PHASM_DEBUG_LEFT="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "CAP8 OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    caps = [ln for ln in out.stderr.splitlines() if ln.startswith("[left]")]
+    assert caps and all("cap 8" in ln for ln in caps), caps[:3]       # the variant library was the one that ran
+    assert any("max 8 per wave" in ln for ln in caps), caps[:6]       # and some wave's list did fill up
+
+
 def test_long_reads_take_the_global_verify_path():
     """Reads longer than the 64 KB LDS staging limit (262 144 bases at 2 bit) are compared straight
     from global memory."""
