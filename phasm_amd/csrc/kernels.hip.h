@@ -1708,29 +1708,36 @@ __global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __
 // when every read 2i+1 is the reverse complement of read 2i):
 //   A (a, b, la-l, la, 0, l)   <->  (b^1, a^1, lb-l, lb, 0, l)
 //   B (a, b, p, p+lb, 0, lb)   <->  (a^1, b^1, la-p-lb, la-p, 0, lb)
+// ceil(l * bits / 8) for bits in {2, 8} without 64-bit arithmetic (v_mad_u64_u32 issues at a quarter of the rate)
+__device__ inline uint32_t packed_bytes(uint32_t l, uint32_t bits) { return bits == 8u ? l : (l >> 2) + ((l & 3u) != 0u); }
+
 __device__ inline void write_rows(Row* __restrict__ rows, uint32_t off, uint32_t t, uint32_t a, uint32_t p, uint32_t b,
                                   uint32_t la, uint32_t lb, uint32_t bits, uint32_t paired, uint64_t& suml,
                                   uint64_t& sumb) {
+    // (the counters grow by one row's worth next to each row store: sums of k * l as 64-bit products or shifts
+    // issue at a quarter of the rate)
     if (t & 1u) {
         const uint32_t l = la - p;
-        uint32_t k = 1;
+        const uint64_t two_pb = 2ull * packed_bytes(l, bits);
         rows[off++] = Row{a, b, (int32_t)p, (int32_t)la, 0, (int32_t)l};
+        suml += l;
+        sumb += two_pb;
         if (paired && a != (b ^ 1u)) {
             rows[off++] = Row{b ^ 1u, a ^ 1u, (int32_t)(lb - l), (int32_t)lb, 0, (int32_t)l};
-            k = 2;
+            suml += l;
+            sumb += two_pb;
         }
-        suml += (uint64_t)k * l;
-        sumb += (uint64_t)k * 2ull * (((uint64_t)l * bits + 7) / 8);
     }
     if (t & 2u) {
-        uint32_t k = 1;
+        const uint64_t two_pb = 2ull * packed_bytes(lb, bits);
         rows[off++] = Row{a, b, (int32_t)p, (int32_t)(p + lb), 0, (int32_t)lb};
+        suml += lb;
+        sumb += two_pb;
         if (paired) {
             rows[off++] = Row{a ^ 1u, b ^ 1u, (int32_t)(la - p - lb), (int32_t)(la - p), 0, (int32_t)lb};
-            k = 2;
+            suml += lb;
+            sumb += two_pb;
         }
-        suml += (uint64_t)k * lb;
-        sumb += (uint64_t)k * 2ull * (((uint64_t)lb * bits + 7) / 8);
     }
 }
 
