@@ -1294,6 +1294,17 @@ struct __attribute__((aligned(16))) VRec {
     uint32_t wo;  // first 64-bit word of b in words[] (the host checks that it fits 32 bits)
 };
 
+// value of the group's first lane in every lane of the group: a 16-lane group is a DPP row (row_newbcast:0, one
+// VALU op) -- no ds_bpermute round trip behind the LDS atomic that drew the value
+__device__ __forceinline__ uint32_t group_bcast0(uint32_t v, uint32_t gshift) {
+    if constexpr (VER_GROUP == 16) {
+        (void)gshift;
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150, 0xf, 0xf, false);
+    } else {
+        return (uint32_t)__shfl((int)v, (int)gshift);
+    }
+}
+
 template <int BITS, bool SCRAMBLED, bool IN_LDS, bool STAGED>
 __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
                                            const uint32_t* __restrict__ len, const uint32_t* __restrict__ cand_p,
@@ -1356,7 +1367,7 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
             wo = r.wo;
             uint32_t drawn = 0;
             if (sub == 0) drawn = atomicAdd(s_next, 1u);
-            cA = __shfl(drawn, (int)gshift);  // lane 0 of the group drew for all 16
+            cA = group_bcast0(drawn, gshift);  // lane 0 of the group drew for all 16
         } else {
             p = m0p;
             b = m0b;
@@ -1371,7 +1382,7 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
             m0w = woff[m1b];
             uint32_t drawn = 0;
             if (sub == 0) drawn = atomicAdd(s_next, 1u);
-            cB = __shfl(drawn, (int)gshift);  // lane 0 of the group drew for all 16
+            cB = group_bcast0(drawn, gshift);  // lane 0 of the group drew for all 16
             const uint32_t c2 = min(cB, c_last);
             m1p = cand_p[c2];
             m1b = cand_b[c2];
