@@ -532,6 +532,31 @@ def test_many_identical_and_nested_reads():
             assert np.array_equal(got, want), (len(seqs), m, "4 shards")
 
 
+@pytest.mark.parametrize("n_b,strands", [(100, 1), (100, 2), (240, 1), (240, 2)])
+def test_tiles_with_more_survivors_than_one_probe_round(n_b, strands, capfd, monkeypatch):
+    """One long read and n_b shorter ones that start at consecutive bases inside one 2048-base scan tile of it: that
+    tile has n_b TRUE filter survivors -- more than the 64 one probe round settles (second round: 65..128), and with
+    240 more than the two rounds together (the rest goes through the leftover list)."""
+    monkeypatch.setenv("PHASM_DEBUG_LEFT", "1")
+    rng = np.random.default_rng(77 + n_b)
+    g = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=9000))
+    reads = [g[:8000]] + [g[2100 + i:2100 + i + 1500 + (i % 7)] for i in range(n_b)] + [g[5000:9000]]
+    rc = bytes.maketrans(b"ACGT", b"TGCA")
+    seqs = []
+    for r in reads:
+        seqs += [r] if strands == 1 else [r, r.translate(rc)[::-1]]
+    want = oo.oracle_overlaps(seqs, 1000)
+    assert len(want) > n_b * n_b // 4
+    got, st = hip_rows(seqs, 1000)
+    assert st["wide_index"] == 0
+    assert np.array_equal(got, want)
+    got, _ = hip_rows(seqs, 1000, shard=3)
+    assert np.array_equal(got, want)
+    deferred = [int(ln.split("deferred")[1].split()[0]) for ln in capfd.readouterr().err.splitlines() if ln.startswith("[left]")]
+    if n_b > 128:
+        assert max(deferred) >= n_b - 128      # survivors 129.. of that tile took the leftover path
+
+
 def test_many_identical_reads_wide_index(monkeypatch):
     monkeypatch.setenv("PHASM_INDEX", "wide")
     rng = np.random.default_rng(321)
