@@ -1294,6 +1294,18 @@ struct __attribute__((aligned(16))) VRec {
     uint32_t wo;  // first 64-bit word of b in words[] (the host checks that it fits 32 bits)
 };
 
+// fetch-and-increment of an LDS counter by the lanes that call it.  Spelled as the instruction: for a plain
+// atomicAdd hipcc builds the wave-aggregated form (two v_mbcnt, a compare, one ds_add_rtn of the lane count,
+// v_readfirstlane, an add) -- right for 64 callers, six extra instructions in the verify kernel's completion path
+// for the one to four that call here
+__device__ __forceinline__ uint32_t lds_draw(uint32_t* counter) {
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const uint32_t addr = (uint32_t)(uintptr_t)(lds_u32*)counter;
+    uint32_t old, one = 1u;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(addr), "v"(one) : "memory");
+    return old;
+}
+
 // value of the group's first lane in every lane of the group: a 16-lane group is a DPP row (row_newbcast:0, one
 // VALU op) -- no ds_bpermute round trip behind the LDS atomic that drew the value
 __device__ __forceinline__ uint32_t group_bcast0(uint32_t v, uint32_t gshift) {
@@ -1366,7 +1378,7 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
             lb = r.nk;
             wo = r.wo;
             uint32_t drawn = 0;
-            if (sub == 0) drawn = atomicAdd(s_next, 1u);
+            if (sub == 0) drawn = lds_draw(s_next);
             cA = group_bcast0(drawn, gshift);  // lane 0 of the group drew for all 16
         } else {
             p = m0p;
@@ -1381,7 +1393,7 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
             m0l = len[m1b];
             m0w = woff[m1b];
             uint32_t drawn = 0;
-            if (sub == 0) drawn = atomicAdd(s_next, 1u);
+            if (sub == 0) drawn = lds_draw(s_next);
             cB = group_bcast0(drawn, gshift);  // lane 0 of the group drew for all 16
             const uint32_t c2 = min(cB, c_last);
             m1p = cand_p[c2];
