@@ -1345,6 +1345,7 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
     // per candidate: nbits = compared bits, q = first dword of a's window, sh = its bit offset,
     // d = this lane's first dword of b in the current step, keep = rows it can give
     uint32_t nbits = 0, sh = 0, q = 0, d = 0, keep = 0, nblk_var = 1, cur_p = 0, cur_b = 0;
+    uint32_t nd = 0;  // dwords of b to compare = ceil(nbits / 32): block j of a step is this lane's iff d + j * BLK < nd
     // every step covers VER_BLOCKS blocks unless a shorter first step is configured (PO_VER_FIRST): since the
     // locality order keeps b in L2, reading 768 bytes of a candidate that dies in its first 256 costs less than the
     // extra iteration the survivors would need (1.09 -> 1.06 ms)
@@ -1411,6 +1412,7 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
         }
         cur_p = p;
         cur_b = b;
+        nd = (nbits + 31u) >> 5;
         const uint64_t bitpos = (uint64_t)p * BITS;
         q = (uint32_t)(bitpos >> 5);
         sh = (uint32_t)(bitpos & 31);
@@ -1456,13 +1458,14 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
         VST(vt[5] += 1; vt[7] += __popcll(__ballot(have && sub == 0));)
         if (have) {
             u32x4 bv[VER_BLOCKS];
+            const int32_t rem = (int32_t)(nd - d);  // dwords from this lane's first one to the end of the range (<= 0: none)
 #pragma unroll
             for (int j = 0; j < VER_BLOCKS; ++j)  // b starts 16-byte aligned
-                if ((uint32_t)j < (UNIFORM_STEPS ? (uint32_t)VER_BLOCKS : nblk_var) && (d + j * BLK) * 32 < nbits) bv[j] = *reinterpret_cast<const u32x4*>(B + d + j * BLK);
+                if ((uint32_t)j < (UNIFORM_STEPS ? (uint32_t)VER_BLOCKS : nblk_var) && rem > (int32_t)(j * BLK)) bv[j] = *reinterpret_cast<const u32x4*>(B + d + j * BLK);
             VST(__builtin_amdgcn_s_waitcnt(0); { const unsigned long long t = __builtin_amdgcn_s_memtime(); vt[1] += t - vt_prev; vt_prev = t; })
 #pragma unroll
             for (int j = 0; j < VER_BLOCKS; ++j)
-                if ((uint32_t)j < (UNIFORM_STEPS ? (uint32_t)VER_BLOCKS : nblk_var) && (d + j * BLK) * 32 < nbits) diff |= cmp16(d + j * BLK, bv[j]);
+                if ((uint32_t)j < (UNIFORM_STEPS ? (uint32_t)VER_BLOCKS : nblk_var) && rem > (int32_t)(j * BLK)) diff |= cmp16(d + j * BLK, bv[j]);
         }
         const uint64_t bal = __ballot(diff != 0);
         VST({ const unsigned long long t = __builtin_amdgcn_s_memtime(); vt[2] += t - vt_prev; vt_prev = t; })
@@ -1470,7 +1473,7 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
             const bool mismatch = ((bal >> gshift) & (VER_GROUP >= 64 ? ~0ull : ((1ull << (VER_GROUP & 63)) - 1ull))) != 0;
             d += (UNIFORM_STEPS ? (uint32_t)VER_BLOCKS : nblk_var) * BLK;
             nblk_var = VER_BLOCKS;
-            if (mismatch || (d - 4 * sub) * 32 >= nbits) {  // group-uniform: candidate finished
+            if (mismatch || d - 4 * sub >= nd) {  // group-uniform: candidate finished
                 if (sub == 0) {
                     uint32_t t = mismatch ? 0u : keep;
                     // 2-bit reads with exception records (non-ACGT bytes, stored as code 0): the packed
