@@ -1522,8 +1522,9 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
     } else if (blockIdx.x >= n_a) {
         return;
     }
-    const uint32_t seg0 = tile_off[read_tile0[a]], seg1 = tile_off[read_tile0[a + 1]];
-    if (seg0 == seg1) return;
+    // (the words of a are requested before the candidate range is known: the range hangs on two dependent loads,
+    // read_tile0 -> tile_off, and a read without candidates is rare)
+    const uint32_t t0 = read_tile0[a], t1 = read_tile0[a + 1];
     const uint32_t la = len[a];
     const uint32_t nwa = (la + W - 1) / W;
     const uint64_t* __restrict__ ga = words + woff[a];
@@ -1535,6 +1536,8 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
     constexpr uint32_t NGROUPS = VER_BLOCK / VER_GROUP;
     if (in_lds)
         for (uint32_t i = threadIdx.x; i < nwa + 3; i += VER_BLOCK) s_a64[i] = ga[i];
+    const uint32_t seg0 = tile_off[t0], seg1 = tile_off[t1];
+    if (seg0 == seg1) return;  // (workgroup-uniform)
     const uint32_t* __restrict__ s_a = reinterpret_cast<const uint32_t*>(s_a64);
     const uint32_t* __restrict__ ga32 = reinterpret_cast<const uint32_t*>(ga);
     if constexpr (STAGED) {
