@@ -886,7 +886,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
             wave_lds_fence();
             truemask[(size_t)prev_t * WAVE + lane] = tm[lane];  // each lane owns the mask of its word
             tm[lane] = 0;
-            n = wave_sum(n);
+            // a lane settles one survivor with one candidate, unless it resolved a chain in place (leftover list full):
+            // the tile's count is a popcount of a ballot almost always
+            n = __any(n > 1u) ? wave_sum(n) : (uint32_t)__popcll(__ballot(n != 0u));
             if (lane == 0) tile_count[prev_t] = n;
         }
         PO_STAMP(st4);
