@@ -102,10 +102,12 @@ __device__ inline uint32_t read_last_lane(uint32_t v) { return __builtin_amdgcn_
 // k_scan_probe's retire step.)
 __device__ inline uint32_t wave_sum(uint32_t v) { return read_last_lane(wave_incl_scan(v)); }
 
+// 64-bit wave total from four 16-bit slices (each slice's total fits 22 bits), all through the DPP scan: exact
+// modulo 2^64 and no ds_bpermute (a 64-bit butterfly is twelve of them, one after the other)
 __device__ inline uint64_t wave_sum64(uint64_t v) {
-#pragma unroll
-    for (int d = WAVE / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
-    return v;
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    const uint64_t s0 = wave_sum(lo & 0xFFFFu), s1 = wave_sum(lo >> 16), s2 = wave_sum(hi & 0xFFFFu), s3 = wave_sum(hi >> 16);
+    return s0 + (s1 << 16) + (s2 << 32) + (s3 << 48);
 }
 
 // LDS hand-off between lanes of ONE wave: DS ops of a wave execute in issue order; this only has
@@ -1916,9 +1918,24 @@ __global__ __launch_bounds__(PS_BLOCK) void k_ps_reduce(const T* __restrict__ in
     __shared__ uint64_t s_part[PS_BLOCK / WAVE];
     const uint64_t base = (uint64_t)blockIdx.x * PS_TILE;
     uint64_t acc = 0;
-    for (int k = 0; k < PS_ITEMS; ++k) {
-        const uint64_t i = base + (uint64_t)k * PS_BLOCK + threadIdx.x;
-        if (i < n) acc += in[i];
+    const uint64_t first = base + (uint64_t)threadIdx.x * PS_ITEMS;   // this thread's PS_ITEMS consecutive items
+    if (first + PS_ITEMS <= n && (reinterpret_cast<uintptr_t>(in + first) & 15u) == 0) {
+        // whole, 16-byte aligned chunk: 16-byte loads (a u8 input is one load per thread instead of sixteen)
+        const u32x4* src = reinterpret_cast<const u32x4*>(in + first);
+#pragma unroll
+        for (int k = 0; k < (int)(PS_ITEMS * sizeof(T) / 16); ++k) {
+            const u32x4 q = src[k];
+            if constexpr (sizeof(T) == 1) {
+                const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += (d[j] & 0xFFu) + ((d[j] >> 8) & 0xFFu) + ((d[j] >> 16) & 0xFFu) + (d[j] >> 24);
+            } else {
+                acc += (uint64_t)q.x + q.y + q.z + q.w;
+            }
+        }
+    } else {
+        for (int k = 0; k < PS_ITEMS; ++k)
+            if (first + k < n) acc += in[first + k];
     }
     acc = wave_sum64(acc);
     if (lane_id() == 0) s_part[threadIdx.x >> 6] = acc;
