@@ -699,24 +699,17 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             // locality order of the a-side reads (k_read_label): worth its ~50 us only when the verify is long
             const uint32_t n_a = r_end - r_begin;
             const uint32_t* perm = nullptr;
-            // (whole-set calls only: a shard holds 1/N of every neighbourhood, the clusters get too small to pay
-            // for the sort -- measured 0.67 -> 0.76 ms at 2 shards, 0.19 -> 0.25 ms at 8)
-            bool use_order = nshards == 1 && n_cand >= 400000 && n_a >= 4096;
+            // (sharded calls too: 0.65 -> 0.51 ms at 2 shards, 0.19 -> 0.17 at 8 -- once the label of a read ranked by
+            // the scrambled order was turned back into a read index, see k_read_label)
+            bool use_order = n_cand >= 400000 && n_a >= 4096;
             if (const char* e = getenv("PHASM_VERIFY_ORDER")) use_order = atoi(e) != 0;
             if (use_order) {
                 // bins of label >> shift, as many as fit into one workgroup's LDS.  Labels are read indices
                 // (whole-set calls) or 32-bit scrambled ranks (sharded calls)
                 const uint32_t max_bins = (uint32_t)((std::min<size_t>(h->lds_max, 160 * 1024) - 1024) / 4);
                 uint32_t shift = 0, n_bins;
-                if (paired == 2u) {
-                    uint32_t k = 10;
-                    while ((2u << k) <= max_bins) ++k;
-                    shift = 32 - k;
-                    n_bins = 1u << k;
-                } else {
-                    while ((n >> shift) + 1 > max_bins) ++shift;
-                    n_bins = (n >> shift) + 1;
-                }
+                while ((n >> shift) + 1 > max_bins) ++shift;   // labels are read indices in both pairing modes
+                n_bins = (n >> shift) + 1;
                 const size_t sort_lds = ((size_t)n_bins + po::SORT_BLOCK / 64) * 4;
                 PO_TRY(ensure(h, h->d_vlabel, (size_t)n_a * 4));
                 PO_TRY(ensure(h, h->d_vperm, (size_t)n_a * 4));

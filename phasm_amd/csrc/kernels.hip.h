@@ -1150,6 +1150,10 @@ __global__ __launch_bounds__(256) void k_read_label(const uint32_t* __restrict__
     for (uint32_t c = seg0 + sub; c < seg1; c += 16) best = max(best, mirror_rank(cand_b[c] ^ 1u, paired));
 #pragma unroll
     for (int o = 8; o >= 1; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o, 16));
+    // the label is the top-ranked READ, whatever order ranked it: a scrambled rank (sharded calls) is turned back
+    // into the read index, so that the sort's bins hold a few neighbouring indices in both modes -- binning the
+    // scrambled rank's top bits put the 256 reads of an index block into one bin and lost the locality
+    if (paired == 2u) best = (__brev(best & 0xFFFFFF00u) << 8) | (best & 0xFFu);
     if (sub == 0) label[i] = best;
 }
 
@@ -1353,8 +1357,7 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
     // every step covers VER_BLOCKS blocks unless a shorter first step is configured (PO_VER_FIRST): since the
     // locality order keeps b in L2, reading 768 bytes of a candidate that dies in its first 256 costs less than the
     // extra iteration the survivors would need (1.09 -> 1.06 ms)
-    // (sharded calls run without the locality order: their first step stays at one block)
-    constexpr bool UNIFORM_STEPS = PO_VER_FIRST == PO_VER_BLOCKS && !SCRAMBLED;
+    constexpr bool UNIFORM_STEPS = PO_VER_FIRST == PO_VER_BLOCKS;
     const uint32_t* B = reinterpret_cast<const uint32_t*>(words);
     // (!STAGED only) Candidate metadata runs two candidates ahead of the compare loop, so that a group starting a
     // new candidate has (p, b, len[b], woff[b]) in registers already: m0 = the next candidate to
@@ -1422,7 +1425,7 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
         sh = (uint32_t)(bitpos & 31);
         B = reinterpret_cast<const uint32_t*>(words + wo);
         d = 4 * sub;
-        nblk_var = SCRAMBLED ? 1 : PO_VER_FIRST;  // first step (a wrong-haplotype candidate dies in its first 256 bytes);
+        nblk_var = PO_VER_FIRST;  // first step (a wrong-haplotype candidate dies in its first 256 bytes);
                    // all loads of a step are issued before its first compare
     };
     // compare this lane's 16 bytes of b at dword dd with the facing window of a

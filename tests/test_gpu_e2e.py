@@ -71,43 +71,61 @@ def test_merge_helper_single_gpu():
     ov.close()
 
 
+_RCCL_CHILD = r"""
+import os, socket, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import golden_utils as gu
+from oracle import overlap_oracle as oo
+from phasm_amd.dist import CandidateExchange, rows_tensor_to_struct, sharded_overlaps
+from phasm_amd.overlapper import ExactOverlapper
+with socket.socket() as sk:          # a port nobody holds, instead of a fixed one
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = str(port)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+try:
+    _, seqs, m, want = gu.ladder_case("ladder_cfg2_mini")
+    ov = ExactOverlapper(device=0)
+    for i, s in enumerate(seqs):
+        ov.add_sequence("r%%d" %% i, s)
+    t = sharded_overlaps(ov, m, device=dev)
+    whole = ov.overlaps_array(m)
+    assert np.array_equal(rows_tensor_to_struct(t), whole)
+    assert np.array_equal(oo.sort_rows(oo.struct_to_rows(whole)), want)
+    # the repeated-step form: first step sizes the slot (a stricter min_length: fewer candidates), the second
+    # outgrows it (slot grows in the middle of the step), the third and fourth write straight into the slot
+    ex = CandidateExchange(ov, device=dev, slack=1.0)
+    r0 = ex.rows(4 * m)
+    assert len(r0) < len(whole)
+    r0.free()
+    for _ in range(3):
+        r = ex.rows(m)
+        assert np.array_equal(r.rows(), whole)
+        r.free()
+    assert ex.n_collectives == 2 + 2 + 1 + 1
+    ov.close()
+finally:
+    dist.destroy_process_group()
+print("RCCL OK")
+"""
+
+
 def test_rccl_collectives_one_rank_group():
     """The N>1 merge goes through RCCL (`nccl` backend).  A one-rank process group on this GPU runs the
-    very same calls (count all-gather, padded all_gather_into_tensor of int32[n,4], expansion)."""
-    import torch.distributed as dist
-    from phasm_amd.dist import rows_tensor_to_struct, sharded_overlaps
-    import socket
-    with socket.socket() as sk:          # a port nobody holds, instead of a fixed one
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dev = torch.device("cuda", 0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    try:
-        _, seqs, m, want = gu.ladder_case("ladder_cfg2_mini")
-        ov = ExactOverlapper(device=0)
-        for i, s in enumerate(seqs):
-            ov.add_sequence("r%d" % i, s)
-        t = sharded_overlaps(ov, m, device=dev)
-        whole = ov.overlaps_array(m)
-        assert np.array_equal(rows_tensor_to_struct(t), whole)
-        assert np.array_equal(oo.sort_rows(oo.struct_to_rows(whole)), want)
-        # the repeated-step form: first step sizes the slot (a stricter min_length: fewer candidates), the second
-        # outgrows it (slot grows in the middle of the step), the third and fourth write straight into the slot
-        from phasm_amd.dist import CandidateExchange
-        ex = CandidateExchange(ov, device=dev, slack=1.0)
-        r0 = ex.rows(4 * m)
-        assert len(r0) < len(whole)
-        r0.free()
-        for _ in range(3):
-            r = ex.rows(m)
-            assert np.array_equal(r.rows(), whole)
-            r.free()
-        assert ex.n_collectives == 2 + 2 + 1 + 1
-        ov.close()
-    finally:
-        dist.destroy_process_group()
+    very same calls (count all-gather, padded all_gather_into_tensor of int32[n,4], expansion) -- in a child
+    process: a process group brings RCCL's proxy threads and pinned buffers with it, and the rest of the suite
+    should not share an address space with them."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _RCCL_CHILD % {"root": root, "tests": os.path.join(root, "tests")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0 and "RCCL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 @pytest.mark.skipif(os.environ.get("PHASM_SKIP_FULL") == "1", reason="full-size run disabled")
