@@ -474,6 +474,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         if (!strcmp(e, "narrow")) wide = false;
     }
     S.wide_index = wide ? 1u : 0u;
+    bool rows_late = false;  // rows emitted into a kept buffer before their number reached the host
     bool ver_timed = false;  // the verify kernel ran (there were candidates): its own events are valid
     const uint64_t n_keys = wide ? n_elig * W : n_elig;
     // ---- sizes
@@ -798,12 +799,19 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                            h->d_type.as<uint8_t>(), n_cand, selfrep, ptab, pbits, paired, h->d_rowcnt.as<uint8_t>(),
                            want_cands ? h->d_flag.as<uint8_t>() : nullptr);
         HIP_TRY(h, hipGetLastError());
+        // A candidate gives at most 2 rows (4 with their mirrors).  When the row buffer kept from an earlier call
+        // holds that many, the rows are emitted without asking the host for their number first (one host round
+        // trip less per step); the number arrives with the counters at the end.
+        const uint64_t worst_rows = (uint64_t)n_cand * (paired ? 4u : 2u);
         if (!want_cands) {
             PO_TRY(prefix_sum<uint8_t>(h, h->d_rowcnt.as<uint8_t>(), n_cand, h->d_row_off.as<uint32_t>(), &h->pinned[2]));
             HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
-            HIP_TRY(h, hipStreamSynchronize(st));
-            n_rows64 = h->pinned[2];
-            if (n_rows64 >= 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "row count exceeds one call's capacity (2^32)");
+            rows_late = h->spare_rows.p && h->spare_rows.cap >= worst_rows * sizeof(po_row);
+            if (!rows_late) {
+                HIP_TRY(h, hipStreamSynchronize(st));
+                n_rows64 = h->pinned[2];
+                if (n_rows64 >= 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "row count exceeds one call's capacity (2^32)");
+            }
         }
         if (want_cands) {
             // ---- multi-GPU form: hand out the verified candidates (one per strand-mirror pair), compacted
@@ -830,13 +838,18 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             n_rows64 = n_ver;
         } else {
             // ---- emit
-            if (h->spare_rows.cap >= n_rows64 * sizeof(po_row) && h->spare_rows.p) {
+            if (rows_late || (h->spare_rows.cap >= n_rows64 * sizeof(po_row) && h->spare_rows.p)) {
                 res->d_rows = h->spare_rows;
                 h->spare_rows = DevBuf();
             } else {
                 h->spare_rows.release();
             }
-            PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_rows64 * sizeof(po_row), 256)));
+            if (!rows_late) {
+                // (room for the worst case up to 2 GiB, so that the next call of this size need not ask)
+                const size_t exact = n_rows64 * sizeof(po_row);
+                const size_t roomy = worst_rows * sizeof(po_row) <= (2ull << 30) ? (size_t)(worst_rows * sizeof(po_row)) : 0;
+                PO_TRY(ensure(h, res->d_rows, std::max<size_t>(std::max(exact, roomy), 256)));
+            }
             hipLaunchKernelGGL(po::k_emit, dim3(std::min<uint32_t>(cdiv(n_cand, 256), (uint32_t)h->n_cu * 16)), dim3(256), 0,
                                st, A.cand_a, A.cand_p, A.cand_b, h->d_type.as<uint8_t>(), h->d_row_off.as<uint32_t>(),
                                n_cand, len, res->d_rows.as<po::Row>(), (uint32_t)BITS, paired, scalars + 4);
@@ -851,6 +864,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     uint64_t* counters = h->pinned + 4;
     HIP_TRY(h, hipMemcpyAsync(counters, scalars + 4, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
+    if (rows_late) n_rows64 = h->pinned[2];  // (<= worst_rows < 2^32 by construction of the fast path)
     res->count = n_rows64;
     S.n_rows = want_cands ? 0 : n_rows64;
     S.n_verified = want_cands ? n_rows64 : counters[0];
