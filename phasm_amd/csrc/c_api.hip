@@ -904,17 +904,28 @@ po_status run_expand(po_handle* h, const void* d_cands, uint64_t n, po_result* r
     HIP_TRY(h, hipGetLastError());
     PO_TRY(prefix_sum<uint8_t>(h, h->d_rowcnt.as<uint8_t>(), nc, h->d_row_off.as<uint32_t>(), &h->pinned[2]));
     HIP_TRY(h, hipMemcpyAsync(h->pinned + 3, scalars + 3, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipStreamSynchronize(st));
-    if ((uint32_t)h->pinned[3] != 0) return fail(h, PO_ERR_INVALID, "po_expand: candidate array holds invalid entries");
-    const uint64_t n_rows = h->pinned[2];
-    if (n_rows >= 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "row count exceeds one call's capacity (2^32)");
-    if (h->spare_rows.cap >= n_rows * sizeof(po_row) && h->spare_rows.p) {
+    // (as in po_overlaps: a kept row buffer that holds the worst case -- 4 rows per candidate -- is written without
+    // waiting for the count; invalid entries have no rows, so emitting before the check writes nothing for them)
+    const uint64_t worst_rows = (uint64_t)nc * (paired ? 4u : 2u);
+    const bool rows_late = h->spare_rows.p && h->spare_rows.cap >= worst_rows * sizeof(po_row);
+    uint64_t n_rows = 0;
+    if (!rows_late) {
+        HIP_TRY(h, hipStreamSynchronize(st));
+        if ((uint32_t)h->pinned[3] != 0) return fail(h, PO_ERR_INVALID, "po_expand: candidate array holds invalid entries");
+        n_rows = h->pinned[2];
+        if (n_rows >= 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "row count exceeds one call's capacity (2^32)");
+    }
+    if (rows_late || (h->spare_rows.cap >= n_rows * sizeof(po_row) && h->spare_rows.p)) {
         res->d_rows = h->spare_rows;
         h->spare_rows = DevBuf();
     } else {
         h->spare_rows.release();
     }
-    PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_rows * sizeof(po_row), 256)));
+    if (!rows_late) {
+        const size_t exact = n_rows * sizeof(po_row);
+        const size_t roomy = worst_rows * sizeof(po_row) <= (2ull << 30) ? (size_t)(worst_rows * sizeof(po_row)) : 0;
+        PO_TRY(ensure(h, res->d_rows, std::max<size_t>(std::max(exact, roomy), 256)));
+    }
     HIP_TRY(h, hipMemsetAsync(h->d_scalars.p, 0, 64, st));
     hipLaunchKernelGGL(po::k_emit_cands, dim3(std::min<uint32_t>(cdiv(nc, 256), (uint32_t)h->n_cu * 16)), dim3(256), 0, st,
                        cands, h->d_rowcnt.as<uint8_t>(), h->d_row_off.as<uint32_t>(), nc, h->d_len.as<uint32_t>(),
@@ -923,6 +934,10 @@ po_status run_expand(po_handle* h, const void* d_cands, uint64_t n, po_result* r
     HIP_TRY(h, hipEventRecord(h->ev[EV_EMIT], st));
     HIP_TRY(h, hipMemcpyAsync(h->pinned + 4, scalars + 4, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
+    if (rows_late) {
+        if ((uint32_t)h->pinned[3] != 0) return fail(h, PO_ERR_INVALID, "po_expand: candidate array holds invalid entries");
+        n_rows = h->pinned[2];
+    }
     res->count = n_rows;
     S.n_rows = n_rows;
     S.sum_overlap_bases = h->pinned[5];
