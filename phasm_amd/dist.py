@@ -110,7 +110,7 @@ class CandidateExchange:
     (so they always agree on it).  If a shard outgrows the slot the headers say so on every rank at once and the
     step is repeated with a bigger slot.  The first step sizes the slot with a count all-gather."""
 
-    def __init__(self, ov, group=None, device: Optional[torch.device] = None, slack: float = 1.25):
+    def __init__(self, ov, group=None, device: Optional[torch.device] = None, slack: float = 1.1):
         self.ov = ov
         self.group = group
         self.on = dist.is_available() and dist.is_initialized()
