@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PO_ABI_VERSION 1
+#define PO_ABI_VERSION 2
 
 typedef enum {
     PO_OK = 0,
@@ -112,6 +112,12 @@ uint32_t po_get_length(const po_handle* h, uint32_t idx);
  * po_overlaps* call.  Idempotent until the next po_add_sequence.                          */
 po_status po_upload(po_handle* h);
 
+/* Forget the device copy of the read set: the next po_upload / po_overlaps* copies the packed reads host->device
+ * again, as the first call of a fresh process does.  The reference's overlaps() starts from the host-side string
+ * set on every call (index built from `readset`, src/overlapper.cpp:33-36), so ONE reference call corresponds to
+ * po_invalidate + po_upload + po_overlaps + po_result_rows: the region bench.py times. */
+po_status po_invalidate(po_handle* h);
+
 /* overlaps(min_length)  -- src/overlapper.cpp:28-150.  Rows stay on the device until
  * po_result_rows() is called.  Stateless across calls like the reference (index rebuilt per
  * call, :33-36); min_length 0 behaves as 1 (a suffix array has no empty suffix).          */
@@ -147,7 +153,9 @@ po_status po_candidates_shard_into(po_handle* h, uint32_t min_length, uint32_t s
 po_status po_shard_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint32_t* r_begin, uint32_t* r_end);
 
 uint64_t po_result_count(const po_result* r);
-/* Host pointer to po_result_count() rows (copied device->host on first use); NULL on error. */
+/* Host pointer to po_result_count() rows (copied device->host on first use, into page-locked memory owned by the
+ * library: one DMA, valid until po_result_free); NULL on error.  The counterpart of the reference returning its
+ * vector<OverlapT> to the host (src/overlapper.cpp:149). */
 const po_row* po_result_rows(po_result* r);
 /* Device pointer to the same rows (valid until po_result_free). */
 const void* po_result_device_rows(const po_result* r);

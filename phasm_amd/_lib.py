@@ -78,6 +78,7 @@ SYMBOLS = [
     ("po_get_id", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]),
     ("po_get_length", ctypes.c_uint32, [_P, ctypes.c_uint32]),
     ("po_upload", ctypes.c_int, [_P]),
+    ("po_invalidate", ctypes.c_int, [_P]),
     ("po_overlaps", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_overlaps_shard", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_candidates_shard", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),

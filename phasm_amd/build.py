@@ -8,7 +8,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "c_api.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "kernels.hip.h"), os.path.join(ROOT, "include", "phasm_overlap.h")]
+DEPS = ([SRC, os.path.join(ROOT, "include", "phasm_overlap.h")] +
+        sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h")))
 LIB = os.path.join(HERE, "libphasm_overlap.so")
 ARCH = "gfx950"
 

@@ -38,6 +38,19 @@ struct DevBuf {
     }
 };
 
+// host-pinned buffer (hipHostMalloc): every device->host copy of this library lands in one of these, never in
+// pageable heap memory -- the HIP runtime then neither stages the copy nor pins (and caches the pin of) a range
+// of the caller's malloc heap
+struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 enum { EV_START = 0, EV_INDEX, EV_COUNT, EV_FILL, EV_VERIFY, EV_SELECT, EV_EMIT, EV_PROBE0, EV_PROBE1, EV_VER0, EV_VER1, EV_N };
 
 }  // namespace
@@ -84,6 +97,13 @@ struct po_handle {
     DevBuf spare_rows;   // device buffers of freed results, kept for the next call (hipFree / hipMalloc of a
     DevBuf spare_cands;  // 50-170 MB buffer costs ~0.2 ms each and synchronises the device)
     DevBuf spare_edges;
+    HostBuf spare_host;    // pinned row buffer of a freed result, kept for the next po_result_rows
+    HostBuf scratch_host;  // pinned landing zone for small device->host copies into caller memory
+    // the packed host store registered with the HIP runtime (hipHostRegister) while it is unchanged: the H2D of
+    // po_upload then runs at the DMA rate instead of through the runtime's staging buffers
+    void* reg_ptr = nullptr;
+    size_t reg_bytes = 0;
+    int poison = -1;       // PHASM_POISON=<byte>: per-call workspaces are filled with it before every call
     int live_results = 0;
 
     po_stats stats = {};
@@ -102,7 +122,9 @@ struct po_result {
     uint64_t count = 0;
     size_t elem = sizeof(po_row);
     bool kind_edges = false;  // po_edge entries (same size as po_cand)
-    void* host = nullptr;
+    void* host = nullptr;     // host copy of the entries: pinned (hipHostMalloc, host_cap bytes) unless host_malloced
+    size_t host_cap = 0;
+    bool host_malloced = false;  // po_result_from_rows: plain malloc (works without a GPU)
     // po_candidates_shard_into: the caller's buffer the candidates go to when they fit
     void* ext_dst = nullptr;
     uint64_t ext_cap = 0;
@@ -135,7 +157,36 @@ po_status ensure(po_handle* h, DevBuf& b, size_t bytes) {
         return fail(h, PO_ERR_NOMEM, "hipMalloc(" + std::to_string(want) + " bytes): " + hipGetErrorString(e));
     }
     b.cap = want;
+    // PHASM_POISON: a fresh allocation starts out as garbage of the caller's choosing (hipMalloc usually hands out
+    // zeros or whatever an earlier handle of the process left there): a kernel that reads what this call has not
+    // written shows up as a parity failure instead of depending on the history of the process
+    if (h && h->poison >= 0 && h->stream) (void)hipMemsetAsync(b.p, h->poison, want, h->stream);
     return PO_OK;
+}
+
+po_status ensure_host(po_handle* h, HostBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return PO_OK;
+    b.release();
+    const size_t want = bytes + bytes / 16 + 4096;
+    hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(h, PO_ERR_NOMEM, "hipHostMalloc(" + std::to_string(want) + " bytes): " + hipGetErrorString(e));
+    }
+    b.cap = want;
+    return PO_OK;
+}
+
+// the packed host store is about to change (or go away): the runtime must let go of it first
+void unpin_words(po_handle* h) {
+    if (!h->reg_ptr) return;
+    if (h->dev_ready) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+    }
+    (void)hipHostUnregister(h->reg_ptr);
+    h->reg_ptr = nullptr;
+    h->reg_bytes = 0;
 }
 
 #define PO_TRY(expr)                    \
@@ -164,6 +215,7 @@ po_status init_device(po_handle* h) {
     HIP_TRY(h, hipEventCreate(&h->ev_up0));
     HIP_TRY(h, hipEventCreate(&h->ev_up1));
     HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->pinned), 512, hipHostMallocDefault));
+    if (const char* e = getenv("PHASM_POISON")) h->poison = (int)(strtol(e, nullptr, 0) & 0xFF);
     h->dev_ready = true;
     return PO_OK;
 }
@@ -314,28 +366,35 @@ po_status upload(po_handle* h) {
     if (!h->dirty) return PO_OK;
     const uint32_t n = (uint32_t)h->len.size();
     const size_t per = 64 / h->bits;
-    // tiles: 64 words each, never spanning reads
-    std::vector<po::TileRec> tiles;
+    // tiles: 64 words each, never spanning reads.  The host only counts them (first tile of every read); the
+    // 32-byte records are written on the device (k_build_tiles) instead of travelling over PCIe (25 MB at config 2)
     h->h_read_tile0.assign((size_t)n + 1, 0);
     h->max_len = 0;
+    uint64_t nt = 0;
     for (uint32_t r = 0; r < n; ++r) {
-        h->h_read_tile0[r] = (uint32_t)tiles.size();
+        h->h_read_tile0[r] = (uint32_t)nt;
         h->max_len = std::max(h->max_len, h->len[r]);
         const size_t nw = (h->len[r] + per - 1) / per;
-        for (size_t w0 = 0; w0 < nw; w0 += po::TILE_WORDS) {
-            po::TileRec t;
-            t.wabs = h->woff[r] + w0;
-            t.wread = h->woff[r];
-            t.read = r;
-            t.la = h->len[r];
-            t.word0 = (uint32_t)w0;
-            t.pad = 0;
-            tiles.push_back(t);
-        }
-        if (tiles.size() > 0x7FFFFF00ull / po::WAVE) return fail(h, PO_ERR_CAPACITY, "too many scan tiles");
+        nt += (nw + po::TILE_WORDS - 1) / po::TILE_WORDS;
+        if (nt > 0x7FFFFF00ull / po::WAVE) return fail(h, PO_ERR_CAPACITY, "too many scan tiles");
     }
-    h->h_read_tile0[n] = (uint32_t)tiles.size();
-    h->n_tiles = (uint32_t)tiles.size();
+    h->h_read_tile0[n] = (uint32_t)nt;
+    h->n_tiles = (uint32_t)nt;
+
+    // Pin the packed store in place (once per state of the store; po_add_* unpins before it changes it): a
+    // pageable source goes through the runtime's staging buffers at a fraction of the PCIe rate.  Failure to
+    // register is not an error -- the copy below works either way.
+    const size_t word_bytes = h->words.size() * 8;
+    if (word_bytes >= (1u << 20) && !getenv("PHASM_NO_PIN") &&
+        (h->reg_ptr != (void*)h->words.data() || h->reg_bytes != word_bytes)) {
+        unpin_words(h);
+        if (hipHostRegister(h->words.data(), word_bytes, hipHostRegisterDefault) == hipSuccess) {
+            h->reg_ptr = h->words.data();
+            h->reg_bytes = word_bytes;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
 
     const size_t nwords = h->words.size() + 72;  // trailing zero padding: a scan tile may read 64+1 words past a read's start
     PO_TRY(ensure(h, h->d_words, nwords * 8));
@@ -344,17 +403,20 @@ po_status upload(po_handle* h) {
     PO_TRY(ensure(h, h->d_tiles, ((size_t)h->n_tiles + 1) * sizeof(po::TileRec)));
     PO_TRY(ensure(h, h->d_read_tile0, ((size_t)n + 1) * 4));
     HIP_TRY(h, hipEventRecord(h->ev_up0, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->d_words.p, 0, nwords * 8, h->stream));
+    // (the guard words between the reads are zeros in the host store already: only the tail needs clearing)
+    HIP_TRY(h, hipMemsetAsync(h->d_words.as<uint64_t>() + h->words.size(), 0, 72 * 8, h->stream));
     if (!h->words.empty())
-        HIP_TRY(h, hipMemcpyAsync(h->d_words.p, h->words.data(), h->words.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_words.p, h->words.data(), word_bytes, hipMemcpyHostToDevice, h->stream));
     if (n) {
         HIP_TRY(h, hipMemcpyAsync(h->d_woff.p, h->woff.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->d_len.p, h->len.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     }
-    if (h->n_tiles) {
-        HIP_TRY(h, hipMemcpyAsync(h->d_tiles.p, tiles.data(), (size_t)h->n_tiles * sizeof(po::TileRec), hipMemcpyHostToDevice, h->stream));
-    }
     HIP_TRY(h, hipMemcpyAsync(h->d_read_tile0.p, h->h_read_tile0.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, h->stream));
+    if (h->n_tiles) {
+        hipLaunchKernelGGL(po::k_build_tiles, dim3(cdiv(h->n_tiles, 256)), dim3(256), 0, h->stream, h->d_woff.as<uint64_t>(),
+                           h->d_len.as<uint32_t>(), h->d_read_tile0.as<uint32_t>(), n, h->n_tiles, h->d_tiles.as<po::TileRec>());
+        HIP_TRY(h, hipGetLastError());
+    }
     // exception records (2-bit mode only; usually none)
     const size_t n_exc = h->bits == 2 ? h->exc_pos.size() : 0;
     if (n_exc) {
@@ -386,7 +448,7 @@ po_status upload(po_handle* h) {
         HIP_TRY(h, hipMemcpyAsync(h->pinned, h->d_scalars.p, 8, hipMemcpyDeviceToHost, h->stream));
     }
     HIP_TRY(h, hipEventRecord(h->ev_up1, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));  // host vectors above go out of scope
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (try_paired) h->paired = (uint32_t)h->pinned[0] == 0;
     float ms = 0;
     (void)hipEventElapsedTime(&ms, h->ev_up0, h->ev_up1);
@@ -523,6 +585,16 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     unsigned long long* scalars = h->d_scalars.as<unsigned long long>();  // [0] scan total, [1] n_long, [4..6] emit counters
     uint32_t* n_long = reinterpret_cast<uint32_t*>(scalars + 1);
 
+    if (h->poison >= 0) {
+        // PHASM_POISON: whatever earlier calls left in the per-call workspaces is replaced by the caller's byte
+        DevBuf* ws[] = {&h->d_table, &h->d_slot_cnt, &h->d_slot_cur, &h->d_slot_start, &h->d_read_slot, &h->d_chain,
+                        &h->d_chain_tmp, &h->d_long_list, &h->d_bloom, &h->d_selfrep, &h->d_tile_count, &h->d_tile_off,
+                        &h->d_truemask, &h->d_ps_blocks, &h->d_left, &h->d_left_cnt, &h->d_tile_extra, &h->d_cand_a,
+                        &h->d_cand_p, &h->d_cand_b, &h->d_type, &h->d_rowcnt, &h->d_row_off, &h->d_flag, &h->d_pair_key,
+                        &h->d_vlabel, &h->d_vrank, &h->d_vperm, &h->spare_rows, &h->spare_cands};
+        for (DevBuf* b : ws)
+            if (b->p) HIP_TRY(h, hipMemsetAsync(b->p, h->poison, b->cap, st));
+    }
     // ---- index: anchor table, chains, Bloom filter
     HIP_TRY(h, hipEventRecord(h->ev[EV_START], st));
     {
@@ -635,12 +707,13 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         hipLaunchKernelGGL(po::k_add_extra, dim3(cdiv(ntiles, 256)), dim3(256), 0, st, A.tile_count, A.tile_extra, tile_begin,
                            tile_end);
         if (getenv("PHASM_DEBUG_LEFT")) {  // how many positions did the scan waves defer to k_scan_fixup?
-            std::vector<uint32_t> lc(n_scan_waves);
-            HIP_TRY(h, hipMemcpyAsync(lc.data(), h->d_left_cnt.p, (size_t)n_scan_waves * 4, hipMemcpyDeviceToHost, st));
+            PO_TRY(ensure_host(h, h->scratch_host, (size_t)n_scan_waves * 4));
+            HIP_TRY(h, hipMemcpyAsync(h->scratch_host.p, h->d_left_cnt.p, (size_t)n_scan_waves * 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(h, hipStreamSynchronize(st));
+            const uint32_t* lc = static_cast<const uint32_t*>(h->scratch_host.p);
             uint64_t sum = 0;
             uint32_t mx = 0;
-            for (uint32_t v : lc) sum += v, mx = std::max(mx, v);
+            for (uint32_t k = 0; k < n_scan_waves; ++k) sum += lc[k], mx = std::max(mx, lc[k]);
             std::fprintf(stderr, "[left] %u scan waves deferred %llu positions (max %u per wave, cap %d)\n", n_scan_waves,
                          (unsigned long long)sum, mx, (int)po::LEFT_CAP);
         }
@@ -1060,8 +1133,12 @@ po_status run_layout(po_handle* h, po_result* rows, const po_layout_params& prm,
         HIP_TRY(h, hipEventRecord(h->ev_lay[2], st));
     }
     HIP_TRY(h, hipEventRecord(h->ev_lay[3], st));
-    if (removed_out && n_names) HIP_TRY(h, hipMemcpyAsync(removed_out, h->d_removed.p, n_names, hipMemcpyDeviceToHost, st));
+    if (removed_out && n_names) {
+        PO_TRY(ensure_host(h, h->scratch_host, n_names));
+        HIP_TRY(h, hipMemcpyAsync(h->scratch_host.p, h->d_removed.p, n_names, hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(h, hipStreamSynchronize(st));
+    if (removed_out && n_names) std::memcpy(removed_out, h->scratch_host.p, n_names);
     res->count = n_edges;
     L.n_edges = n_edges;
     (void)hipEventElapsedTime(&L.ms_classify, h->ev_lay[0], h->ev_lay[1]);
@@ -1372,6 +1449,9 @@ void po_destroy(po_handle* h) {
         (void)hipEventDestroy(h->ev_up0);
         (void)hipEventDestroy(h->ev_up1);
         if (h->pinned) (void)hipHostFree(h->pinned);
+        h->spare_host.release();
+        h->scratch_host.release();
+        unpin_words(h);
         (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -1389,6 +1469,7 @@ po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const cha
     if (h->segments_only) return fail(h, PO_ERR_INVALID, "this handle holds GFA segments (no sequences); use a new handle");
     if (seq_len > 0x7FFFFFF0ull) return fail(h, PO_ERR_CAPACITY, "read longer than 2^31 bases");
     if (h->len.size() >= 0xFFFFFFF0ull) return fail(h, PO_ERR_CAPACITY, "too many reads");
+    unpin_words(h);  // (the store may move)
     try {
         const unsigned char* s = reinterpret_cast<const unsigned char*>(seq);
         if (h->bits != 2 || !append_packed(h, s, seq_len, 2)) {
@@ -1414,6 +1495,7 @@ po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const cha
 po_status po_add_fasta(po_handle* h, const char* path, int both_strands, uint64_t* n_records) {
     if (!h || !path) return PO_ERR_INVALID;
     if (n_records) *n_records = 0;
+    unpin_words(h);  // (the store may move)
     if (both_strands && !h->segments_only && !getenv("PHASM_FASTA_SEQUENTIAL")) {
         // fast path: map the file, pack with a few threads (pure upper-case ACGT only; see add_fasta_parallel)
         const int fd = ::open(path, O_RDONLY);
@@ -1520,11 +1602,21 @@ uint32_t po_get_length(const po_handle* h, uint32_t idx) { return (h && idx < h-
 
 po_status po_upload(po_handle* h) {
     if (!h) return PO_ERR_INVALID;
+    po_status st;
     try {
-        return upload(h);
+        st = upload(h);
     } catch (const std::bad_alloc&) {
-        return fail(h, PO_ERR_NOMEM, "out of host memory in po_upload");
+        st = fail(h, PO_ERR_NOMEM, "out of host memory in po_upload");
     }
+    // (a failed upload may have copies from the host store in flight: nothing returns before they are done)
+    if (st != PO_OK && h->dev_ready) (void)hipStreamSynchronize(h->stream);
+    return st;
+}
+
+po_status po_invalidate(po_handle* h) {
+    if (!h) return PO_ERR_INVALID;
+    h->dirty = true;
+    return PO_OK;
 }
 
 static po_status overlaps_common(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, bool want_cands,
@@ -1617,35 +1709,31 @@ uint64_t po_result_count(const po_result* r) { return r ? r->count : 0; }
 
 const po_row* po_result_rows(po_result* r) {
     if (!r) return nullptr;
-    if (r->wrote_ext && !r->host) {  // the entries live in the caller's buffer: copy them back from there
-        po_handle* h = r->h;
-        if (r->count == 0) return nullptr;
-        r->host = std::malloc(r->count * r->elem);
-        if (!r->host) return nullptr;
-        (void)hipSetDevice(h->device);
-        hipError_t e = hipMemcpyAsync(r->host, r->ext_dst, r->count * r->elem, hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        if (e != hipSuccess) {
-            std::free(r->host);
-            r->host = nullptr;
-        }
-        return static_cast<const po_row*>(r->host);
-    }
     if (r->host || r->count == 0) return static_cast<const po_row*>(r->host);
     po_handle* h = r->h;
-    r->host = std::malloc(r->count * r->elem);
-    if (!r->host) {
-        fail(h, PO_ERR_NOMEM, "out of host memory for the row array");
+    const void* src = r->wrote_ext ? r->ext_dst : r->d_rows.p;  // (wrote_ext: the entries live in the caller's buffer)
+    if (!src) return nullptr;
+    if (hipSetDevice(h->device) != hipSuccess) return nullptr;
+    // the destination is pinned memory owned by the handle's pool: one DMA at the PCIe rate, and no pageable
+    // heap range is ever handed to the runtime as a copy target
+    const size_t bytes = r->count * r->elem;
+    HostBuf hb;
+    if (h->spare_host.cap >= bytes) {
+        hb = h->spare_host;
+        h->spare_host = HostBuf();
+    } else if (ensure_host(h, hb, bytes) != PO_OK) {
         return nullptr;
     }
-    (void)hipSetDevice(h->device);
-    hipError_t e = hipMemcpyAsync(r->host, r->d_rows.p, r->count * r->elem, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e = hipMemcpyAsync(hb.p, src, bytes, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
+        (void)hipStreamSynchronize(h->stream);
         fail(h, PO_ERR_HIP, std::string("row copy device->host: ") + hipGetErrorString(e));
-        std::free(r->host);
-        r->host = nullptr;
+        hb.release();
+        return nullptr;
     }
+    r->host = hb.p;
+    r->host_cap = hb.cap;
     return static_cast<const po_row*>(r->host);
 }
 
@@ -1677,7 +1765,20 @@ po_status po_result_copy_prefix_to_device(po_result* r, void* dst_device, uint64
 void po_result_free(po_result* r) {
     if (!r) return;
     po_handle* h = r->h;
-    std::free(r->host);
+    if (r->host_malloced) {
+        std::free(r->host);
+    } else if (r->host) {
+        HostBuf hb;
+        hb.p = r->host;
+        hb.cap = r->host_cap;
+        if (h && hb.cap > h->spare_host.cap) {  // keep the larger pinned buffer for the next result
+            h->spare_host.release();
+            h->spare_host = hb;
+        } else {
+            hb.release();
+        }
+    }
+    r->host = nullptr;
     if (h) {
         --h->live_results;
         // keep the larger buffer for the next call
@@ -1843,6 +1944,7 @@ po_status po_result_from_rows(po_handle* h, const po_row* rows, uint64_t n, po_r
             return fail(h, PO_ERR_NOMEM, "out of host memory for the row array");
         }
         std::memcpy(r->host, rows, n * sizeof(po_row));
+        r->host_malloced = true;
     }
     ++h->live_results;
     *out = r;

@@ -56,6 +56,30 @@ struct __attribute__((aligned(32))) TileRec {
     uint32_t pad;
 };
 
+// The tile records, written at upload from what the host sends anyway (woff, len, first tile of every read):
+// one thread per tile finds its read by binary search over read_tile0 (n_reads + 1 entries, L2-resident).
+// Reads without tiles (length 0) share their successor's first tile index; the LAST read whose first tile is
+// <= t is the one that owns tile t.
+__global__ void k_build_tiles(const uint64_t* __restrict__ woff, const uint32_t* __restrict__ len,
+                              const uint32_t* __restrict__ read_tile0, uint32_t n_reads, uint32_t n_tiles,
+                              TileRec* __restrict__ tiles) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    uint32_t lo = 0, hi = n_reads;  // read_tile0[lo] <= t < read_tile0[hi]  (read_tile0[n_reads] = n_tiles)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (read_tile0[mid] <= t) lo = mid; else hi = mid;
+    }
+    TileRec rec;
+    rec.word0 = (t - read_tile0[lo]) * (uint32_t)TILE_WORDS;
+    rec.wread = woff[lo];
+    rec.wabs = rec.wread + rec.word0;
+    rec.read = lo;
+    rec.la = len[lo];
+    rec.pad = 0;
+    tiles[t] = rec;
+}
+
 // ----------------------------------------------------------------------------------------
 // small helpers
 // ----------------------------------------------------------------------------------------

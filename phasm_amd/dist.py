@@ -137,6 +137,10 @@ class CandidateExchange:
         self.gathered = torch.empty((self.ws * self.slot, 4), dtype=torch.int32, device=self.device)
         pin = self.device.type == "cuda"
         self.hdr_host = torch.empty(self.ws, dtype=torch.int32, pin_memory=pin)
+        if pin:
+            # the zero fill and the move above run on torch's stream; the library writes into the same rows on ITS
+            # stream (created non-blocking: no implicit ordering with torch's) right after this returns
+            torch.cuda.current_stream(self.device).synchronize()
 
     def candidates(self, min_length: int) -> torch.Tensor:
         """All ranks' verified candidates of one step as ``int32[ws * slot, 4]`` (padding and neutralised headers

@@ -75,6 +75,20 @@ class OverlapResult:
         buf = (ctypes.c_char * (n * self._dtype.itemsize)).from_address(p)
         return np.frombuffer(buf, dtype=self._dtype).copy()
 
+    def rows_view(self) -> np.ndarray:
+        """The same rows WITHOUT the copy: a read-only view of the library's page-locked host buffer, valid until
+        ``free()`` (the C ABI's ``po_result_rows`` pointer as it is)."""
+        n = len(self)
+        if n == 0:
+            return np.empty(0, dtype=self._dtype)
+        p = self._lib.po_result_rows(self._ptr)
+        if not p:
+            _check(self._owner._h, _lib.PO_ERR_HIP)
+        buf = (ctypes.c_char * (n * self._dtype.itemsize)).from_address(p)
+        v = np.frombuffer(buf, dtype=self._dtype)
+        v.flags.writeable = False
+        return v
+
     def write_gfa_edges(self, fileobj) -> int:
         """Native bulk writer of the GFA2 ``E`` lines (``po_write_gfa_edges``) to a real file."""
         fileobj.flush()
@@ -204,6 +218,10 @@ class ExactOverlapper:
 
     def upload(self) -> None:
         _check(self._h, self._lib.po_upload(self._h))
+
+    def invalidate(self) -> None:
+        """``po_invalidate``: the next upload / overlaps call copies the packed reads to the device again."""
+        _check(self._h, self._lib.po_invalidate(self._h))
 
     # ---- the consumer side: stage 1 of `phasm layout` (phasm_amd/layout.py is the host mirror) ----
     def add_segment(self, name, length: int) -> None:

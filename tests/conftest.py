@@ -10,6 +10,17 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The checker process (oracle/sidecar.py: C oracle, layout restatement, reference binary, every child command)
+    # starts HERE, before anything in this process initialises the GPU: the code under test never shares a heap
+    # with what checks it, and a process that holds the GPU never forks.
+    if "not gpu" not in (config.getoption("-m", default="") or ""):
+        import checker
+        checker.start()
+
+
+def pytest_unconfigure(config):
+    import checker
+    checker.stop()
 
 
 def _have_gpu() -> bool:

@@ -7,8 +7,9 @@ import numpy as np
 import pytest
 import torch
 
+import checker as ck
 import golden_utils as gu
-from oracle import overlap_oracle as oo
+from oracle import overlap_oracle as oo   # row helpers only; the oracle itself runs in the checker process
 from phasm_amd import cli, synth
 from phasm_amd.io import gfa
 from phasm_amd.overlapper import ExactOverlapper
@@ -120,12 +121,11 @@ def test_rccl_collectives_one_rank_group():
     very same calls (count all-gather, padded all_gather_into_tensor of int32[n,4], expansion) -- in a child
     process: a process group brings RCCL's proxy threads and pinned buffers with it, and the rest of the suite
     should not share an address space with them."""
-    import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = _RCCL_CHILD % {"root": root, "tests": os.path.join(root, "tests")}
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=500)
-    assert out.returncode == 0 and "RCCL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    rc, stdout, stderr = ck.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=500)
+    assert rc == 0 and "RCCL OK" in stdout, stdout[-2000:] + stderr[-3000:]
 
 
 @pytest.mark.skipif(os.environ.get("PHASM_SKIP_FULL") == "1", reason="full-size run disabled")
@@ -150,7 +150,7 @@ def test_full_size_cfg2_properties():
     from phasm_amd import layout
     g = layout.build_assembly_graph(ov, res, min_read_length=0, min_overlap_length=2000)
     res.free()
-    want_g = lo.layout_vectorised(oo.struct_to_rows(arr), ov.lengths(), min_overlap_length=2000)
+    want_g = ck.layout_vectorised(oo.struct_to_rows(arr), ov.lengths(), min_overlap_length=2000)
     e = g.edges
     got_e = np.stack([e["u"], e["v"], e["weight"], e["overlap_len"]], 1).astype(np.int64)
     got_e = got_e[np.lexsort((got_e[:, 1], got_e[:, 0]))]
@@ -189,6 +189,24 @@ def test_full_size_cfg2_properties():
     # oracle on a closed neighbourhood: rows among the first 400 oriented reads must equal the
     # oracle run on those 400 reads alone (rows only depend on the two reads involved)
     sub = [s_ for _, s_ in oriented[:400]]
-    want = oo.oracle_overlaps(sub, 1000)
+    want = ck.oracle_overlaps(sub, 1000)
     got = oo.sort_rows(rows[(rows[:, 0] < 400) & (rows[:, 1] < 400)])
-    assert np.array_equal(got, want)
+    ck.assert_same_rows(got, want, sub, 1000, "cfg2 full size, first 400 oriented reads")
+
+
+def test_one_hip_runtime_in_the_process():
+    """torch bundles its own libamdhip64.so; the library binds to whichever copy is mapped first
+    (phasm_amd/_lib.py preloads torch's).  Two HIP runtimes in one address space would each own a device context
+    and their own staging threads -- this process must hold exactly one."""
+    ov = ExactOverlapper(device=0)
+    ov.add_sequence("a", "ACGTACGTAGGCTAGCTAGGATCGATCGATTAGC")
+    ov.add_sequence("b", "GATCGATTAGCAAAAACCCCCGGGGGTTTTTACG")
+    ov.overlaps_array(5)
+    ov.close()
+    torch.zeros(4, device="cuda").sum().item()
+    paths = set()
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                paths.add(os.path.realpath(line.split()[-1]))
+    assert len(paths) == 1, sorted(paths)

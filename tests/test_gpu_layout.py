@@ -8,7 +8,7 @@ import pytest
 
 import golden_utils as gu
 import layout_utils as lu
-from oracle import layout_oracle as lo
+import checker as ck   # the layout restatement runs in the checker process (tests/checker.py)
 from phasm_amd import layout, synth
 from phasm_amd.overlapper import ExactOverlapper
 
@@ -28,8 +28,8 @@ def test_layout_edges_from_gfa_file_match_oracle(case, tmp_path):
     p.write_text(case["text"])
     got = layout.layout_from_gfa(str(p), **case["params"])
     L = lu.node_lengths(case["lengths"])
-    want = lo.layout_sequential(case["rows"], L, **case["params"])
-    assert np.array_equal(edge_array(got.edges), lo.edges_dict_to_array(want["edges"]))
+    want = ck.layout_sequential(case["rows"], L, **case["params"])
+    assert np.array_equal(edge_array(got.edges), want["edges_array"])
     contained = np.zeros(len(case["names"]), dtype=bool)
     for n in want["filters"][0]["nodes_to_remove"]:
         contained[n >> 1] = True
@@ -58,7 +58,7 @@ def test_overlap_then_layout_without_a_file(name):
     for params in (layout.DEFAULTS, dict(layout.DEFAULTS, min_read_length=5000, min_overlap_length=2000)):
         got = layout.build_assembly_graph(ov, res, **params)
         r6 = np.stack([rows[k] for k in rows.dtype.names], 1).astype(np.int64)
-        want = lo.layout_vectorised(r6, ov.lengths(), **params)
+        want = ck.layout_vectorised(r6, ov.lengths(), **params)
         assert np.array_equal(edge_array(got.edges), want["edges"])
         assert got.contained.tolist() == want["contained"].tolist()
         # exact overlaps have no overhang and every B row is a containment
@@ -100,7 +100,7 @@ def test_random_bulk_rows_against_vectorised_oracle():
     res = ov.result_from_rows(rows)
     for params in (layout.DEFAULTS, dict(min_read_length=400, min_overlap_length=150, max_overhang_abs=60, max_overhang_rel=0.3)):
         got = layout.build_assembly_graph(ov, res, **params)
-        want = lo.layout_vectorised(rows, L, **params)
+        want = ck.layout_vectorised(rows, L, **params)
         assert np.array_equal(edge_array(got.edges), want["edges"])
         assert got.contained.tolist() == want["contained"].tolist()
         assert got.stats["n_edges"] == len(want["edges"]) > 1000
@@ -146,7 +146,7 @@ def test_cli_overlap_then_layout_edges_files(tmp_path):
     assert cli.main(["layout-edges", str(ovl), "-l", "3000", "-s", "800", "-o", str(graph)]) == 0
     names, lengths, rows = gfa.read_gfa2_rows(ovl.read_text().splitlines(True))
     L = np.repeat(lengths, 2)
-    want = lo.layout_sequential(rows, L, min_read_length=3000, min_overlap_length=800)
+    want = ck.layout_sequential(rows, L, min_read_length=3000, min_overlap_length=800)
     assert len(want["edges"]) > 50
     lines = graph.read_text().splitlines(True)
     assert lines[0] == "H\tVN:z:2.0\n"
@@ -181,8 +181,8 @@ def test_layout_from_daligner_dumps(case, tmp_path):
     assert np.array_equal(edge_array(direct.edges), edge_array(via_file.edges))
     assert direct.contained.tolist() == via_file.contained.tolist()
     names, lengths, rows = gfa.read_gfa2_rows(io.StringIO(case["gfa"]["ok"]))
-    want = lo.layout_sequential([tuple(r) for r in rows.tolist()], lu.node_lengths(lengths.tolist()), **params)
-    assert np.array_equal(edge_array(direct.edges), lo.edges_dict_to_array(want["edges"]))
+    want = ck.layout_sequential([tuple(r) for r in rows.tolist()], lu.node_lengths(lengths.tolist()), **params)
+    assert np.array_equal(edge_array(direct.edges), want["edges_array"])
     # and as a command
     (tmp_path / "db.txt").write_text(case["db"])
     (tmp_path / "las.txt").write_text(case["las"])

@@ -7,15 +7,19 @@ import os
 import numpy as np
 import pytest
 
+import checker as ck
 import golden_utils as gu
-from oracle import overlap_oracle as oo
-from phasm_amd import synth
+from oracle import overlap_oracle as oo   # row helpers only (sort_rows / struct_to_rows): the oracle itself runs in the
+from phasm_amd import synth               # checker process (tests/checker.py), never in this one
 from phasm_amd.overlapper import ExactOverlapper
 
 pytestmark = pytest.mark.gpu
 
+_last = {}
+
 
 def hip_rows(seqs, m, shard=None):
+    _last.update(seqs=seqs, m=m)
     ov = ExactOverlapper()
     for i, s in enumerate(seqs):
         ov.add_sequence("r%d" % i, s)
@@ -28,12 +32,18 @@ def hip_rows(seqs, m, shard=None):
     return oo.sort_rows(oo.struct_to_rows(arr)), st
 
 
+def same(got, want, ctx=""):
+    """HIP rows == expected rows as sorted multisets; a mismatch is a failure that says which side is wrong
+    (tests/checker.py: the contract evaluated on the reads of the last hip_rows call)."""
+    ck.assert_same_rows(got, want, _last.get("seqs"), _last.get("m", 1), ctx)
+
+
 def test_toy_and_adversarial_goldens():
     cases = gu.all_small_cases()
     bits_seen = set()
     for name, seqs, m, want in cases:
         got, st = hip_rows(seqs, m)
-        assert np.array_equal(got, want), name
+        same(got, want, name)
         bits_seen.add(st["bits_per_base"])
     assert 2 in bits_seen  # (short reads with N / lower case stay 2-bit + exception records)
 
@@ -41,14 +51,14 @@ def test_toy_and_adversarial_goldens():
 def test_repeats_goldens():
     for name, seqs, m, want in gu.repeats_cases():
         got, _ = hip_rows(seqs, m)
-        assert np.array_equal(got, want), name
+        same(got, want, name)
 
 
 @pytest.mark.parametrize("name", gu.LADDER_NAMES)
 def test_ladder_goldens(name):
     _, seqs, m, want = gu.ladder_case(name)
     got, st = hip_rows(seqs, m)
-    assert np.array_equal(got, want)
+    same(got, want)
     assert st["n_rows"] == len(want)
     assert st["paired"] == 1  # both strands were added: the strand-mirror shortcut is active
 
@@ -59,7 +69,7 @@ def test_mirror_shortcut_off_gives_the_same_rows(name, monkeypatch):
     monkeypatch.setenv("PHASM_NO_MIRROR", "1")
     got, st = hip_rows(seqs, m)
     assert st["paired"] == 0
-    assert np.array_equal(got, want)
+    same(got, want)
 
 
 def test_pairing_is_detected_not_assumed():
@@ -71,7 +81,7 @@ def test_pairing_is_detected_not_assumed():
     seqs[41] = bytes(s)
     got, st = hip_rows(seqs, m)
     assert st["paired"] == 0
-    assert np.array_equal(got, oo.oracle_overlaps(seqs, m))
+    same(got, ck.oracle_overlaps(seqs, m))
     # odd lengths / odd tail words still pair up
     rng = np.random.default_rng(8)
     reads = []
@@ -80,17 +90,17 @@ def test_pairing_is_detected_not_assumed():
         reads += [r, r.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1]]
     got, st = hip_rows(reads, 1)
     assert st["paired"] == 1
-    assert np.array_equal(got, oo.oracle_overlaps(reads, 1))
+    same(got, ck.oracle_overlaps(reads, 1))
 
 
 @pytest.mark.parametrize("nshards", [2, 3, 8])
 def test_shard_union_equals_whole(nshards):
     _, seqs, m, want = gu.ladder_case("ladder_varlen")
     got, _ = hip_rows(seqs, m, shard=nshards)
-    assert np.array_equal(got, want)
+    same(got, want)
     for name, seqs, m, want in gu.repeats_cases()[:1]:
         got, _ = hip_rows(seqs, m, shard=nshards)
-        assert np.array_equal(got, want), name
+        same(got, want, name)
 
 
 def test_byte_mode_matches_oracle_on_mixed_alphabet():
@@ -105,7 +115,7 @@ def test_byte_mode_matches_oracle_on_mixed_alphabet():
     for m in (8, 9, 40):
         got, st = hip_rows(seqs, m)
         assert st["bits_per_base"] == 8
-        assert np.array_equal(got, oo.oracle_overlaps(seqs, m)), m
+        same(got, ck.oracle_overlaps(seqs, m), m)
 
 
 def test_repeated_calls_and_incremental_adds():
@@ -115,7 +125,7 @@ def test_repeated_calls_and_incremental_adds():
     for i, s in enumerate(seqs[:half]):
         ov.add_sequence("r%d" % i, s)
     first = oo.sort_rows(oo.struct_to_rows(ov.overlaps_array(m)))
-    assert np.array_equal(first, oo.oracle_overlaps(seqs[:half], m))
+    same(first, ck.oracle_overlaps(seqs[:half], m))
     for i, s in enumerate(seqs[half:]):
         ov.add_sequence("r%d" % (half + i), s)
     a = ov.overlaps_array(m)
@@ -124,7 +134,7 @@ def test_repeated_calls_and_incremental_adds():
     assert np.array_equal(oo.sort_rows(oo.struct_to_rows(a)), want)
     # a different min_length on the same handle (index is rebuilt per call, overlapper.cpp:33-36)
     c = oo.sort_rows(oo.struct_to_rows(ov.overlaps_array(m * 3)))
-    assert np.array_equal(c, oo.oracle_overlaps(seqs, m * 3))
+    same(c, ck.oracle_overlaps(seqs, m * 3))
     ov.close()
 
 
@@ -147,9 +157,9 @@ def test_midsize_against_oracle():
     cfg = synth.scaled(synth.CONFIGS["cfg2"], 2000)
     seqs = [s for _, s in synth.oriented(synth.generate_reads(cfg))]
     got, st = hip_rows(seqs, 1000)
-    want = oo.oracle_overlaps(seqs, 1000)
+    want = ck.oracle_overlaps(seqs, 1000)
     assert len(want) > 100_000
-    assert np.array_equal(got, want)
+    same(got, want)
     assert st["bits_per_base"] == 2 and st["kmer"] == 32
 
 
@@ -158,7 +168,7 @@ def test_long_chain_many_identical_reads():
     base = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=300))
     seqs = [base] * 40 + [base[50:] + b"ACGTACGT", b"TTTT" + base[:200]]
     got, _ = hip_rows(seqs, 100)
-    assert np.array_equal(got, oo.oracle_overlaps(seqs, 100))
+    same(got, ck.oracle_overlaps(seqs, 100))
 
 
 @pytest.mark.parametrize("nshards", [1, 2, 5])
@@ -195,7 +205,7 @@ def test_compact_candidates_then_expand_equals_rows(nshards):
         assert np.array_equal(oo.sort_rows(oo.struct_to_rows(got)), want)
         if nshards > 1:
             _, other = expanded(5)
-            assert np.array_equal(got, other)        # row for row, whatever the shard count
+            same(got, other)  # row for row, whatever the shard count
         # garbage in -> loud failure, not garbage rows
         bad = merged.clone()
         bad[0, 0] = 10 ** 9
@@ -213,10 +223,10 @@ def test_scan_pipeline_many_tiles_per_wave(waves, monkeypatch):
     _, seqs, m, want = gu.ladder_case("ladder_cfg2_mini")
     for _ in range(3):
         got, _ = hip_rows(seqs, m)
-        assert np.array_equal(got, want)
+        same(got, want)
     monkeypatch.setenv("PHASM_NO_MIRROR", "1")
     got, _ = hip_rows(seqs, m)
-    assert np.array_equal(got, want)
+    same(got, want)
 
 
 @pytest.mark.parametrize("mult,waves", [("1.5", "16"), ("1.5", "2"), ("40", "16")])
@@ -230,7 +240,7 @@ def test_crowded_and_sparse_anchor_table(mult, waves, monkeypatch, capfd):
     for name in ("cfg2_1k", "cfg1_full"):
         _, seqs, m, want = gu.ladder_case(name)
         got, _ = hip_rows(seqs, m)
-        assert np.array_equal(got, want)
+        same(got, want)
     err = capfd.readouterr().err
     deferred = [int(ln.split("deferred")[1].split()[0]) for ln in err.splitlines() if ln.startswith("[left]")]
     assert deferred, "PHASM_DEBUG_LEFT printed nothing"
@@ -243,16 +253,16 @@ def test_full_leftover_list_resolves_in_place(tmp_path):
     pipeline).  The list holds 2048 entries per wave, which no test input fills: build the library with room for 8
     (hipcc is on the GPU box) and run two goldens through it in a child process."""
     import shutil
-    import subprocess
     import sys
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc on this box")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = str(tmp_path / "libphasm_overlap_cap8.so")
-    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DPO_LEFT_CAP=8", "-o", lib,
-                    os.path.join(root, "phasm_amd", "csrc", "c_api.hip")], check=True, timeout=900,
-                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    # (both children are started by the checker process: this one has the GPU open and does not fork)
+    rc, _, err = ck.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DPO_LEFT_CAP=8", "-o", lib,
+                         os.path.join(root, "phasm_amd", "csrc", "c_api.hip")], timeout=900, capture_output=True, text=True)
+    assert rc == 0, err[-3000:]
     code = (
         "import sys, numpy as np\n"
         "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
@@ -264,9 +274,9 @@ def test_full_leftover_list_resolves_in_place(tmp_path):
         "    assert np.array_equal(got, want), name\n"
         "print('CAP8 OK')\n" % (root, os.path.join(root, "tests")))
     env = dict(os.environ, PHASM_LIB=lib, PHASM_TABLE_MULT="1.5", PHASM_SCAN_WAVES="2", PHASM_DEBUG_LEFT="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "CAP8 OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
-    caps = [ln for ln in out.stderr.splitlines() if ln.startswith("[left]")]
+    rc, stdout, stderr = ck.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert rc == 0 and "CAP8 OK" in stdout, stdout[-2000:] + stderr[-3000:]
+    caps = [ln for ln in stderr.splitlines() if ln.startswith("[left]")]
     assert caps and all("cap 8" in ln for ln in caps), caps[:3]       # the variant library was the one that ran
     assert any("max 8 per wave" in ln for ln in caps), caps[:6]       # and some wave's list did fill up
 
@@ -284,9 +294,9 @@ def test_long_reads_take_the_global_verify_path():
         seqs += [r, r.translate(rc)[::-1]]
     got, st = hip_rows(seqs, 1000)
     assert st["paired"] == 1
-    want = oo.oracle_overlaps(seqs, 1000)
+    want = ck.oracle_overlaps(seqs, 1000)
     assert len(want) >= 8
-    assert np.array_equal(got, want)
+    same(got, want)
 
 
 def test_wide_index_matches_goldens(monkeypatch):
@@ -297,17 +307,18 @@ def test_wide_index_matches_goldens(monkeypatch):
         _, seqs, m, want = gu.ladder_case(name)
         got, st = hip_rows(seqs, m)
         assert st["wide_index"] == 1, name
-        assert np.array_equal(got, want), name
+        same(got, want, name)
     for name, seqs, m, want in gu.repeats_cases():
         got, st = hip_rows(seqs, m)
         assert st["wide_index"] == (1 if m >= 63 else 0)   # needs min_length >= 2W-1
-        assert np.array_equal(got, want), name
+        same(got, want, name)
     _, seqs, m, want = gu.ladder_case("ladder_varlen")
     got, _ = hip_rows(seqs, m, shard=3)
-    assert np.array_equal(got, want)
+    same(got, want)
     monkeypatch.setenv("PHASM_NO_MIRROR", "1")
     got, st = hip_rows(seqs, m)
-    assert st["paired"] == 0 and np.array_equal(got, want)
+    assert st["paired"] == 0
+    same(got, want)
     # 8-bit reads: W = 8, needs min_length >= 15
     rng = np.random.default_rng(6)
     alpha = np.frombuffer(b"ACGTNacgt", dtype=np.uint8)
@@ -316,7 +327,7 @@ def test_wide_index_matches_goldens(monkeypatch):
     for m8 in (15, 40):
         got, st = hip_rows(seqs8, m8)
         assert st["bits_per_base"] == 8 and st["wide_index"] == 1
-        assert np.array_equal(got, oo.oracle_overlaps(seqs8, m8)), m8
+        same(got, ck.oracle_overlaps(seqs8, m8), m8)
 
 
 def test_wide_index_midsize_against_oracle(monkeypatch):
@@ -325,7 +336,7 @@ def test_wide_index_midsize_against_oracle(monkeypatch):
     seqs = [s for _, s in synth.oriented(synth.generate_reads(cfg))]
     got, st = hip_rows(seqs, 1000)
     assert st["wide_index"] == 1
-    assert np.array_equal(got, oo.oracle_overlaps(seqs, 1000))
+    same(got, ck.oracle_overlaps(seqs, 1000))
 
 
 @pytest.mark.parametrize("index", ["narrow", "wide"])
@@ -367,32 +378,11 @@ def test_seeded_fuzz_against_oracle(index, monkeypatch):
             seqs = reads
         m = int(rng.choice([1, 2, 5, 31, 32, 33, 62, 63, 64, 100, 500]))
         got, st = hip_rows(seqs, m)
-        want = oo.oracle_overlaps(seqs, m)
-        if not np.array_equal(got, want):
-            # Say which side moved: run both again.  Once in some twenty-five runs of the WHOLE GPU suite (never in a
-            # run of this file alone) the CPU oracle's first answer here was short by a few rows while the HIP rows
-            # were the ones the oracle gives for the same reads in a fresh process: the checker's host memory had
-            # been touched by something earlier in the process.  If the oracle, asked twice more, agrees with itself
-            # and with the HIP rows, the comparison holds and the odd answer is reported as a warning; anything else
-            # (the HIP side moved, or the two sides still differ) fails with the difference.
-            from collections import Counter
-            import warnings
-            got2, _ = hip_rows(seqs, m)
-            want2 = oo.oracle_overlaps(seqs, m)
-            want3 = oo.oracle_overlaps(seqs, m)
-            cg, cw = Counter(map(tuple, got.tolist())), Counter(map(tuple, want.tolist()))
-            msg = ("trial %d m %d reads %d wide %d paired %d: hip %d rows (again: %d, same %s), oracle %d rows "
-                   "(again: %d, same %s); hip-only %s oracle-only %s" % (
-                       trial, m, len(seqs), st["wide_index"], st["paired"], len(got), len(got2),
-                       np.array_equal(got, got2), len(want), len(want2), np.array_equal(want, want2),
-                       list((cg - cw).elements())[:12], list((cw - cg).elements())[:12]))
-            if np.array_equal(got, got2) and np.array_equal(want2, want3) and np.array_equal(got, want2):
-                warnings.warn("CPU oracle gave a different answer the first time: " + msg)
-            else:
-                raise AssertionError(msg)
+        want = ck.oracle_overlaps(seqs, m)
+        same(got, want, "trial %d m %d reads %d wide %d paired %d" % (trial, m, len(seqs), st["wide_index"], st["paired"]))
         # the sharded form of the same call (scrambled canonical order, every foreign read a repeat suspect)
         got3, _ = hip_rows(seqs, m, shard=3)
-        assert np.array_equal(got3, want), (trial, m, len(seqs), "3 shards")
+        same(got3, want, (trial, m, len(seqs), "3 shards"))
 
 
 def test_sparse_non_acgt_bytes_stay_on_the_2bit_path():
@@ -427,12 +417,13 @@ def test_sparse_non_acgt_bytes_stay_on_the_2bit_path():
         got, st = hip_rows(seqs, m)
         assert st["bits_per_base"] == 2          # exceptions, not the 8-bit path
         assert st["paired"] == 1                 # strand pairs recognised although they contain N / R / Y
-        want = oo.oracle_overlaps(seqs, m)
+        want = ck.oracle_overlaps(seqs, m)
         assert len(want) > 500
-        assert np.array_equal(got, want), m
+        same(got, want, m)
     # unpaired use + mirror off give the same rows
     got, st = hip_rows(seqs[:-1], 500)
-    assert st["paired"] == 0 and np.array_equal(got, oo.oracle_overlaps(seqs[:-1], 500))
+    assert st["paired"] == 0
+    same(got, ck.oracle_overlaps(seqs[:-1], 500))
     # a pair that is NOT a reverse complement at an exceptional byte only
     bad = list(seqs)
     j = next(i for i, s_ in enumerate(bad) if i % 2 == 1 and any(c not in b"ACGT" for c in s_))
@@ -441,7 +432,8 @@ def test_sparse_non_acgt_bytes_stay_on_the_2bit_path():
     b[kk] = ord("N") if b[kk] != ord("N") else ord("R")
     bad[j] = bytes(b)
     got, st = hip_rows(bad, 500)
-    assert st["paired"] == 0 and np.array_equal(got, oo.oracle_overlaps(bad, 500))
+    assert st["paired"] == 0
+    same(got, ck.oracle_overlaps(bad, 500))
 
 
 def test_tandem_repeats_many_hits_per_pair():
@@ -464,9 +456,9 @@ def test_tandem_repeats_many_hits_per_pair():
         seqs += [r, r.translate(rc)[::-1]]
     for m in (64, 300):
         got, st = hip_rows(seqs, m)
-        want = oo.oracle_overlaps(seqs, m)
+        want = ck.oracle_overlaps(seqs, m)
         assert st["n_candidates"] > 20 * len(want) > 0      # far more hits than rows
-        assert np.array_equal(got, want), m
+        same(got, want, m)
 
 
 def test_expand_skips_all_zero_padding():
@@ -489,7 +481,7 @@ def test_expand_skips_all_zero_padding():
     res = ov.expand_result(merged.data_ptr(), merged.shape[0])
     got = oo.sort_rows(oo.struct_to_rows(res.rows()))
     res.free()
-    assert np.array_equal(got, want)
+    same(got, want)
     bad = merged.clone()
     bad[-1, 3] = 1                      # a = b = 0 with a type: not padding, not possible
     with pytest.raises(ValueError):
@@ -505,13 +497,15 @@ def test_verify_locality_order_forced_on_small_sets(name, monkeypatch):
     _, seqs, m, want = gu.ladder_case(name)
     monkeypatch.setenv("PHASM_VERIFY_ORDER", "1")
     got, _ = hip_rows(seqs, m)
-    assert np.array_equal(got, want)
+    same(got, want)
     monkeypatch.setenv("PHASM_INDEX", "wide")
     got, st = hip_rows(seqs, m)
-    assert st["wide_index"] == 1 and np.array_equal(got, want)
+    assert st["wide_index"] == 1
+    same(got, want)
     monkeypatch.setenv("PHASM_NO_MIRROR", "1")
     got, st = hip_rows(seqs, m)
-    assert st["paired"] == 0 and np.array_equal(got, want)
+    assert st["paired"] == 0
+    same(got, want)
 
 
 @pytest.mark.skipif(not oo.have_reference(), reason="oracle/_ref/ref_overlapper not built (make -C oracle ref)")
@@ -524,12 +518,12 @@ def test_live_against_the_reference_binary_on_fresh_data():
                                 len_sd=2500.0, len_min=800, len_max=15000), 600)]
     for cfg, m in cases:
         seqs = [s for _, s in synth.oriented(synth.generate_reads(cfg))]
-        want, secs, nrows = oo.reference_overlaps(seqs, m)
+        want, secs, nrows = ck.reference_overlaps(seqs, m)
         assert nrows == len(want) > 1000
         got, st = hip_rows(seqs, m)
-        assert np.array_equal(got, want)
+        same(got, want)
         got3, _ = hip_rows(seqs, m, shard=3)
-        assert np.array_equal(got3, want)
+        same(got3, want)
 
 
 def test_many_identical_and_nested_reads():
@@ -545,12 +539,12 @@ def test_many_identical_and_nested_reads():
         both += [r, r.translate(rc)[::-1]]
     for seqs in (reads, both):
         for m in (64, 500):
-            want = oo.oracle_overlaps(seqs, m)
+            want = ck.oracle_overlaps(seqs, m)
             assert len(want) > 5000
             got, st = hip_rows(seqs, m)
-            assert np.array_equal(got, want), (len(seqs), m, "whole")
+            same(got, want, (len(seqs), m, "whole"))
             got, _ = hip_rows(seqs, m, shard=4)
-            assert np.array_equal(got, want), (len(seqs), m, "4 shards")
+            same(got, want, (len(seqs), m, "4 shards"))
 
 
 @pytest.mark.parametrize("n_b,strands", [(100, 1), (100, 2), (240, 1), (240, 2)])
@@ -566,13 +560,13 @@ def test_tiles_with_more_survivors_than_one_probe_round(n_b, strands, capfd, mon
     seqs = []
     for r in reads:
         seqs += [r] if strands == 1 else [r, r.translate(rc)[::-1]]
-    want = oo.oracle_overlaps(seqs, 1000)
+    want = ck.oracle_overlaps(seqs, 1000)
     assert len(want) > n_b * n_b // 4
     got, st = hip_rows(seqs, 1000)
     assert st["wide_index"] == 0
-    assert np.array_equal(got, want)
+    same(got, want)
     got, _ = hip_rows(seqs, 1000, shard=3)
-    assert np.array_equal(got, want)
+    same(got, want)
     deferred = [int(ln.split("deferred")[1].split()[0]) for ln in capfd.readouterr().err.splitlines() if ln.startswith("[left]")]
     if n_b > 128:
         assert max(deferred) >= n_b - 128      # survivors 129.. of that tile took the leftover path
@@ -583,8 +577,9 @@ def test_many_identical_reads_wide_index(monkeypatch):
     rng = np.random.default_rng(321)
     base = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=1200))
     seqs = [base] * 50 + [base[:700]] * 30 + [base[400:]] * 30
-    want = oo.oracle_overlaps(seqs, 100)
+    want = ck.oracle_overlaps(seqs, 100)
     got, st = hip_rows(seqs, 100)
-    assert st["wide_index"] == 1 and np.array_equal(got, want)
+    assert st["wide_index"] == 1
+    same(got, want)
     got, _ = hip_rows(seqs, 100, shard=3)
-    assert np.array_equal(got, want)
+    same(got, want)
