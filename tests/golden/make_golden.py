@@ -164,6 +164,10 @@ LADDER = {
     "cfg1_full": (synth.CONFIGS["cfg1"], 1000),
     # BASELINE.json configs[1] density (75x per haplotype) at 1 000 reads = 2 000 oriented x 15 kb
     "cfg2_1k": (synth.scaled(synth.CONFIGS["cfg2"], 1000), 1000),
+    # BASELINE.json configs[2] density (triploid, 50x per haplotype) and configs[4] density (tetraploid, 12 kb
+    # reads, 30x per haplotype) at 1 000 reads = 2 000 oriented reads each
+    "cfg3_1k": (synth.scaled(synth.CONFIGS["cfg3"], 1000), 1000),
+    "cfg5_1k": (synth.scaled(synth.CONFIGS["cfg5"], 1000), 1000),
 }
 
 
@@ -171,8 +175,10 @@ def ladder_reads(cfg):
     return [s for _, s in synth.oriented(synth.generate_reads(cfg))]
 
 
-def ladder():
+def ladder(only=None):
     for name, (cfg, m) in LADDER.items():
+        if only and name not in only:
+            continue
         seqs = ladder_reads(cfg)
         rows, secs, _ = oo.reference_overlaps(seqs, m)
         np.savez_compressed(os.path.join(HERE, name + ".npz"),
@@ -185,6 +191,9 @@ def ladder():
 def main():
     if not oo.have_reference():
         sys.exit("oracle/_ref/ref_overlapper missing: run `make -C oracle ref` first")
+    if len(sys.argv) > 1:   # only the named ladder cases (the others are left as committed)
+        ladder(set(sys.argv[1:]))
+        return
     with open(os.path.join(HERE, "toy_cases.json"), "w") as f:
         json.dump(toy_cases(), f, indent=0)
     adv = adversarial()

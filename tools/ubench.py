@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Run tools/ubench.hip on the GPU and print the measured rates as JSON (measurement infrastructure).
+
+    python tools/ubench.py > profiles/r02_ubench.json
+
+valu: wave64 integer instructions per second per SIMD, and the cycles each one takes at 2.4 GHz (the chip's
+maximum clock; the clock held under load is lower, so the true cycle count is a little below the number printed);
+lds / l2: bytes per second, whole chip."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "ubench.hip")
+LIB = os.path.join(HERE, "libpo_ubench.so")
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O3", "-std=c++17", "--offload-arch=gfx950",
+                               "-fPIC", "-shared", "-o", LIB, SRC])
+    return LIB
+
+
+def load():
+    lib = ctypes.CDLL(build())
+    lib.ub_valu.restype = ctypes.c_double
+    lib.ub_valu.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.ub_lds.restype = ctypes.c_double
+    lib.ub_lds.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.ub_l2.restype = ctypes.c_double
+    lib.ub_l2.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
+    return lib
+
+
+def measure(quick=False):
+    lib = load()
+    it = 20000 if quick else 100000
+    out = {"valu": {}, "lds_random_b64_TBps": {}, "l2_hit_dwordx4_TBps": {}}
+    for op, name in enumerate(("v_alignbit_b32", "v_xor_b32", "v_lshrrev_b32")):
+        out["valu"][name] = {}
+        for w in (1, 2, 4, 8):
+            r = lib.ub_valu(op, w, it)
+            out["valu"][name]["%d_waves_per_simd" % w] = {"wave_insts_per_sec_per_simd": r, "cycles_per_inst_at_2.4GHz": 2.4e9 / r}
+    for w in (1, 2, 4, 8):
+        out["lds_random_b64_TBps"]["%d_waves_per_simd" % w] = lib.ub_lds(w, it // 10) / 1e12
+    for w in (2, 4, 8):
+        out["l2_hit_dwordx4_TBps"]["%d_waves_per_simd" % w] = lib.ub_l2(w, it // 20, 2 << 20) / 1e12
+    out["l2_miss_64MB_per_xcd_TBps"] = lib.ub_l2(8, it // 40, 64 << 20) / 1e12
+    best = max(v["wave_insts_per_sec_per_simd"] for d in out["valu"].values() for v in d.values())
+    out["peaks"] = {"valu_wave_insts_per_sec_per_simd": best,
+                    "valu_wave_insts_per_sec_chip": best * 1024,
+                    "lds_random_b64_TBps": max(out["lds_random_b64_TBps"].values()),
+                    "l2_hit_TBps": max(out["l2_hit_dwordx4_TBps"].values())}
+    return out
+
+
+if __name__ == "__main__":
+    if "--build" in sys.argv:
+        print(build(force=True))
+    else:
+        print(json.dumps(measure("--quick" in sys.argv), indent=1))
