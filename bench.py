@@ -352,9 +352,10 @@ def main() -> int:
         except (OSError, ValueError):
             pass
         if world == 1:
-            h2d_bytes = last["total_bases"] * last["bits_per_base"] / 8
+            h2d_bytes = float(last["upload_bytes"])   # (half the packed set when the odd reads are rebuilt on the device)
             d2h_bytes = 24.0 * n_rows
-            out["pcie"] = {"h2d_bytes_per_step": int(h2d_bytes), "h2d_ms": pcie["h2d_s"] / K * 1e3,
+            out["pcie"] = {"h2d_bytes_per_step": int(h2d_bytes), "packed_read_set_bytes": int(last["total_bases"] * last["bits_per_base"] / 8),
+                           "h2d_ms": pcie["h2d_s"] / K * 1e3,
                            "h2d_GBps": h2d_bytes / (pcie["h2d_s"] / K) / 1e9 if pcie["h2d_s"] > 0 else None,
                            "d2h_bytes_per_step": int(d2h_bytes), "d2h_ms": pcie["d2h_s"] / K * 1e3,
                            "d2h_GBps": d2h_bytes / (pcie["d2h_s"] / K) / 1e9 if pcie["d2h_s"] > 0 else None,

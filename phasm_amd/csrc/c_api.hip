@@ -70,8 +70,17 @@ struct po_handle {
     int bits = 2;
     std::vector<std::string> ids;
     std::vector<uint32_t> len;
+    // Packed reads live in TWO host stores: words[0] holds the reads with an even index, words[1] those with an odd
+    // index, woff[r] is read r's first word inside ITS store.  `phasm overlap` adds every read as (x, revcomp x):
+    // when every odd read is exactly the reverse complement of its even partner (all_pairs_rc, checked word by word
+    // as the reads arrive) only store 0 crosses PCIe and store 1 is rebuilt on the device -- half the H2D bytes.
+    // On the device the two stores are one buffer [store 0 | store 1 | padding]; d_woff holds absolute offsets.
     std::vector<uint64_t> woff;
-    std::vector<uint64_t> words;
+    std::vector<uint64_t> words[2];
+    bool all_pairs_rc = true;   // every complete (even, odd) pair so far: same length, odd == revcomp(even), no exception records
+    uint64_t base1 = 0;         // first word of store 1 in the device buffer (set at upload)
+    uint64_t dev_words = 0;     // words in the device buffer, padding included
+    uint64_t upload_bytes = 0;  // bytes the last upload moved host->device
     // 2-bit mode: bytes other than upper-case A/C/G/T are stored as code 0 plus an exception record
     // (position, byte), sorted by read then position; exc_off has one entry per read + 1
     std::vector<uint32_t> exc_off{0};
@@ -101,8 +110,8 @@ struct po_handle {
     HostBuf scratch_host;  // pinned landing zone for small device->host copies into caller memory
     // the packed host store registered with the HIP runtime (hipHostRegister) while it is unchanged: the H2D of
     // po_upload then runs at the DMA rate instead of through the runtime's staging buffers
-    void* reg_ptr = nullptr;
-    size_t reg_bytes = 0;
+    void* reg_ptr[2] = {nullptr, nullptr};
+    size_t reg_bytes[2] = {0, 0};
     int poison = -1;       // PHASM_POISON=<byte>: per-call workspaces are filled with it before every call
     int live_results = 0;
 
@@ -179,14 +188,37 @@ po_status ensure_host(po_handle* h, HostBuf& b, size_t bytes) {
 
 // the packed host store is about to change (or go away): the runtime must let go of it first
 void unpin_words(po_handle* h) {
-    if (!h->reg_ptr) return;
+    if (!h->reg_ptr[0] && !h->reg_ptr[1]) return;
     if (h->dev_ready) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
     }
-    (void)hipHostUnregister(h->reg_ptr);
-    h->reg_ptr = nullptr;
-    h->reg_bytes = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (h->reg_ptr[k]) (void)hipHostUnregister(h->reg_ptr[k]);
+        h->reg_ptr[k] = nullptr;
+        h->reg_bytes[k] = 0;
+    }
+}
+
+// Pin host store k in place (once per state of the store; po_add_* unpins before it changes it): a pageable
+// source goes through the runtime's staging buffers at a fraction of the PCIe rate.  Failure to register is not
+// an error -- the copy works either way.
+void pin_words(po_handle* h, int k) {
+    const size_t bytes = h->words[k].size() * 8;
+    if (bytes < (1u << 20) || getenv("PHASM_NO_PIN")) return;
+    if (h->reg_ptr[k] == (void*)h->words[k].data() && h->reg_bytes[k] == bytes) return;
+    if (h->reg_ptr[k]) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipHostUnregister(h->reg_ptr[k]);
+        h->reg_ptr[k] = nullptr;
+        h->reg_bytes[k] = 0;
+    }
+    if (hipHostRegister(h->words[k].data(), bytes, hipHostRegisterDefault) == hipSuccess) {
+        h->reg_ptr[k] = h->words[k].data();
+        h->reg_bytes[k] = bytes;
+    } else {
+        (void)hipGetLastError();
+    }
 }
 
 #define PO_TRY(expr)                    \
@@ -240,11 +272,12 @@ const BaseLut g_lut;
 // which case the caller moves the whole handle to 8 bits per base.
 bool append_packed(po_handle* h, const unsigned char* s, size_t n, int bits) {
     const size_t per = 64 / bits;
-    const size_t old_size = h->words.size();
+    std::vector<uint64_t>& store = h->words[h->woff.size() & 1];  // (woff has one entry per read appended so far)
+    const size_t old_size = store.size();
     const size_t off = (old_size + 1) & ~size_t(1);
     const size_t nw = (n + per - 1) / per;
-    h->words.resize(off + nw + 1, 0);
-    uint64_t* w = h->words.data() + off;
+    store.resize(off + nw + 1, 0);
+    uint64_t* w = store.data() + off;
     if (bits == 2) {
         const uint8_t* lut = g_lut.v;
         uint8_t bad = 0;
@@ -272,7 +305,7 @@ bool append_packed(po_handle* h, const unsigned char* s, size_t n, int bits) {
             size_t cnt = 0;
             for (size_t i = 0; i < n; ++i) cnt += lut[s[i]] >> 7;
             if (cnt > n / 64 + 16) {
-                h->words.resize(old_size);
+                store.resize(old_size);
                 return false;
             }
             for (size_t i = 0; i < n; ++i) {
@@ -291,10 +324,10 @@ bool append_packed(po_handle* h, const unsigned char* s, size_t n, int bits) {
 }
 
 // The bytes of read r as they were added (2-bit mode: codes + exception records).
-void materialize(const po_handle* h, size_t r, const uint64_t* words, const uint64_t* woff, std::vector<unsigned char>& out) {
+void materialize(const po_handle* h, size_t r, const std::vector<uint64_t>* stores, const uint64_t* woff, std::vector<unsigned char>& out) {
     const uint32_t n = h->len[r];
     out.resize(n);
-    const uint64_t* w = words + woff[r];
+    const uint64_t* w = stores[r & 1].data() + woff[r];
     for (uint32_t i = 0; i < n; ++i) out[i] = "ACGT"[(w[i >> 5] >> ((i & 31) * 2)) & 3];
     for (uint32_t e = h->exc_off[r]; e < h->exc_off[r + 1]; ++e) out[h->exc_pos[e]] = h->exc_byte[e];
 }
@@ -302,16 +335,18 @@ void materialize(const po_handle* h, size_t r, const uint64_t* words, const uint
 // Non-ACGT bytes too dense for exception records: re-encode everything held so far at 8 bits per
 // base (lossless).
 void widen_to_bytes(po_handle* h) {
-    std::vector<uint64_t> old_words;
+    std::vector<uint64_t> old_words[2];
     std::vector<uint64_t> old_off;
-    old_words.swap(h->words);
+    old_words[0].swap(h->words[0]);
+    old_words[1].swap(h->words[1]);
     old_off.swap(h->woff);
     std::vector<unsigned char> tmp;
     for (size_t r = 0; r < h->len.size(); ++r) {
-        materialize(h, r, old_words.data(), old_off.data(), tmp);
+        materialize(h, r, old_words, old_off.data(), tmp);
         append_packed(h, tmp.data(), h->len[r], 8);
     }
     h->bits = 8;
+    h->all_pairs_rc = false;
     h->exc_off.assign(1, 0);
     h->exc_pos.clear();
     h->exc_byte.clear();
@@ -346,7 +381,7 @@ void host_pair_check(po_handle* h, size_t r, const unsigned char* s) {
         state = 2;
     } else {
         std::vector<unsigned char> prev;
-        materialize(h, r - 1, h->words.data(), h->woff.data(), prev);
+        materialize(h, r - 1, h->words, h->woff.data(), prev);
         const unsigned char* c = comp_table();
         for (uint32_t i = 0; i < n; ++i) {
             const unsigned char x = prev[n - 1 - i], y = s[i];
@@ -357,6 +392,35 @@ void host_pair_check(po_handle* h, size_t r, const unsigned char* s) {
         }
     }
     h->pair_state[pair] = state;
+}
+
+// 2-bit mode, read r (odd index) just appended: are its packed words exactly the reverse complement of read r-1's?
+// (word arithmetic of k_paired_check / k_revcomp_store on the host: ~2 us per 15 kb read)
+bool packed_is_revcomp(const po_handle* h, size_t r) {
+    const uint32_t L = h->len[r];
+    if (h->len[r - 1] != L) return false;
+    if (h->exc_off[r - 1] != h->exc_off[r] || h->exc_off[r] != h->exc_off[r + 1]) return false;  // exception records
+    const uint64_t* R = h->words[0].data() + h->woff[r - 1];
+    const uint64_t* S = h->words[1].data() + h->woff[r];
+    const uint32_t nw = (L + 31) / 32;
+    for (uint32_t w = 0; w < nw; ++w) {
+        const int64_t o = (int64_t)L - 32 * (int64_t)w - 32;  // first base of R facing word w of S
+        uint64_t x;
+        uint32_t valid = 32;
+        if (o >= 0) {
+            const uint32_t sh = (uint32_t)(o & 31) * 2;
+            x = sh ? (R[o >> 5] >> sh) | (R[(o >> 5) + 1] << (64 - sh)) : R[o >> 5];
+        } else {
+            valid = (uint32_t)(32 + o);
+            x = R[0] << ((uint32_t)(-o) * 2);
+        }
+        uint64_t y = __builtin_bitreverse64(x);
+        y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+        y = ~y;
+        const uint64_t mask = valid >= 32 ? ~0ull : ((1ull << (valid * 2)) - 1ull);
+        if (((y ^ S[w]) & mask) != 0) return false;
+    }
+    return true;
 }
 
 inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -381,42 +445,70 @@ po_status upload(po_handle* h) {
     h->h_read_tile0[n] = (uint32_t)nt;
     h->n_tiles = (uint32_t)nt;
 
-    // Pin the packed store in place (once per state of the store; po_add_* unpins before it changes it): a
-    // pageable source goes through the runtime's staging buffers at a fraction of the PCIe rate.  Failure to
-    // register is not an error -- the copy below works either way.
-    const size_t word_bytes = h->words.size() * 8;
-    if (word_bytes >= (1u << 20) && !getenv("PHASM_NO_PIN") &&
-        (h->reg_ptr != (void*)h->words.data() || h->reg_bytes != word_bytes)) {
-        unpin_words(h);
-        if (hipHostRegister(h->words.data(), word_bytes, hipHostRegisterDefault) == hipSuccess) {
-            h->reg_ptr = h->words.data();
-            h->reg_bytes = word_bytes;
-        } else {
-            (void)hipGetLastError();
-        }
-    }
-
-    const size_t nwords = h->words.size() + 72;  // trailing zero padding: a scan tile may read 64+1 words past a read's start
+    // Device buffer: [store 0 | store 1 | 72 zero words] (a scan tile may read 64+1 words past a read's start).
+    // Only store 0 travels when every odd read is the reverse complement of its even partner: store 1 is then
+    // rebuilt on the device, bit for bit what the host packed (k_revcomp_store).
+    const uint64_t base1 = (h->words[0].size() + 1) & ~uint64_t(1);
+    const uint64_t nwords = base1 + h->words[1].size() + 72;
+    const bool generate = h->bits == 2 && n >= 2 && (n % 2) == 0 && h->all_pairs_rc && h->exc_pos.empty() &&
+                          !getenv("PHASM_FULL_UPLOAD");
+    h->base1 = base1;
+    h->dev_words = nwords;
+    pin_words(h, 0);
+    if (!generate) pin_words(h, 1);
     PO_TRY(ensure(h, h->d_words, nwords * 8));
     PO_TRY(ensure(h, h->d_woff, ((size_t)n + 1) * 8));
     PO_TRY(ensure(h, h->d_len, ((size_t)n + 1) * 4));
     PO_TRY(ensure(h, h->d_tiles, ((size_t)h->n_tiles + 1) * sizeof(po::TileRec)));
     PO_TRY(ensure(h, h->d_read_tile0, ((size_t)n + 1) * 4));
     HIP_TRY(h, hipEventRecord(h->ev_up0, h->stream));
-    // (the guard words between the reads are zeros in the host store already: only the tail needs clearing)
-    HIP_TRY(h, hipMemsetAsync(h->d_words.as<uint64_t>() + h->words.size(), 0, 72 * 8, h->stream));
-    if (!h->words.empty())
-        HIP_TRY(h, hipMemcpyAsync(h->d_words.p, h->words.data(), word_bytes, hipMemcpyHostToDevice, h->stream));
+    uint64_t* dw = h->d_words.as<uint64_t>();
+    // (the guard words between the reads are zeros in the host stores already: only the seam and the tail need clearing)
+    HIP_TRY(h, hipMemsetAsync(dw + base1 + h->words[1].size(), 0, 72 * 8, h->stream));
+    if (base1 != h->words[0].size()) HIP_TRY(h, hipMemsetAsync(dw + h->words[0].size(), 0, 8, h->stream));
+    h->upload_bytes = 0;
+    if (!h->words[0].empty()) {
+        HIP_TRY(h, hipMemcpyAsync(dw, h->words[0].data(), h->words[0].size() * 8, hipMemcpyHostToDevice, h->stream));
+        h->upload_bytes += h->words[0].size() * 8;
+    }
+    if (!generate && !h->words[1].empty()) {
+        HIP_TRY(h, hipMemcpyAsync(dw + base1, h->words[1].data(), h->words[1].size() * 8, hipMemcpyHostToDevice, h->stream));
+        h->upload_bytes += h->words[1].size() * 8;
+    }
     if (n) {
         HIP_TRY(h, hipMemcpyAsync(h->d_woff.p, h->woff.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->d_len.p, h->len.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+        h->upload_bytes += (size_t)n * 12;
+        // store-relative offsets -> offsets into the device buffer
+        hipLaunchKernelGGL(po::k_abs_woff, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, h->d_woff.as<uint64_t>(), n, base1);
     }
     HIP_TRY(h, hipMemcpyAsync(h->d_read_tile0.p, h->h_read_tile0.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, h->stream));
+    h->upload_bytes += ((size_t)n + 1) * 4;
+    if (generate) {
+        hipLaunchKernelGGL(po::k_revcomp_store, dim3(cdiv((uint64_t)(n / 2) * 64, 256)), dim3(256), 0, h->stream, dw,
+                           h->d_woff.as<uint64_t>(), h->d_len.as<uint32_t>(), n / 2);
+        if (getenv("PHASM_VERIFY_GENERATED") && !h->words[1].empty()) {
+            // test mode: the host's own store 1 is uploaded next to the generated one and compared word by word
+            DevBuf tmp;
+            PO_TRY(ensure(h, tmp, h->words[1].size() * 8));
+            PO_TRY(ensure(h, h->d_scalars, 64));
+            HIP_TRY(h, hipMemsetAsync(h->d_scalars.p, 0, 64, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(tmp.p, h->words[1].data(), h->words[1].size() * 8, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(po::k_count_diff, dim3(1024), dim3(256), 0, h->stream, dw + base1, tmp.as<uint64_t>(),
+                               (uint64_t)h->words[1].size(), h->d_scalars.as<unsigned long long>());
+            HIP_TRY(h, hipMemcpyAsync(h->pinned, h->d_scalars.p, 8, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            tmp.release();
+            if (h->pinned[0] != 0)
+                return fail(h, PO_ERR_HIP, "generated reverse-complement store differs from the host's in " +
+                                               std::to_string(h->pinned[0]) + " words");
+        }
+    }
     if (h->n_tiles) {
         hipLaunchKernelGGL(po::k_build_tiles, dim3(cdiv(h->n_tiles, 256)), dim3(256), 0, h->stream, h->d_woff.as<uint64_t>(),
                            h->d_len.as<uint32_t>(), h->d_read_tile0.as<uint32_t>(), n, h->n_tiles, h->d_tiles.as<po::TileRec>());
-        HIP_TRY(h, hipGetLastError());
     }
+    HIP_TRY(h, hipGetLastError());
     // exception records (2-bit mode only; usually none)
     const size_t n_exc = h->bits == 2 ? h->exc_pos.size() : 0;
     if (n_exc) {
@@ -430,7 +522,9 @@ po_status upload(po_handle* h) {
     h->n_exc_uploaded = n_exc;
     // strand pairing: decides whether po_overlaps may compute one member of each mirror pair
     h->paired = false;
-    const bool try_paired = h->bits == 2 && n >= 2 && (n % 2) == 0 && !getenv("PHASM_NO_MIRROR");
+    const bool mirror_ok = !getenv("PHASM_NO_MIRROR");
+    const bool try_paired = h->bits == 2 && n >= 2 && (n % 2) == 0 && mirror_ok && !generate;
+    if (generate && mirror_ok) h->paired = true;  // (checked word by word on the host as the reads arrived)
     if (try_paired) {
         PO_TRY(ensure(h, h->d_scalars, 64));
         HIP_TRY(h, hipMemsetAsync(h->d_scalars.p, 0, 64, h->stream));
@@ -453,6 +547,7 @@ po_status upload(po_handle* h) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, h->ev_up0, h->ev_up1);
     h->stats.ms_upload = ms;
+    h->stats.upload_bytes = h->upload_bytes;
     h->dirty = false;
     return PO_OK;
 }
@@ -505,6 +600,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     const float keep_upload = S.ms_upload;
     S = po_stats();
     S.ms_upload = keep_upload;
+    S.upload_bytes = h->upload_bytes;
     S.bits_per_base = BITS;
     S.kmer = K;
     S.n_reads = n;
@@ -802,7 +898,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             }
             const uint32_t ver_grid = perm ? 8 * ((n_a + 7) / 8) : n_a;
             // candidate records staged in LDS (word offsets must fit 32 bits); PHASM_VERIFY_STAGED=0 switches back
-            bool staged = h->words.size() + 72 < 0xFFFFFFF0ull;
+            bool staged = h->dev_words < 0xFFFFFFF0ull;
             if (const char* e = getenv("PHASM_VERIFY_STAGED")) staged = staged && atoi(e) != 0;
             auto verify = paired == 2u ? (staged ? po::k_verify_a<BITS, true, true> : po::k_verify_a<BITS, true, false>)
                                        : (staged ? po::k_verify_a<BITS, false, true> : po::k_verify_a<BITS, false, false>);
@@ -1303,20 +1399,23 @@ bool add_fasta_parallel(po_handle* h, const char* data, size_t size, uint64_t* n
     for (const FastaRec& r : recs)
         if (r.seq_len > 0x7FFFFFF0ull) return false;  // (the sequential path reports it)
     if (h->len.size() + 2 * recs.size() >= 0xFFFFFFF0ull) return false;
-    // final place of every oriented read in the packed store (append_packed's layout)
-    const size_t old_words = h->words.size();
+    // final place of every oriented read in its packed store (append_packed's layout): forward reads go to the
+    // store of the next read's parity, reverse complements to the other one
+    if (h->len.size() & 1) return false;  // (an odd number of reads so far: pairs would straddle the stores; sequential path)
+    const size_t old_words[2] = {h->words[0].size(), h->words[1].size()};
     std::vector<size_t> off(2 * recs.size());
-    size_t cur = old_words;
+    size_t cur[2] = {old_words[0], old_words[1]};
     for (size_t i = 0; i < recs.size(); ++i) {
         const size_t nw = (recs[i].seq_len + 31) / 32;
         for (int k = 0; k < 2; ++k) {
-            const size_t o = (cur + 1) & ~size_t(1);
+            const size_t o = (cur[k] + 1) & ~size_t(1);
             off[2 * i + k] = o;
-            cur = o + nw + 1;
+            cur[k] = o + nw + 1;
         }
     }
-    h->words.resize(cur, 0);
-    uint64_t* words = h->words.data();
+    h->words[0].resize(cur[0], 0);
+    h->words[1].resize(cur[1], 0);
+    uint64_t* words[2] = {h->words[0].data(), h->words[1].data()};
     const uint8_t* lut = g_lut.v;
     const unsigned char* comp = comp_table();
     std::atomic<size_t> next{0};
@@ -1366,10 +1465,14 @@ bool add_fasta_parallel(po_handle* h, const char* data, size_t size, uint64_t* n
                     p += n;
                 }
                 const size_t n = seq.size();
+                if (n != r.seq_len) {  // (pass A sized the stores with seq_len: never pack anything else into them)
+                    bad.store(1);
+                    return;
+                }
                 rc.resize(n);
                 for (size_t k = 0; k < n; ++k) rc[k] = (char)comp[(unsigned char)seq[n - 1 - k]];
-                uint8_t b = pack(reinterpret_cast<const unsigned char*>(seq.data()), n, words + off[2 * i]);
-                b |= pack(reinterpret_cast<const unsigned char*>(rc.data()), n, words + off[2 * i + 1]);
+                uint8_t b = pack(reinterpret_cast<const unsigned char*>(seq.data()), n, words[0] + off[2 * i]);
+                b |= pack(reinterpret_cast<const unsigned char*>(rc.data()), n, words[1] + off[2 * i + 1]);
                 if (n != r.seq_len || (b & 0x80)) {
                     bad.store(1);
                     return;
@@ -1393,7 +1496,8 @@ bool add_fasta_parallel(po_handle* h, const char* data, size_t size, uint64_t* n
         for (auto& th : thr) th.join();
     }
     if (bad.load()) {  // something other than upper-case ACGT: let the sequential path deal with it
-        h->words.resize(old_words);
+        h->words[0].resize(old_words[0]);
+        h->words[1].resize(old_words[1]);
         return false;
     }
     h->ids.reserve(h->ids.size() + 2 * recs.size());
@@ -1481,7 +1585,10 @@ po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const cha
         h->total_bases += seq_len;
         h->dirty = true;
         h->ids_paired = -1;
-        if (h->bits == 2 && (h->len.size() & 1) == 0 && !h->exc_pos.empty()) host_pair_check(h, h->len.size() - 1, s);
+        if (h->bits == 2 && (h->len.size() & 1) == 0) {
+            if (!h->exc_pos.empty()) host_pair_check(h, h->len.size() - 1, s);
+            if (h->all_pairs_rc) h->all_pairs_rc = packed_is_revcomp(h, h->len.size() - 1);
+        }
     } catch (const std::bad_alloc&) {
         return fail(h, PO_ERR_NOMEM, "out of host memory in po_add_sequence");
     }

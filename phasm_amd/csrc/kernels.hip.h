@@ -80,6 +80,22 @@ __global__ void k_build_tiles(const uint64_t* __restrict__ woff, const uint32_t*
     tiles[t] = rec;
 }
 
+// woff arrives relative to each read's host store (even reads: store 0, odd reads: store 1); on the device the
+// stores sit one behind the other
+__global__ void k_abs_woff(uint64_t* __restrict__ woff, uint32_t n_reads, uint64_t base1) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_reads && (r & 1u)) woff[r] += base1;
+}
+
+// word-by-word difference count of two buffers (PHASM_VERIFY_GENERATED: generated store 1 against the host's)
+__global__ void k_count_diff(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t n,
+                             unsigned long long* __restrict__ n_diff) {
+    unsigned long long d = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        d += a[i] != b[i];
+    if (d) atomicAdd(n_diff, d);
+}
+
 // ----------------------------------------------------------------------------------------
 // small helpers
 // ----------------------------------------------------------------------------------------
@@ -1931,6 +1947,40 @@ __global__ __launch_bounds__(256) void k_paired_check(const uint64_t* __restrict
         }
     }
     if (__any(bad) && lane == 0) atomicAdd(n_bad, 1u);
+}
+
+// Store 1 rebuilt on the device: when every odd read is the reverse complement of its even partner (checked on the
+// host as the reads were added) only the even reads cross PCIe.  One wave per pair; lane l writes words l, l+64, ...
+// of read 2i+1 = the matching window of read 2i reversed (bit reverse + swap the two bits of every base) and
+// complemented (~), bits beyond the read's end cleared, plus the zero guard word -- bit for bit what the host packs.
+__global__ __launch_bounds__(256) void k_revcomp_store(uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
+                                                       const uint32_t* __restrict__ len, uint32_t n_pairs) {
+    const uint32_t pair = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (pair >= n_pairs) return;
+    const uint32_t lane = lane_id();
+    const uint32_t L = len[2 * pair];
+    const uint64_t* __restrict__ R = words + woff[2 * pair];
+    uint64_t* __restrict__ S = words + woff[2 * pair + 1];
+    const uint32_t nw = (L + 31) / 32;
+    for (uint32_t w = lane; w <= nw; w += WAVE) {
+        uint64_t out = 0;  // w == nw: the guard word
+        if (w < nw) {
+            const int64_t o = (int64_t)L - 32 * (int64_t)w - 32;  // first base of R facing this word
+            uint64_t x;
+            uint32_t valid = 32;
+            if (o >= 0) {
+                x = funnel(R[o >> 5], R[(o >> 5) + 1], (uint32_t)(o & 31) * 2);
+            } else {
+                valid = (uint32_t)(32 + o);
+                x = R[0] << ((uint32_t)(-o) * 2);
+            }
+            uint64_t y = __brevll(x);
+            y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+            y = ~y;
+            out = valid >= 32 ? y : (y & ((1ull << (valid * 2)) - 1ull));
+        }
+        S[w] = out;
+    }
 }
 
 // ----------------------------------------------------------------------------------------

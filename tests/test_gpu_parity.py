@@ -583,3 +583,46 @@ def test_many_identical_reads_wide_index(monkeypatch):
     same(got, want)
     got, _ = hip_rows(seqs, 100, shard=3)
     same(got, want)
+
+
+def test_store1_rebuilt_on_the_device_is_what_the_host_packed(monkeypatch):
+    """Reads added as (x, revcomp x) pairs: only the even reads cross PCIe, the odd ones are rebuilt on the device
+    (k_revcomp_store).  PHASM_VERIFY_GENERATED uploads the host's own packed odd reads next to the rebuilt ones and
+    fails the call on any differing word; PHASM_FULL_UPLOAD switches the shortcut off.  Same rows every way."""
+    monkeypatch.setenv("PHASM_VERIFY_GENERATED", "1")
+    rc = bytes.maketrans(b"ACGT", b"TGCA")
+    rng = np.random.default_rng(99)
+    lens = [1, 2, 31, 32, 33, 63, 64, 65, 100, 257, 2047, 2048, 2049, 4097]
+    reads = []
+    for ln in lens * 3:
+        r = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=ln))
+        reads += [r, r.translate(rc)[::-1]]
+    ov = ExactOverlapper()
+    for i, s in enumerate(reads):
+        ov.add_sequence("r%d" % i, s)
+    got = oo.sort_rows(oo.struct_to_rows(ov.overlaps_array(1)))
+    st = ov.stats()
+    ov.close()
+    packed = sum(((len(s) + 31) // 32 + 1) * 8 for s in reads)
+    assert st["paired"] == 1 and st["upload_bytes"] < 0.6 * packed + 16 * len(reads) + 4096
+    _last.update(seqs=reads, m=1)
+    same(got, ck.oracle_overlaps(reads, 1))
+    for name in ("ladder_varlen", "cfg2_1k"):
+        _, seqs, m, want = gu.ladder_case(name)
+        got, st = hip_rows(seqs, m)
+        assert st["paired"] == 1
+        same(got, want, name)
+    # one base off in one odd read: no shortcut, the pair check fails, still the right rows
+    seqs = list(seqs)
+    s = bytearray(seqs[41])
+    s[7] = ord("A") if s[7] != ord("A") else ord("C")
+    seqs[41] = bytes(s)
+    got, st = hip_rows(seqs, m)
+    assert st["paired"] == 0
+    same(got, ck.oracle_overlaps(seqs, m))
+    monkeypatch.delenv("PHASM_VERIFY_GENERATED")
+    monkeypatch.setenv("PHASM_FULL_UPLOAD", "1")
+    _, seqs, m, want = gu.ladder_case("cfg2_1k")
+    got, st2 = hip_rows(seqs, m)
+    assert st2["paired"] == 1 and st2["upload_bytes"] > 1.9 * sum(((len(s) + 31) // 32) * 8 for s in seqs[::2])
+    same(got, want)

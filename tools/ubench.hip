@@ -27,7 +27,19 @@ __global__ __launch_bounds__(256) void k_valu(uint32_t* out, int iters, uint32_t
 #define STEP(r)                                                                                              \
     if (OP == 0) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(sh));                  \
     else if (OP == 1) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r) : "v"(c));                               \
-    else asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(r) : "v"(sh));
+    else if (OP == 2) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(r) : "v"(sh));                          \
+    else if (OP == 3) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(r) : "v"(c));                       \
+    else if (OP == 4) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "s"(sh));             \
+    else if (OP == 5) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(sh));                 \
+    else if (OP == 6) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(sh));               \
+    else if (OP == 7) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(r) : "v"(c));                        \
+    else if (OP == 8) asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(r));                                     \
+    else if (OP == 9) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(sh));                 \
+    else if (OP == 10) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(sh));                \
+    else if (OP == 11) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x80" : "+v"(r) : "v"(c), "v"(sh));  \
+    else if (OP == 12) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r) : "s"(sh));                             \
+    else if (OP == 13) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "s"(sh));                \
+    else asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(sh));
         STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
         STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
 #undef STEP
@@ -84,7 +96,7 @@ static double time_ms(hipEvent_t e0, hipEvent_t e1) {
 
 extern "C" {
 
-// wave-instructions per second per SIMD (1024 SIMDs); op 0 v_alignbit_b32, 1 v_xor_b32, 2 v_lshrrev_b32
+// wave-instructions per second per SIMD (1024 SIMDs); op: see the STEP macro
 double ub_valu(int op, int waves_per_simd, int iters) {
     const int n_cu = 256, rounds = 4;
     const int grid = n_cu * waves_per_simd * rounds;
@@ -94,7 +106,10 @@ double ub_valu(int op, int waves_per_simd, int iters) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    auto kern = op == 0 ? k_valu<0> : op == 1 ? k_valu<1> : k_valu<2>;
+    void (*kerns[])(uint32_t*, int, uint32_t) = {k_valu<0>, k_valu<1>, k_valu<2>, k_valu<3>, k_valu<4>, k_valu<5>, k_valu<6>, k_valu<7>,
+                                                 k_valu<8>, k_valu<9>, k_valu<10>, k_valu<11>, k_valu<12>, k_valu<13>, k_valu<14>};
+    if (op < 0 || op > 14) return -1.0;
+    auto kern = kerns[op];
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, out, iters / 8, 7u);
     CHECK(hipDeviceSynchronize());

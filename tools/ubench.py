@@ -39,9 +39,12 @@ def measure(quick=False):
     lib = load()
     it = 20000 if quick else 100000
     out = {"valu": {}, "lds_random_b64_TBps": {}, "l2_hit_dwordx4_TBps": {}}
-    for op, name in enumerate(("v_alignbit_b32", "v_xor_b32", "v_lshrrev_b32")):
+    ops = ("v_alignbit_b32 v,v,v", "v_xor_b32", "v_lshrrev_b32", "v_alignbit_b32 v,v,imm", "v_alignbit_b32 v,v,s",
+           "v_or3_b32 v,v,v", "v_and_or_b32 v,v,v", "v_lshl_or_b32 v,imm,v", "v_bfe_u32 v,imm,imm", "v_add3_u32 v,v,v",
+           "v_perm_b32 v,v,v", "v_bitop3_b32 v,v,v", "v_and_b32 v,s", "v_or3_b32 v,v,s", "v_mad_u32_u24 v,v,v")
+    for op, name in enumerate(ops):
         out["valu"][name] = {}
-        for w in (1, 2, 4, 8):
+        for w in ((1, 2, 4, 8) if op < 3 else (2, 8)):
             r = lib.ub_valu(op, w, it)
             out["valu"][name]["%d_waves_per_simd" % w] = {"wave_insts_per_sec_per_simd": r, "cycles_per_inst_at_2.4GHz": 2.4e9 / r}
     for w in (1, 2, 4, 8):
