@@ -1962,8 +1962,10 @@ __global__ __launch_bounds__(256) void k_revcomp_store(uint64_t* __restrict__ wo
     const uint64_t* __restrict__ R = words + woff[2 * pair];
     uint64_t* __restrict__ S = words + woff[2 * pair + 1];
     const uint32_t nw = (L + 31) / 32;
-    for (uint32_t w = lane; w <= nw; w += WAVE) {
-        uint64_t out = 0;  // w == nw: the guard word
+    // words nw (the guard word) and, when the next read's 16-byte alignment leaves one, the padding word behind it
+    const uint32_t last = nw + (uint32_t)((woff[2 * pair + 1] + nw + 1) & 1ull);
+    for (uint32_t w = lane; w <= last; w += WAVE) {
+        uint64_t out = 0;  // w >= nw: guard / padding
         if (w < nw) {
             const int64_t o = (int64_t)L - 32 * (int64_t)w - 32;  // first base of R facing this word
             uint64_t x;
