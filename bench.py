@@ -85,6 +85,23 @@ def measured_hbm_gbs(device) -> float:
     return 2.0 * n / (ms * 1e-3) / 1e9
 
 
+def measured_peaks() -> dict:
+    """The hardware rates the kernels are priced against, measured now (tools/ubench.hip through tools/ubench.py)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import ubench
+        lib = ubench.load()
+        valu = max(lib.ub_valu(op, 8, 40000) for op in (1, 2))      # v_xor_b32 / v_lshrrev_b32, 8 waves per SIMD
+        return {"valu_wave_insts_per_sec_chip": valu * 1024,
+                "valu_cycles_per_inst_at_2.4GHz": 2.4e9 / valu,
+                "valu_vop3_wave_insts_per_sec_chip": lib.ub_valu(0, 8, 40000) * 1024,   # v_alignbit_b32: VOP3 forms issue at half rate
+                "lds_random_b64_TBps": lib.ub_lds(8, 4000) / 1e12,
+                "l2_hit_TBps": lib.ub_l2(8, 2000, 2 << 20) / 1e12,
+                "fabric_TBps": lib.ub_l2(8, 1000, 64 << 20) / 1e12}
+    except Exception as e:  # noqa: BLE001 -- the bench line must come out even if the microbenchmarks cannot run
+        return {"error": repr(e)}
+
+
 def layout_leg(ov: ExactOverlapper, m: int, with_cpu: bool) -> dict:
     """Next row of the path: stage 1 of `phasm layout` -- classify, contained-read
     and alignment filters, assembly-graph edges -- on the rows of one step, still resident in HBM."""
@@ -103,12 +120,20 @@ def layout_leg(ov: ExactOverlapper, m: int, with_cpu: bool) -> dict:
     dt = (time.perf_counter() - t0) / K
     st = ov.layout_stats()
     algo = 24 * st["n_rows"] + 16 * st["n_edges"]           # every row read once, every edge written once
+    traffic = None
+    try:   # HBM-side bytes of the layout kernels from the rocprofv3 --pmc passes (profiles/traffic.json)
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            lt = [v for k, v in json.load(f).get("cfg2", {}).items() if k.startswith("k_layout_") or k.startswith("k_count_bytes")]
+        traffic = int(sum(lt)) if lt else None
+    except (OSError, ValueError):
+        pass
     out = {"rows_per_sec": st["n_rows"] / dt, "ms_per_call": dt * 1e3, "device_ms": acc / K,
            "n_rows": st["n_rows"], "n_edges": st["n_edges"], "n_contained_reads": st["n_contained_reads"],
            "stage_ms": {k: round(st[k], 4) for k in ("ms_classify", "ms_dedupe", "ms_emit")},
            "roofline": {"bound": "hbm", "kernel": "k_layout_insert + k_layout_winner (hash table, random access)",
                         "achieved": algo / (acc / K * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": algo / (acc / K * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac": algo / (acc / K * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                        "traffic_GBps": traffic / (acc / K * 1e-3) / 1e9 if traffic else None,
                         "algorithmic_bytes_per_call": int(algo)}}
     if with_cpu:
         from oracle import layout_oracle as lo
@@ -303,54 +328,82 @@ def main() -> int:
             "stage_ms": {k: round(v, 4) for k, v in avg.items()},
             "load_seconds": round(t_load, 1),
         }
-        # The two kernels that make up three quarters of a step, each against the HBM roofline with its share of
-        # SURVEY.md section 8d's algorithmic bytes: the scan streams the packed reads once (B * bits / 8), the verify
-        # carries both sides of every emitted overlap (sum 2 * ceil(l * bits / 8)).  `roofline` itself is the one with
-        # the longer launch, as the contract asks; both are VALU-issue bound, not HBM bound.
+        # ---- roofline.  The contract's figure -- SURVEY.md section 8d's algorithmic bytes / launch time -- is kept as
+        # `algorithmic_GBps`, but it is not a fraction of anything for these kernels: the verify reads a from LDS and b
+        # from L2, compares a strand-mirror pair once and emits it twice.  Each kernel is priced instead against the
+        # four things it can saturate, with peaks MEASURED on this box (tools/ubench.hip, run live below):
+        #   hbm   bytes on the memory side of L2 (PMC FETCH_SIZE / WRITE_SIZE, profiles/traffic.json) vs 8 TB/s
+        #   l2    bytes the kernel loads from L2 vs the measured L2-hit rate of global_load_dwordx4
+        #   lds   bytes it reads from LDS vs the measured rate of random ds_read_b64
+        #   valu  VALU wave-instructions (PMC SQ_INSTS_VALU) vs the measured issue rate of 2-operand integer ops
+        # `bound` = the largest fraction; every fraction is <= 1 by construction.
         bits = last["bits_per_base"]
         scan_bytes = last["shard_bases"] * bits // 8
+        exec_bytes = last["verify_bytes_exec"]          # both sides of every VERIFIED CANDIDATE, once
         sharded = "true" if world > 1 else "false"
-        kern = {
-            ("k_wide_scan<%d, false>" % bits) if last["wide_index"] else ("k_scan_probe<%d, true>" % bits): {
-                "algorithmic_bytes_per_launch": int(scan_bytes), "avg_launch_ms": avg["ms_scan_probe"]},
-            "k_verify_a<%d, %s, true>" % (bits, sharded): {
-                "algorithmic_bytes_per_launch": int(ver_bytes), "avg_launch_ms": avg["ms_verify_kernel"]},
-        }
-        for v in kern.values():
-            v["achieved"] = v["algorithmic_bytes_per_launch"] / (v["avg_launch_ms"] * 1e-3) / 1e9 if v["avg_launch_ms"] > 0 else 0.0
-            v["frac"] = v["achieved"] / HBM_PEAK_GBS
-            v["traffic"] = None
-        dom = max(kern, key=lambda k: kern[k]["avg_launch_ms"])
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": kern[dom]["frac"], "traffic": None,
-                           "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes_per_launch"],
-                           "avg_launch_ms": kern[dom]["avg_launch_ms"],
-                           "actual_bound": "VALU issue (integer compare / bit tests), see DESIGN.md 3.3 and 3.5",
-                           "kernels": kern,
-                           "job_achieved": job_gbs, "job_frac": job_gbs / HBM_PEAK_GBS,
-                           "job_algorithmic_bytes": int(job_bytes)}
-        # HBM-side traffic comes from separate rocprofv3 --pmc passes on the same workload (profiles/r01_v9_pmc.md,
-        # profiles/traffic.json); it cannot be read from inside this process
+        scan_name = ("k_wide_scan<%d, false>" % bits) if last["wide_index"] else ("k_scan_probe<%d, true>" % bits)
+        ver_name = "k_verify_a<%d, %s, true>" % (bits, sharded)
+        peaks = measured_peaks() if world == 1 else {}
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                tr = json.load(f).get(args.config, {}) if not args.reads and world == 1 else {}
-            for k, v in kern.items():
-                v["traffic"] = tr.get(k)
-            out["roofline"]["traffic"] = kern[dom]["traffic"]
-            # issue-side view of the same kernels (SQ counters, same passes): VALU instructions x 4 cycles on a
-            # 16-lane SIMD against the SIMD cycles of the launch, 4 SIMDs x SQ_BUSY_CU_CYCLES (summed over the CUs:
-            # the launch in shader clocks, which run near 2.05 GHz under this load, not at the 2.4 GHz peak)
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                tj = json.load(f)
-            vi = tj.get(args.config + "_valu_wave_insts", {}) if not args.reads and world == 1 else {}
-            bc = tj.get(args.config + "_busy_cu_cycles", {}) if not args.reads and world == 1 else {}
-            for k, v in kern.items():
-                if k in vi and k in bc and v["avg_launch_ms"] > 0:
-                    v["valu_utilisation"] = vi[k] * 4.0 / (4.0 * bc[k])
-                    v["shader_clock_ghz_profiled"] = bc[k] / 256.0 / (v["avg_launch_ms"] * 1e-3) / 1e9
-            out["roofline"]["valu_utilisation"] = kern[dom].get("valu_utilisation")
+                tj = json.load(f) if not args.reads and world == 1 else {}
         except (OSError, ValueError):
-            pass
+            tj = {}
+        pmc_traffic = tj.get(args.config, {})
+        pmc_ctr = tj.get(args.config + "_counters", {})
+        positions = last["shard_bases"]                  # one filter lookup (8 B of LDS) per position of the scan
+        kern = {
+            scan_name: {"avg_launch_ms": avg["ms_scan_probe"], "algorithmic_bytes_per_launch": int(scan_bytes),
+                        "l2_bytes": None if last["wide_index"] else int(scan_bytes),   # (+ the table groups, counted on the hbm side)
+                        "lds_bytes": None if last["wide_index"] else int(positions * 8)},
+            ver_name: {"avg_launch_ms": avg["ms_verify_kernel"], "algorithmic_bytes_per_launch": int(ver_bytes),
+                       "executed_compare_bytes": int(exec_bytes),
+                       "l2_bytes": int(exec_bytes // 2),             # the b side streams from L2 (locality order)
+                       "lds_bytes": int(exec_bytes // 2 * 5 // 4)},  # the a side: 5 dwords read per 4 compared
+        }
+        for name, v in kern.items():
+            t = v["avg_launch_ms"] * 1e-3
+            v["algorithmic_GBps"] = v["algorithmic_bytes_per_launch"] / t / 1e9 if t > 0 else 0.0
+            v["traffic"] = pmc_traffic.get(name)
+            lim = {}
+            if v["traffic"] and t > 0:
+                lim["hbm"] = {"GBps": v["traffic"] / t / 1e9, "peak_GBps": HBM_PEAK_GBS}
+            if v.get("l2_bytes") and peaks.get("l2_hit_TBps") and t > 0:
+                lim["l2"] = {"GBps": v["l2_bytes"] / t / 1e9, "peak_GBps": peaks["l2_hit_TBps"] * 1e3}
+            if v.get("lds_bytes") and peaks.get("lds_random_b64_TBps") and t > 0:
+                lim["lds"] = {"GBps": v["lds_bytes"] / t / 1e9, "peak_GBps": peaks["lds_random_b64_TBps"] * 1e3}
+            ctr = pmc_ctr.get(name, {})
+            if ctr.get("SQ_INSTS_VALU") and peaks.get("valu_wave_insts_per_sec_chip") and t > 0:
+                lim["valu"] = {"G_wave_insts_per_s": ctr["SQ_INSTS_VALU"] / t / 1e9,
+                               "peak_G_wave_insts_per_s": peaks["valu_wave_insts_per_sec_chip"] / 1e9,
+                               "wave_insts_per_launch": ctr["SQ_INSTS_VALU"]}
+            for k2, x in lim.items():
+                ach = x.get("GBps", x.get("G_wave_insts_per_s"))
+                pk = x.get("peak_GBps", x.get("peak_G_wave_insts_per_s"))
+                x["frac"] = ach / pk
+            v["limits"] = lim
+            if lim:
+                v["bound"] = max(lim, key=lambda k2: lim[k2]["frac"])
+                v["frac"] = lim[v["bound"]]["frac"]
+        dom = max(kern, key=lambda k: kern[k]["avg_launch_ms"])
+        d = kern[dom]
+        bl = d["limits"].get(d.get("bound", ""), {})
+        out["roofline"] = {"bound": d.get("bound"), "kernel": dom,
+                           "achieved": bl.get("GBps", bl.get("G_wave_insts_per_s")),
+                           "peak": bl.get("peak_GBps", bl.get("peak_G_wave_insts_per_s")),
+                           "unit": "G wave-instructions/s" if d.get("bound") == "valu" else "GB/s",
+                           "frac": d.get("frac"), "traffic": d["traffic"],
+                           "hbm_frac": d["limits"].get("hbm", {}).get("frac"),
+                           "avg_launch_ms": d["avg_launch_ms"],
+                           "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                           "algorithmic_GBps": d["algorithmic_GBps"],
+                           "algorithmic_note": "SURVEY 8d bytes / launch time; above the HBM peak because a comes from LDS, b from L2, and a "
+                                               "strand-mirror pair is compared once and emitted twice -- not a roofline fraction",
+                           "measured_peaks": peaks,
+                           "pmc_source": "profiles/traffic.json (rocprofv3 --pmc passes, tools/collect_pmc.sh + tools/pmc_to_traffic.py): "
+                                         "`traffic` and the VALU instruction counts are replayed from there, everything else is measured in this run",
+                           "kernels": kern,
+                           "job_algorithmic_bytes": int(job_bytes), "job_algorithmic_GBps": job_gbs}
         if world == 1:
             h2d_bytes = float(last["upload_bytes"])   # (half the packed set when the odd reads are rebuilt on the device)
             d2h_bytes = 24.0 * n_rows

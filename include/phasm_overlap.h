@@ -81,6 +81,8 @@ typedef struct {
     float ms_upload;             /* H2D of the packed read set if this call uploaded it     */
     float ms_scan_probe;         /* the scan kernel alone (k_scan_probe / k_wide_scan count pass), inside ms_scan_count */
     float ms_verify_kernel;      /* the verify kernel alone (k_verify_a), inside ms_verify; 0 when there was nothing to verify */
+    uint64_t verify_bytes_exec;  /* sum over the VERIFIED CANDIDATES of 2*ceil(n*bits/8): the bytes the verify kernel  */
+                                 /* really compared (a strand-mirror pair is compared once and emitted twice)        */
     uint64_t upload_bytes;       /* bytes the last po_upload moved host->device (half the packed set when every   */
                                  /* odd read is the reverse complement of its even partner: the device rebuilds them) */
 } po_stats;

@@ -59,7 +59,7 @@ class PoStats(ctypes.Structure):
         ("ms_select", ctypes.c_float), ("ms_emit", ctypes.c_float),
         ("ms_total", ctypes.c_float), ("ms_upload", ctypes.c_float),
         ("ms_scan_probe", ctypes.c_float), ("ms_verify_kernel", ctypes.c_float),
-        ("upload_bytes", ctypes.c_uint64),
+        ("verify_bytes_exec", ctypes.c_uint64), ("upload_bytes", ctypes.c_uint64),
     ]
 
     def as_dict(self) -> dict:

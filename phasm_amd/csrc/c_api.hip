@@ -1031,7 +1031,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     }
     HIP_TRY(h, hipEventRecord(h->ev[EV_EMIT], st));
     uint64_t* counters = h->pinned + 4;
-    HIP_TRY(h, hipMemcpyAsync(counters, scalars + 4, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(counters, scalars + 4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
     if (rows_late) n_rows64 = h->pinned[2];  // (<= worst_rows < 2^32 by construction of the fast path)
     res->count = n_rows64;
@@ -1039,6 +1039,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     S.n_verified = want_cands ? n_rows64 : counters[0];
     S.sum_overlap_bases = counters[1];
     S.verify_bytes_algo = counters[2];
+    S.verify_bytes_exec = counters[3];
     (void)hipEventElapsedTime(&S.ms_index, h->ev[EV_START], h->ev[EV_INDEX]);
     (void)hipEventElapsedTime(&S.ms_scan_count, h->ev[EV_INDEX], h->ev[EV_COUNT]);
     (void)hipEventElapsedTime(&S.ms_scan_fill, h->ev[EV_COUNT], h->ev[EV_FILL]);
@@ -1101,7 +1102,7 @@ po_status run_expand(po_handle* h, const void* d_cands, uint64_t n, po_result* r
                        res->d_rows.as<po::Row>(), (uint32_t)h->bits, paired, scalars + 4);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev[EV_EMIT], st));
-    HIP_TRY(h, hipMemcpyAsync(h->pinned + 4, scalars + 4, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(h->pinned + 4, scalars + 4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
     if (rows_late) {
         if ((uint32_t)h->pinned[3] != 0) return fail(h, PO_ERR_INVALID, "po_expand: candidate array holds invalid entries");
@@ -1111,6 +1112,7 @@ po_status run_expand(po_handle* h, const void* d_cands, uint64_t n, po_result* r
     S.n_rows = n_rows;
     S.sum_overlap_bases = h->pinned[5];
     S.verify_bytes_algo = h->pinned[6];
+    S.verify_bytes_exec = h->pinned[7];
     (void)hipEventElapsedTime(&S.ms_emit, h->ev[EV_SELECT], h->ev[EV_EMIT]);
     return PO_OK;
 }

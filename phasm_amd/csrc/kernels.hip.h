@@ -1789,7 +1789,9 @@ __device__ inline uint32_t packed_bytes(uint32_t l, uint32_t bits) { return bits
 
 __device__ inline void write_rows(Row* __restrict__ rows, uint32_t off, uint32_t t, uint32_t a, uint32_t p, uint32_t b,
                                   uint32_t la, uint32_t lb, uint32_t bits, uint32_t paired, uint64_t& suml,
-                                  uint64_t& sumb) {
+                                  uint64_t& sumb, uint64_t& sume) {
+    // bytes the verify kernel really compared for this candidate (both sides, once -- the mirrored rows cost nothing)
+    sume += 2ull * packed_bytes((t & 1u) ? la - p : lb, bits);
     // (the counters grow by one row's worth next to each row store: sums of k * l as 64-bit products or shifts
     // issue at a quarter of the rate)
     if (t & 1u) {
@@ -1817,19 +1819,23 @@ __device__ inline void write_rows(Row* __restrict__ rows, uint32_t off, uint32_t
     }
 }
 
-// one atomic per counter per workgroup: [0]=verified candidates [1]=sum l [2]=sum 2*ceil(l*bits/8)
-__device__ inline void flush_counters(uint64_t nver, uint64_t suml, uint64_t sumb, unsigned long long* __restrict__ counters) {
-    __shared__ uint64_t s_red[3][256 / WAVE];
+// one atomic per counter per workgroup: [0]=verified candidates [1]=sum l [2]=sum 2*ceil(l*bits/8) over the rows
+// [3]=the same over the verified candidates (what the verify kernel compared)
+__device__ inline void flush_counters(uint64_t nver, uint64_t suml, uint64_t sumb, uint64_t sume,
+                                      unsigned long long* __restrict__ counters) {
+    __shared__ uint64_t s_red[4][256 / WAVE];
     nver = wave_sum64(nver);
     suml = wave_sum64(suml);
     sumb = wave_sum64(sumb);
+    sume = wave_sum64(sume);
     if (lane_id() == 0) {
         s_red[0][threadIdx.x >> 6] = nver;
         s_red[1][threadIdx.x >> 6] = suml;
         s_red[2][threadIdx.x >> 6] = sumb;
+        s_red[3][threadIdx.x >> 6] = sume;
     }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 4) {
         uint64_t v = 0;
         for (int w = 0; w < 256 / WAVE; ++w) v += s_red[threadIdx.x][w];
         if (v) atomicAdd(&counters[threadIdx.x], (unsigned long long)v);
@@ -1842,15 +1848,15 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ cand_
                                               const uint32_t* __restrict__ row_off, uint32_t n_cand,
                                               const uint32_t* __restrict__ len, Row* __restrict__ rows, uint32_t bits,
                                               uint32_t paired, unsigned long long* __restrict__ counters) {
-    uint64_t nver = 0, suml = 0, sumb = 0;
+    uint64_t nver = 0, suml = 0, sumb = 0, sume = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cand; i += gridDim.x * blockDim.x) {
         const uint32_t t = type[i];
         if (t == 0) continue;
         nver += 1;
         const uint32_t a = cand_a[i], p = cand_p[i], b = cand_b[i];
-        write_rows(rows, row_off[i], t, a, p, b, len[a], len[b], bits, paired, suml, sumb);
+        write_rows(rows, row_off[i], t, a, p, b, len[a], len[b], bits, paired, suml, sumb, sume);
     }
-    flush_counters(nver, suml, sumb, counters);
+    flush_counters(nver, suml, sumb, sume, counters);
 }
 
 // ---- multi-GPU form: verified candidates travel (16 B each, one per strand-mirror pair) instead of
@@ -1895,14 +1901,14 @@ __global__ __launch_bounds__(256) void k_emit_cands(const Cand* __restrict__ can
                                                     const uint32_t* __restrict__ len, Row* __restrict__ rows,
                                                     uint32_t bits, uint32_t paired,
                                                     unsigned long long* __restrict__ counters) {
-    uint64_t nver = 0, suml = 0, sumb = 0;
+    uint64_t nver = 0, suml = 0, sumb = 0, sume = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (rowcnt[i] == 0) continue;
         const Cand c = cands[i];
         nver += 1;
-        write_rows(rows, row_off[i], c.type, c.a, c.p, c.b, len[c.a], len[c.b], bits, paired, suml, sumb);
+        write_rows(rows, row_off[i], c.type, c.a, c.p, c.b, len[c.a], len[c.b], bits, paired, suml, sumb, sume);
     }
-    flush_counters(nver, suml, sumb, counters);
+    flush_counters(nver, suml, sumb, sume, counters);
 }
 
 // Paired-strand detection (2-bit reads only): is read 2i+1 exactly the reverse complement of read

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Hardware-counter passes behind profiles/traffic.json (run on the GPU box):
+#
+#     tools/collect_pmc.sh gpurun_out/pmc_r02 && python3 tools/pmc_to_traffic.py gpurun_out/pmc_r02 profiles/r02_pmc
+#
+# Every pass is its own `rocprofv3 --pmc ...` run of the SAME workload (config 2, three calls), counters only -- never
+# combined with a trace domain -- with the program itself behind `--`.  FETCH_SIZE and WRITE_SIZE do not fit one pass
+# (MI355X_MICROARCH.md, rocprofv3 PMC slots); SQ counters go four at a time.
+set -uo pipefail
+OUT="${1:?output directory}"
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+run_pass() {   # name, program args..., then counters after '--pmc--'
+    local name="$1"; shift
+    local prog=(); while [ "$1" != "--pmc--" ]; do prog+=("$1"); shift; done; shift
+    echo "== pass $name: $*" >&2
+    rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "${prog[@]}" > "$OUT/$name.log" 2>&1 || echo "pass $name failed (see $OUT/$name.log)" >&2
+}
+P="$ROOT/tools/perf_probe.py"
+L="$ROOT/tools/layout_probe.py"
+run_pass fetch  "$P" --config cfg2 --iters 3 --pmc-- FETCH_SIZE
+run_pass write  "$P" --config cfg2 --iters 3 --pmc-- WRITE_SIZE
+run_pass sq1    "$P" --config cfg2 --iters 3 --pmc-- SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CU_CYCLES
+run_pass sq2    "$P" --config cfg2 --iters 3 --pmc-- SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES
+run_pass sq3    "$P" --config cfg2 --iters 3 --pmc-- SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY
+run_pass sq4    "$P" --config cfg2 --iters 3 --pmc-- SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH
+run_pass tcc    "$P" --config cfg2 --iters 3 --pmc-- TCC_HIT_sum TCC_MISS_sum
+run_pass lfetch "$L" --config cfg2 --iters 3 --pmc-- FETCH_SIZE
+run_pass lwrite "$L" --config cfg2 --iters 3 --pmc-- WRITE_SIZE
+echo done >&2
