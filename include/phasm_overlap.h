@@ -83,6 +83,9 @@ typedef struct {
     float ms_verify_kernel;      /* the verify kernel alone (k_verify_a), inside ms_verify; 0 when there was nothing to verify */
     uint64_t verify_bytes_exec;  /* sum over the VERIFIED CANDIDATES of 2*ceil(n*bits/8): the bytes the verify kernel  */
                                  /* really compared (a strand-mirror pair is compared once and emitted twice)        */
+    uint64_t dp_steps;           /* po_overlaps_ex: antidiagonals swept by the DP kernel, summed over the candidates */
+    uint64_t dp_stopped;         /*                 candidates whose whole band rose above max_diff before the end   */
+    uint32_t max_diff, band;     /*                 the parameters of the call (0, 0 for the exact entry points)     */
     uint64_t upload_bytes;       /* bytes the last po_upload moved host->device (half the packed set when every   */
                                  /* odd read is the reverse complement of its even partner: the device rebuilds them) */
 } po_stats;
@@ -126,6 +129,18 @@ po_status po_invalidate(po_handle* h);
  * po_result_rows() is called.  Stateless across calls like the reference (index rebuilt per
  * call, :33-36); min_length 0 behaves as 1 (a suffix array has no empty suffix).          */
 po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out);
+
+/* Banded seed-extension mode -- an EXTENSION BEYOND THE REFERENCE, which is exact (src/overlapper.cpp:28-150; CLI help
+ * "exact overlaps", phasm/cli/assembler.py:436-439).  Same anchors as po_overlaps (b's K-base prefix found in a); every
+ * candidate is extended by a banded edit-distance DP (unit costs, diagonals -band..band, band <= 31, one wavefront per
+ * candidate: phasm_amd/csrc/extend.hip.h) and accepted with at most max_diff differences:
+ *   A  all of a[p:] against a prefix of b  -> row (a, b, p, len(a), 0, bend)
+ *   B  all of b against a prefix of a[p:]  -> row (a, b, p, aend, 0, len(b))
+ * longest-only for A per ordered pair, every B occurrence, as in the exact contract.  max_diff = 0 returns exactly the
+ * rows of po_overlaps (checked against the reference goldens); max_diff > 0 has no reference counterpart -- its checker
+ * is the build's own CPU restatement, oracle/extend_oracle.c ("parity unpinned").  Needs pure ACGT (2-bit) or 8-bit reads
+ * when max_diff > 0. */
+po_status po_overlaps_ex(po_handle* h, uint32_t min_length, uint32_t max_diff, uint32_t band, po_result** out);
 
 /* Multi-GPU form: only the rows whose `a` read lies in shard `shard` of `nshards` (contiguous
  * read-index ranges balanced by base count) are produced.  The union over all shards is

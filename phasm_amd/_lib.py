@@ -59,7 +59,8 @@ class PoStats(ctypes.Structure):
         ("ms_select", ctypes.c_float), ("ms_emit", ctypes.c_float),
         ("ms_total", ctypes.c_float), ("ms_upload", ctypes.c_float),
         ("ms_scan_probe", ctypes.c_float), ("ms_verify_kernel", ctypes.c_float),
-        ("verify_bytes_exec", ctypes.c_uint64), ("upload_bytes", ctypes.c_uint64),
+        ("verify_bytes_exec", ctypes.c_uint64), ("dp_steps", ctypes.c_uint64), ("dp_stopped", ctypes.c_uint64),
+        ("max_diff", ctypes.c_uint32), ("band", ctypes.c_uint32), ("upload_bytes", ctypes.c_uint64),
     ]
 
     def as_dict(self) -> dict:
@@ -81,6 +82,7 @@ SYMBOLS = [
     ("po_upload", ctypes.c_int, [_P]),
     ("po_invalidate", ctypes.c_int, [_P]),
     ("po_overlaps", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(_P)]),
+    ("po_overlaps_ex", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_overlaps_shard", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_candidates_shard", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_expand", ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(_P)]),

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "kernels.hip.h"
+#include "extend.hip.h"
 #include "layout.hip.h"
 
 namespace {
@@ -113,6 +114,10 @@ struct po_handle {
     void* reg_ptr[2] = {nullptr, nullptr};
     size_t reg_bytes[2] = {0, 0};
     int poison = -1;       // PHASM_POISON=<byte>: per-call workspaces are filled with it before every call
+    // po_overlaps_ex: the verify step is the banded DP of extend.hip.h (set around the call by po_overlaps_ex)
+    bool ex_on = false;
+    uint32_t ex_E = 0, ex_W = 0;
+    DevBuf d_end_a, d_end_b, d_dpcnt;
     int live_results = 0;
 
     po_stats stats = {};
@@ -607,8 +612,16 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     S.total_bases = h->total_bases;
     // strand-mirror mode + the read order that picks the canonical member of a mirror pair (keep_bits):
     // 1 = index order (whole-set calls), 2 = scrambled block order (sharded calls, balances verify work)
-    const uint32_t paired = (BITS == 2 && h->paired) ? (nshards > 1 ? 2u : 1u) : 0u;
+    const bool dp = h->ex_on;
+    const uint32_t dpE = dp ? h->ex_E : 0u, dpW = dp && h->ex_E ? h->ex_W : 0u;
+    // (inexact extension: every candidate is extended itself, no strand-mirror shortcut)
+    const uint32_t paired = (BITS == 2 && h->paired && dpE == 0) ? (nshards > 1 ? 2u : 1u) : 0u;
     S.paired = paired ? 1u : 0u;
+    S.max_diff = dpE;
+    S.band = dpW;
+    if (dp && dpE && want_cands) return fail(h, PO_ERR_INVALID, "the candidate (multi-GPU) form has no inexact mode");
+    if (dp && dpE && BITS == 2 && !h->exc_pos.empty())
+        return fail(h, PO_ERR_INVALID, "po_overlaps_ex with max_diff > 0 needs pure upper-case ACGT reads (or the 8-bit representation)");
 
     uint32_t r_begin = 0, r_end = n;
     S.shard_bases = h->total_bases;
@@ -833,7 +846,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     HIP_TRY(h, hipStreamSynchronize(st));
     const uint64_t n_cand64 = h->pinned[1];
     uint32_t n_selfrep_reads = (uint32_t)h->pinned[8];
-    if (nshards > 1 || wide) n_selfrep_reads |= 1u;  // k_select_local may hand repetitive reads to the global selection
+    if (nshards > 1 || wide || dpE) n_selfrep_reads |= 1u;  // k_select_local may hand repetitive reads to the global selection
     S.n_candidates = n_cand64;
     if (n_cand64 >= 0xFFFFFF00ull)
         return fail(h, PO_ERR_CAPACITY, "candidate count " + std::to_string(n_cand64) + " exceeds one call's capacity (2^32)");
@@ -862,7 +875,36 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(h->ev[EV_FILL], st));
         // ---- verify
-        {
+        if (dp) {
+            // banded seed-extension DP, one wave per candidate (extend.hip.h); max_diff = 0 gives the packed compare's answer
+            PO_TRY(ensure(h, h->d_end_a, (size_t)n_cand * 4));
+            PO_TRY(ensure(h, h->d_end_b, (size_t)n_cand * 4));
+            PO_TRY(ensure(h, h->d_dpcnt, 64));
+            HIP_TRY(h, hipMemsetAsync(h->d_dpcnt.p, 0, 64, st));
+            po::ExtArgs X = {};
+            X.words = words;
+            X.woff = woff;
+            X.len = len;
+            X.cand_a = A.cand_a;
+            X.cand_p = A.cand_p;
+            X.cand_b = A.cand_b;
+            X.n_cand = n_cand;
+            X.max_diff = dpE;
+            X.band = dpW;
+            X.paired = paired;
+            X.exc_off = h->n_exc_uploaded ? h->d_exc_off.as<uint32_t>() : nullptr;
+            X.exc_pos = h->d_exc_pos.as<uint32_t>();
+            X.exc_byte = h->d_exc_byte.as<uint8_t>();
+            X.type = h->d_type.as<uint8_t>();
+            X.end_a = h->d_end_a.as<uint32_t>();
+            X.end_b = h->d_end_b.as<uint32_t>();
+            X.counters = h->d_dpcnt.as<unsigned long long>();
+            HIP_TRY(h, hipEventRecord(h->ev[EV_VER0], st));
+            hipLaunchKernelGGL((po::k_extend_dp<BITS>), dim3(cdiv(n_cand, 256 / po::WAVE)), dim3(256), 0, st, X);
+            HIP_TRY(h, hipEventRecord(h->ev[EV_VER1], st));
+            HIP_TRY(h, hipMemcpyAsync(h->pinned + 32, h->d_dpcnt.p, 16, hipMemcpyDeviceToHost, st));
+            ver_timed = true;
+        } else {
             // a's words live in LDS (read length + 3 guard words); reads too long for 64 KB use the global path
             const uint64_t need_words = ((uint64_t)h->max_len + W - 1) / W + 3;
             const uint32_t lds_words_raw = (uint32_t)std::min<uint64_t>(need_words, 8192 - 1100);  // (room for the records in 64 KB)
@@ -933,7 +975,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         // ---- select + row offsets
         po::PairSlot* ptab = nullptr;
         uint32_t pbits = 0;
-        if (nshards > 1 || wide) {
+        if (nshards > 1 || wide || dpE) {
             static_assert(po::SEL_CAP == 512, "k_select_local hashes to 9 bits");
             hipLaunchKernelGGL(po::k_select_local, dim3(cdiv(r_end - r_begin, 256 / po::WAVE)), dim3(256), 0, st,
                                h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_b, h->d_type.as<uint8_t>(),
@@ -1019,6 +1061,12 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                 const size_t roomy = worst_rows * sizeof(po_row) <= (2ull << 30) ? (size_t)(worst_rows * sizeof(po_row)) : 0;
                 PO_TRY(ensure(h, res->d_rows, std::max<size_t>(std::max(exact, roomy), 256)));
             }
+            if (dpE)
+                hipLaunchKernelGGL(po::k_emit_ex, dim3(std::min<uint32_t>(cdiv(n_cand, 256), (uint32_t)h->n_cu * 16)), dim3(256), 0,
+                                   st, A.cand_a, A.cand_p, A.cand_b, h->d_type.as<uint8_t>(), h->d_end_a.as<uint32_t>(),
+                                   h->d_end_b.as<uint32_t>(), h->d_row_off.as<uint32_t>(), n_cand, len,
+                                   res->d_rows.as<po::Row>(), (uint32_t)BITS, scalars + 4);
+            else
             hipLaunchKernelGGL(po::k_emit, dim3(std::min<uint32_t>(cdiv(n_cand, 256), (uint32_t)h->n_cu * 16)), dim3(256), 0,
                                st, A.cand_a, A.cand_p, A.cand_b, h->d_type.as<uint8_t>(), h->d_row_off.as<uint32_t>(),
                                n_cand, len, res->d_rows.as<po::Row>(), (uint32_t)BITS, paired, scalars + 4);
@@ -1040,6 +1088,10 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     S.sum_overlap_bases = counters[1];
     S.verify_bytes_algo = counters[2];
     S.verify_bytes_exec = counters[3];
+    if (dp && n_cand64) {
+        S.dp_steps = h->pinned[32];
+        S.dp_stopped = h->pinned[33];
+    }
     (void)hipEventElapsedTime(&S.ms_index, h->ev[EV_START], h->ev[EV_INDEX]);
     (void)hipEventElapsedTime(&S.ms_scan_count, h->ev[EV_INDEX], h->ev[EV_COUNT]);
     (void)hipEventElapsedTime(&S.ms_scan_fill, h->ev[EV_COUNT], h->ev[EV_FILL]);
@@ -1546,7 +1598,7 @@ void po_destroy(po_handle* h) {
                           &h->d_chain_tmp, &h->d_long_list, &h->d_bloom, &h->d_selfrep, &h->d_tile_count, &h->d_tile_off,
                           &h->d_ps_blocks, &h->d_scalars, &h->d_cand_a, &h->d_cand_p, &h->d_cand_b, &h->d_type,
                           &h->d_rowcnt, &h->d_row_off, &h->d_flag, &h->d_pair_key, &h->d_pair_min, &h->spare_rows, &h->spare_cands, &h->spare_edges,
-                          &h->d_vlabel, &h->d_vrank, &h->d_vperm, &h->d_lay_len, &h->d_lay_cnt, &h->d_rflag, &h->d_removed, &h->d_ekey, &h->d_ecnt,
+                          &h->d_vlabel, &h->d_vrank, &h->d_vperm, &h->d_end_a, &h->d_end_b, &h->d_dpcnt, &h->d_lay_len, &h->d_lay_cnt, &h->d_rflag, &h->d_removed, &h->d_ekey, &h->d_ecnt,
                           &h->d_ewin, &h->d_eoff};
         for (DevBuf* b : bufs) b->release();
         for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(h->ev[i]);
@@ -1802,6 +1854,19 @@ po_status po_expand(po_handle* h, const void* candidates_device, uint64_t n_cand
 
 po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out) {
     return po_overlaps_shard(h, min_length, 0, 1, out);
+}
+
+po_status po_overlaps_ex(po_handle* h, uint32_t min_length, uint32_t max_diff, uint32_t band, po_result** out) {
+    if (!h || !out) return PO_ERR_INVALID;
+    *out = nullptr;
+    if (band > 31) return fail(h, PO_ERR_INVALID, "po_overlaps_ex: band must be <= 31 (2*band+1 diagonals, one lane each)");
+    if (max_diff >= (1u << 16)) return fail(h, PO_ERR_INVALID, "po_overlaps_ex: max_diff must be < 65536");
+    h->ex_on = true;
+    h->ex_E = max_diff;
+    h->ex_W = band;
+    const po_status st = overlaps_common(h, min_length, 0, 1, false, out);
+    h->ex_on = false;
+    return st;
 }
 
 po_status po_shard_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint32_t* r_begin, uint32_t* r_end) {

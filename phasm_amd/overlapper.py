@@ -173,6 +173,21 @@ class ExactOverlapper:
         _check(self._h, self._lib.po_overlaps_shard(self._h, m, int(shard), int(nshards), ctypes.byref(r)))
         return OverlapResult(self, r)
 
+    def overlaps_ex_result(self, min_length: int, max_diff: int = 0, band: int = 0) -> OverlapResult:
+        """``po_overlaps_ex``: banded seed-extension DP with up to ``max_diff`` differences (an extension beyond the
+        exact reference; ``max_diff = 0`` gives the rows of ``overlaps``)."""
+        m = self._min_length(min_length)
+        r = ctypes.c_void_p()
+        _check(self._h, self._lib.po_overlaps_ex(self._h, m, int(max_diff), int(band), ctypes.byref(r)))
+        return OverlapResult(self, r)
+
+    def overlaps_ex_array(self, min_length: int, max_diff: int = 0, band: int = 0) -> np.ndarray:
+        res = self.overlaps_ex_result(min_length, max_diff, band)
+        try:
+            return res.rows()
+        finally:
+            res.free()
+
     def candidates_result(self, min_length: int, shard: int = 0, nshards: int = 1) -> OverlapResult:
         """Verified candidates of one a-side shard (``po_candidates_shard``): the compact form that
         travels between GPUs; ``expand_result`` turns the merged array into rows."""

@@ -124,3 +124,9 @@ def assert_same_rows(got: np.ndarray, want: np.ndarray, seqs: Optional[Sequence]
         np.savez_compressed(os.path.join(dump, "mismatch_%d.npz" % os.getpid()), got=got, want=want, m=m,
                             seqs=np.array(_plain(seqs), dtype=object) if seqs is not None else np.array([], dtype=object))
     raise AssertionError("%s\n%s" % (ctx, explain_difference(got, want, seqs, m)))
+
+
+def oracle_overlaps_ex(seqs: Sequence, min_length: int, max_diff: int, band: int, anchor: int = 32) -> np.ndarray:
+    """``oracle.extend_oracle.oracle_overlaps_ex`` (CPU restatement of po_overlaps_ex) in the checker process."""
+    return sidecar().call("oracle.extend_oracle", "oracle_overlaps_ex", _plain(seqs), int(min_length), int(max_diff),
+                          int(band), int(anchor))

@@ -1,0 +1,126 @@
+"""po_overlaps_ex -- the banded seed-extension DP kernel (phasm_amd/csrc/extend.hip.h).
+
+* max_diff = 0: the DP kernel in place of the packed compare must return exactly the rows of po_overlaps -- checked
+  against the REFERENCE goldens (toy, adversarial incl. N / lower case, repeats, the synthetic ladders).  This half is
+  pinned by the reference.
+* max_diff > 0: the reference is exact (src/overlapper.cpp:28-150) and cannot check an inexact overlap -- PARITY
+  UNPINNED.  The checker is the build's own CPU restatement (oracle/extend_oracle.c, a plain row-by-row banded DP,
+  run in the checker process), on seeded read sets with substitutions and indels.  Bit-exact rows, sorted multisets.
+"""
+import numpy as np
+import pytest
+
+import checker as ck
+import golden_utils as gu
+from oracle import overlap_oracle as oo   # row helpers only
+from phasm_amd import synth
+from phasm_amd.overlapper import ExactOverlapper
+
+pytestmark = pytest.mark.gpu
+
+
+def ex_rows(seqs, m, max_diff, band):
+    ov = ExactOverlapper()
+    for i, s in enumerate(seqs):
+        ov.add_sequence("r%d" % i, s)
+    arr = ov.overlaps_ex_array(m, max_diff, band)
+    st = ov.stats()
+    ov.close()
+    return oo.sort_rows(oo.struct_to_rows(arr)), st
+
+
+def test_max_diff_zero_equals_the_reference_goldens():
+    for name, seqs, m, want in gu.all_small_cases() + gu.repeats_cases():
+        got, st = ex_rows(seqs, m, 0, 0)
+        ck.assert_same_rows(got, want, seqs, m, name)
+        assert st["max_diff"] == 0
+
+
+@pytest.mark.parametrize("name", ["ladder_small", "ladder_varlen", "ladder_cfg1_mini", "ladder_cfg2_mini", "ladder_cfg4_noise"])
+def test_max_diff_zero_equals_the_ladder_goldens(name):
+    _, seqs, m, want = gu.ladder_case(name)
+    got, st = ex_rows(seqs, m, 0, 7)        # (the band is ignored without differences)
+    ck.assert_same_rows(got, want, seqs, m, name)
+    assert st["paired"] == 1 and st["dp_steps"] > 0
+    # ... and equals the packed-compare path row for row
+    ov = ExactOverlapper()
+    for i, s in enumerate(seqs):
+        ov.add_sequence("r%d" % i, s)
+    assert np.array_equal(ov.overlaps_ex_array(m, 0, 0), ov.overlaps_array(m))
+    ov.close()
+
+
+def noisy_reads(rng, n_reads, glen, lo, hi, sub, indel, both_strands):
+    rc = bytes.maketrans(b"ACGT", b"TGCA")
+    genome = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=glen))
+    reads = []
+    for _ in range(n_reads):
+        ln = int(rng.integers(lo, hi))
+        st = int(rng.integers(0, glen - ln + 1))
+        r = bytearray()
+        for ch in genome[st:st + ln]:
+            u = rng.random()
+            if u < sub:
+                r.append(b"ACGT"[(b"ACGT".index(ch) + int(rng.integers(1, 4))) & 3])
+            elif u < sub + indel / 2:
+                continue                                   # deletion
+            elif u < sub + indel:
+                r.append(ch)
+                r.append(b"ACGT"[int(rng.integers(4))])    # insertion
+            else:
+                r.append(ch)
+        r = bytes(r)
+        if rng.random() < 0.5:
+            r = r.translate(rc)[::-1]
+        reads.append(r)
+    if both_strands:
+        out = []
+        for r in reads:
+            out += [r, r.translate(rc)[::-1]]
+        return out
+    return reads
+
+
+@pytest.mark.parametrize("seed,max_diff,band", [(1, 1, 1), (2, 3, 2), (3, 8, 4), (4, 20, 16), (5, 40, 31), (6, 5, 0), (7, 2, 31)])
+def test_inexact_rows_equal_the_cpu_restatement(seed, max_diff, band):
+    rng = np.random.default_rng(1000 + seed)
+    seqs = noisy_reads(rng, n_reads=40, glen=3000, lo=150, hi=1400, sub=0.01, indel=0.006, both_strands=seed % 2 == 0)
+    m = int(rng.choice([40, 64, 100]))
+    got, st = ex_rows(seqs, m, max_diff, band)
+    want = ck.oracle_overlaps_ex(seqs, m, max_diff, band, anchor=32)
+    assert st["paired"] == 0 and st["max_diff"] == max_diff and st["band"] == band
+    assert np.array_equal(got, want), (len(got), len(want), [tuple(r) for r in got[:5]], [tuple(r) for r in want[:5]])
+    exact = ck.oracle_overlaps(seqs, m)
+    assert len(want) >= len(exact)          # tolerance only ever adds overlaps of a pair / occurrences
+    assert len(want) > len(exact)           # ... and on this noise it does
+
+
+def test_inexact_mode_on_8bit_reads_and_errors():
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGTNacgt", dtype=np.uint8)
+    genome = alpha[rng.integers(0, len(alpha), size=4000)].tobytes()
+    seqs = []
+    for _ in range(40):
+        ln = int(rng.integers(100, 900))
+        st = int(rng.integers(0, len(genome) - ln))
+        r = bytearray(genome[st:st + ln])
+        for pos in rng.integers(0, ln, size=ln // 150):
+            r[pos] = alpha[rng.integers(len(alpha))]
+        seqs.append(bytes(r))
+    ov = ExactOverlapper()
+    for i, s in enumerate(seqs):
+        ov.add_sequence("r%d" % i, s)
+    got = oo.sort_rows(oo.struct_to_rows(ov.overlaps_ex_array(30, 4, 3)))
+    assert ov.stats()["bits_per_base"] == 8
+    assert np.array_equal(got, ck.oracle_overlaps_ex(seqs, 30, 4, 3, anchor=8))
+    with pytest.raises(ValueError):
+        ov.overlaps_ex_array(30, 4, 32)      # band > 31
+    ov.close()
+    # sparse non-ACGT bytes on the 2-bit path: exact mode works (exception records), inexact mode refuses
+    ov = ExactOverlapper()
+    ov.add_sequence("a", "ACGTNACGTACGGATTACAGATTACAGGGATCCGATTTACGAGCATCGACTAGCTACGACTAGC")
+    ov.add_sequence("b", "GATTACAGGGATCCGATTTACGAGCATCGACTAGCTACGACTAGCNNACGATCGATCGAAA")
+    assert len(ov.overlaps_ex_array(20, 0, 0)) == len(ov.overlaps_array(20)) == 1
+    with pytest.raises(ValueError):
+        ov.overlaps_ex_array(20, 2, 2)
+    ov.close()

@@ -81,3 +81,25 @@ def test_c_oracle_matches_live_reference_random():
         m = int(rng.integers(1, 40))
         want, _, _ = oo.reference_overlaps(reads, m)
         assert np.array_equal(oo.oracle_overlaps(reads, m), want), t
+
+
+def test_extension_oracle_with_zero_differences_is_the_exact_contract():
+    """oracle/extend_oracle.c (the CPU restatement of po_overlaps_ex) is PARITY UNPINNED for max_diff > 0 -- the
+    reference is exact -- but with max_diff = 0 it must be the exact contract, and that is pinned here by every
+    reference golden (the band is ignored without differences)."""
+    from oracle import extend_oracle as eo
+    for name, seqs, m, want in gu.all_small_cases() + gu.repeats_cases():
+        assert np.array_equal(eo.oracle_overlaps_ex(seqs, m, 0, 5), want), name
+    for name in ("ladder_small", "ladder_varlen"):
+        _, seqs, m, want = gu.ladder_case(name)
+        assert np.array_equal(eo.oracle_overlaps_ex(seqs, m, 0, 0), want), name
+    # a hand case with one substitution and one insertion (x = a[p:], y = b)
+    a = "TTTTTTTTTTACGTACGGATCAGGCATCAGCATTTACGACGGATCAGCTAC"
+    b = "ACGTACGGATCAGGCATGAGCATTTACGACGGATCAGCTACGGGGGGGG"      # C -> G at offset 17 of the overlap
+    assert len(eo.oracle_overlaps_ex([a, b], 20, 0, 0, 8)) == 0
+    rows = eo.oracle_overlaps_ex([a, b], 20, 1, 1, 8)
+    assert rows.tolist() == [[0, 1, 10, len(a), 0, len(a) - 10]]
+    b2 = b[:25] + "T" + b[25:]                                        # plus one inserted base in b
+    assert len(eo.oracle_overlaps_ex([a, b2], 20, 1, 2, 8)) == 0
+    rows = eo.oracle_overlaps_ex([a, b2], 20, 2, 2, 8)
+    assert rows.tolist() == [[0, 1, 10, len(a), 0, len(a) - 10 + 1]]

@@ -31,6 +31,8 @@ if __name__ == "__main__":
     ap.add_argument("--reads", type=int, default=0)
     ap.add_argument("--min-length", type=int, default=1000)
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--max-diff", type=int, default=-1, help=">= 0: po_overlaps_ex (banded DP) with this many differences")
+    ap.add_argument("--band", type=int, default=0)
     a = ap.parse_args()
     cfg = synth.CONFIGS[a.config]
     if a.reads:
@@ -38,7 +40,7 @@ if __name__ == "__main__":
     ov = load(cfg)
     for it in range(a.iters):
         t0 = time.time()
-        res = ov.overlaps_result(a.min_length)
+        res = ov.overlaps_result(a.min_length) if a.max_diff < 0 else ov.overlaps_ex_result(a.min_length, a.max_diff, a.band)
         dt = time.time() - t0
         st = ov.stats()
         res.free()
