@@ -102,6 +102,39 @@ def measured_peaks() -> dict:
         return {"error": repr(e)}
 
 
+def cfg4_leg(dev_idx: int, m: int, max_diff: int, band: int) -> dict:
+    """BASELINE config 4 (config 2 + 1 % substitution noise) both ways: the exact path (parity with the reference:
+    it finds nothing there) and the banded seed-extension DP (po_overlaps_ex; an extension beyond the reference,
+    parity unpinned -- oracle/extend_oracle.c is its checker)."""
+    cfg = synth.CONFIGS["cfg4"]
+    ov = ExactOverlapper(device=dev_idx)
+    for name, seq in synth.oriented(synth.generate_reads(cfg)):
+        ov.add_sequence(name, seq)
+    ov.upload()
+    out = {"workload": "cfg4: %d x %d b reads, %.0f %% substitution noise, both strands, min_overlap %d"
+                       % (cfg.n_reads, cfg.read_len, cfg.noise * 100, m)}
+    for key, call in (("exact", lambda: ov.overlaps_result(m)),
+                      ("banded_dp", lambda: ov.overlaps_ex_result(m, max_diff, band))):
+        call().free()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = call()
+        n = len(res)
+        dt = time.perf_counter() - t0
+        res.free()
+        st = ov.stats()
+        out[key] = {"ms_per_call": dt * 1e3, "rows": n, "candidates": st["n_candidates"], "overlaps_per_sec": n / dt,
+                    "ms_verify_kernel": st["ms_verify_kernel"]}
+        if key == "banded_dp":
+            cells = st["dp_steps"] * (2 * band + 1) / 2.0     # half of the band's lanes hold a cell of each antidiagonal
+            out[key].update({"max_diff": max_diff, "band": band, "antidiagonals": st["dp_steps"], "stopped_early": st["dp_stopped"],
+                             "G_cell_updates_per_sec": cells / (st["ms_verify_kernel"] * 1e-3) / 1e9,
+                             "kernel": "k_extend_dp<2>: one wave per candidate, one lane per diagonal, ~12 VALU instructions per antidiagonal",
+                             "parity": "unpinned (the reference is exact); checker: oracle/extend_oracle.c"})
+    ov.close()
+    return out
+
+
 def layout_leg(ov: ExactOverlapper, m: int, with_cpu: bool) -> dict:
     """Next row of the path: stage 1 of `phasm layout` -- classify, contained-read
     and alignment filters, assembly-graph edges -- on the rows of one step, still resident in HBM."""
@@ -164,6 +197,7 @@ def main() -> int:
     ap.add_argument("--cpu-sample-reads", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tuples", action="store_true", help="skip the Python tuple materialisation leg")
+    ap.add_argument("--no-cfg4", action="store_true", help="skip the config-4 leg (exact path + banded DP)")
     ap.add_argument("--dist-path", action="store_true",
                     help="dev: run the N>1 code path (shard + RCCL all-gather + expansion) even with one rank")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -425,6 +459,8 @@ def main() -> int:
                 del tup
             out["roofline"]["hbm_copy_measured"] = measured_hbm_gbs(device)   # GB/s of a d2d copy on this box
             out["layout_stage1"] = layout_leg(ov, m, not args.no_cpu_baseline)
+            if not args.no_cfg4 and not args.reads:
+                out["cfg4_extension"] = cfg4_leg(dev_idx, m, 400, 8)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(m, args.cpu_sample_reads)
     if world > 1 or args.dist_path:

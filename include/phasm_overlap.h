@@ -132,7 +132,7 @@ po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out);
 
 /* Banded seed-extension mode -- an EXTENSION BEYOND THE REFERENCE, which is exact (src/overlapper.cpp:28-150; CLI help
  * "exact overlaps", phasm/cli/assembler.py:436-439).  Same anchors as po_overlaps (b's K-base prefix found in a); every
- * candidate is extended by a banded edit-distance DP (unit costs, diagonals -band..band, band <= 31, one wavefront per
+ * candidate is extended by a banded edit-distance DP (unit costs, diagonals -band..band, band <= 30, one wavefront per
  * candidate: phasm_amd/csrc/extend.hip.h) and accepted with at most max_diff differences:
  *   A  all of a[p:] against a prefix of b  -> row (a, b, p, len(a), 0, bend)
  *   B  all of b against a prefix of a[p:]  -> row (a, b, p, aend, 0, len(b))

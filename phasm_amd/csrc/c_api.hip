@@ -1859,7 +1859,7 @@ po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out) {
 po_status po_overlaps_ex(po_handle* h, uint32_t min_length, uint32_t max_diff, uint32_t band, po_result** out) {
     if (!h || !out) return PO_ERR_INVALID;
     *out = nullptr;
-    if (band > 31) return fail(h, PO_ERR_INVALID, "po_overlaps_ex: band must be <= 31 (2*band+1 diagonals, one lane each)");
+    if (band > 30) return fail(h, PO_ERR_INVALID, "po_overlaps_ex: band must be <= 30 (2*band+1 diagonals on lanes 1..61, one lane each; lanes 0 and 63 let the bases in)");
     if (max_diff >= (1u << 16)) return fail(h, PO_ERR_INVALID, "po_overlaps_ex: max_diff must be < 65536");
     h->ex_on = true;
     h->ex_E = max_diff;

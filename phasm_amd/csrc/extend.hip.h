@@ -12,14 +12,17 @@
 //   B (containment)    costB = min over i of D[i][lb]  <= max_diff   -> row (a, b, p, p + i*, 0, lb)
 // ties go to the cell closest to the main diagonal, then to the smaller coordinate.
 //
-// Mapping to the machine: ONE WAVE PER CANDIDATE, one lane per diagonal (lane k owns delta = j - i = k - W, so a
-// band of up to 63 diagonals fills the wave), swept antidiagonal by antidiagonal: at step d = i + j the lanes with
-// (d + W - k) even hold the cells of that antidiagonal and compute
+// Mapping to the machine: ONE WAVE PER CANDIDATE, one lane per diagonal (lane k owns delta = j - i = k - 1 - W, so a
+// band of up to 61 diagonals sits on lanes 1..61), swept antidiagonal by antidiagonal: at step d = i + j the lanes with
+// (d - delta) even hold the cells of that antidiagonal and compute
 //     D[i][j] = min(D[i-1][j-1] + (x[i-1] != y[j-1]),  D[i-1][j] + 1,  D[i][j-1] + 1)
 // from their own value two steps back and their neighbours' values of the previous step -- lane k+1 (up) and lane
 // k-1 (left), fetched with whole-wave DPP shifts (wave_shl:1 / wave_shr:1), no LDS, no ds_bpermute.  The bases flow
 // through the lanes systolically: x enters at lane 0 and moves one lane up per step, y enters at lane 63 and moves
 // one lane down, so every lane sees exactly the pair (x[i-1], y[j-1]) of its cell without any per-lane addressing.
+// The steady state runs in blocks of 32 antidiagonals fed from two 32-bit scalar windows (16 bases of x, 16 of y):
+// per antidiagonal ~11 vector instructions and 3 scalar ones; the first and last steps of a candidate (sentinels
+// past the sequence ends, the cells where row rem / column lb are reached) take a slower general step.
 // The sequences themselves are staged through LDS tiles of 64 dwords per wave and side (coalesced 256-byte loads
 // of the packed reads; the feed words are picked up from there by the whole wave, uniformly).  Every 64 steps the
 // band minimum is reduced across the wave (DPP row_shr / row_bcast) and a candidate whose whole band is above
@@ -40,7 +43,7 @@ struct ExtArgs {
     const uint32_t* cand_b;
     uint32_t n_cand;
     uint32_t max_diff;   // E
-    uint32_t band;       // W: diagonals -W..W (W <= 31)
+    uint32_t band;       // W: diagonals -W..W (W <= 30)
     uint32_t paired;     // strand-mirror mode (only with max_diff == 0): keep_bits decides what this candidate may give
     const uint32_t* exc_off;   // exception records (2-bit reads, max_diff == 0 only)
     const uint32_t* exc_pos;
@@ -60,6 +63,9 @@ __device__ __forceinline__ uint32_t dpp_from_lower(uint32_t fill, uint32_t v) { 
 __device__ __forceinline__ uint32_t dpp_from_upper(uint32_t fill, uint32_t v) {   // lane k <- lane k+1; lane 63 <- fill
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false);  // wave_shl:1
 }
+
+// a uniform value enters the wave at one lane (v_writelane_b32: SGPR -> one lane of a VGPR)
+#define door(vreg, sval, LANE) asm("v_writelane_b32 %0, %1, " #LANE : "+v"(vreg) : "s"(sval))
 
 // wave minimum through the DPP scan network (same shape as wave_incl_scan)
 __device__ __forceinline__ uint32_t wave_min(uint32_t v) {
@@ -150,61 +156,124 @@ __global__ __launch_bounds__(256) void k_extend_dp(const ExtArgs A) {
     fx.stage((p * BITS) >> 5);   // (tiles start at the dword that holds base p: the initial fill stays inside the first one)
     fy.stage(0);
 
+    // Lane layout: the band's 2W+1 diagonals sit on lanes 1 .. 2W+1 (lane kk owns delta = j - i = kk - 1 - W); lanes
+    // 0 and 63 are the doors the bases come in through and never hold a cell, so a neighbour read that runs off the
+    // wave (DPP bound_ctrl: reads 0) only ever lands in a lane whose value is not used.
     const int32_t iW = (int32_t)W;
-    const int32_t k = (int32_t)lane;
-    const bool in_band = lane <= 2u * W;
-    // lane parity: lane k holds a cell of antidiagonal d iff (d + W - k) is even
-    const bool even_lane = ((iW - k) & 1) == 0;   // commits on even d
-    // registers at d = 0: lane k faces x[((W - k) >> 1) - 1] and y[((k - W) >> 1) - 1]  (floor shifts)
-    uint32_t xr = fx.base_lane(((iW - k) >> 1) - 1);
-    uint32_t yr = fy.base_lane(((k - iW) >> 1) - 1);
-    uint32_t H = (k == iW) ? 0u : EXT_INF;       // D[0][0] = 0, everything else starts outside the matrix
+    const int32_t dlt = (int32_t)lane - 1 - iW;
+    const bool in_band = lane >= 1u && lane <= 2u * W + 1u;
+    // lane kk holds a cell of antidiagonal d iff (d - delta) is even
+    const bool commit_even = in_band && (dlt & 1) == 0;   // ... on even d
+    const bool commit_odd = in_band && (dlt & 1) != 0;    // ... on odd d
+    // registers at d = 0 (what the doors would have let in at steps -kk and kk - 63)
+    uint32_t xr = fx.base_lane(((-dlt) >> 1) - 1);
+    uint32_t yr = fy.base_lane((dlt >> 1) - 1);
+    uint32_t H = (in_band && dlt == 0) ? 0u : EXT_INF;    // D[0][0] = 0, everything else starts outside the matrix
     uint32_t endA = EXT_INF, endB = EXT_INF;
     const uint32_t one = 1u;
+    constexpr uint32_t BMASK = (1u << BITS) - 1u;
+    constexpr int UNITS = 32 / BITS;   // bases per 32-bit feed window
 
-    // last antidiagonal that can hold a wanted cell
+    // one antidiagonal: neighbours of the previous step through whole-wave DPP shifts, own value from two steps back
+    auto cell = [&](bool commit) __attribute__((always_inline)) {
+        const uint32_t up1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H, 0x130, 0xf, 0xf, true) + one;    // D[i-1][j] + 1: lane kk+1
+        const uint32_t left1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H, 0x138, 0xf, 0xf, true) + one;  // D[i][j-1] + 1: lane kk-1
+        const uint32_t diag = H + min(xr ^ yr, one);                                                          // D[i-1][j-1] + mismatch
+        const uint32_t nw = min(min(diag, up1), min(left1, EXT_INF));
+        H = commit ? nw : H;
+    };
+    auto shift_x = [&]() __attribute__((always_inline)) {   // lane kk <- lane kk-1; lane 0 keeps its base
+        xr = (uint32_t)__builtin_amdgcn_update_dpp((int)xr, (int)xr, 0x138, 0xf, 0xf, false);
+    };
+    auto shift_y = [&]() __attribute__((always_inline)) {   // lane kk <- lane kk+1; lane 63 keeps its base
+        yr = (uint32_t)__builtin_amdgcn_update_dpp((int)yr, (int)yr, 0x130, 0xf, 0xf, false);
+    };
+
+    // last antidiagonal that can hold a wanted cell, first one that reaches row rem (A) / column lb (B)
     uint32_t d_end = 0;
     if (canA) d_end = max(d_end, 2u * rem + W);
     if (canB) d_end = max(d_end, 2u * lb + W);
     d_end = min(d_end, rem + lb);
-    const int32_t recA0 = canA ? (int32_t)(2u * rem) - iW : 0x7FFFFFFF;  // steps at which row rem is reached (lane k: recA0 + k)
-    const int32_t recB1 = canB ? (int32_t)(2u * lb) + iW : -0x7FFFFFFF;  // ... and column lb (lane k: recB1 - k)
+    const uint32_t first_rec = min(canA ? 2u * rem - min(W, 2u * rem) : 0xFFFFFFFFu, canB ? 2u * lb - min(W, 2u * lb) : 0xFFFFFFFFu);
     uint32_t steps = 0;
     bool dead = false;
-    for (uint32_t d = 1; d <= d_end; ++d) {
-        // ---- feeds (uniform): lane 0 takes x[((d + W) >> 1) - 1], lane 63 takes y[((d - W + 63) >> 1) - 1]
-        const uint32_t fa = fx.base((int32_t)((d + W) >> 1) - 1);
-        const uint32_t fb = fy.base((int32_t)((d + 63u - W) >> 1) - 1);
-        xr = dpp_from_lower(fa, xr);
-        yr = dpp_from_upper(fb, yr);
-        // ---- the cell
-        const uint32_t up1 = dpp_from_upper(EXT_INF, H) + one;    // D[i-1][j] + 1   (diagonal delta + 1, previous step)
-        const uint32_t left1 = dpp_from_lower(EXT_INF, H) + one;  // D[i][j-1] + 1   (diagonal delta - 1, previous step)
-        const uint32_t diag = H + min(xr ^ yr, one);              // D[i-1][j-1] + mismatch (own value, two steps back)
-        const uint32_t nw = min(min(diag, up1), min(left1, EXT_INF));
-        const bool commit = in_band && (((d & 1u) == 0u) == even_lane);
-        H = commit ? nw : H;
-        // ---- ends: row rem (A) is reached by lane d - recA0, column lb (B) by lane recB1 - d
-        const int32_t tA = (int32_t)d - recA0, tB = recB1 - (int32_t)d;
-        if (tA >= 0 && tA <= 2 * iW && k == tA) endA = H;
-        if (tB >= 0 && tB <= 2 * iW && k == tB) endB = H;
+    uint32_t d = 1;
+    // slow step: feeds addressed from scratch (sentinels past the ends), ends recorded.  Door feeds at step d:
+    // lane 0 takes x[((d + W + 1) >> 1) - 1], lane 63 takes y[((d + 62 - W) >> 1) - 1]
+    auto slow_step = [&]() __attribute__((always_inline)) {
+        const uint32_t fa = fx.base((int32_t)((d + W + 1u) >> 1) - 1);
+        const uint32_t fb = fy.base((int32_t)((d + 62u - W) >> 1) - 1);
+        shift_x();
+        door(xr, fa, 0);
+        shift_y();
+        door(yr, fb, 63);
+        cell((d & 1u) ? commit_odd : commit_even);
+        // ends: row rem is reached on diagonal d - 2 rem, column lb on diagonal 2 lb - d
+        if (canA && in_band && dlt == (int32_t)d - (int32_t)(2u * rem)) endA = H;
+        if (canB && in_band && dlt == (int32_t)(2u * lb) - (int32_t)d) endB = H;
+        ++d;
         ++steps;
-        if ((d & 63u) == 0u) {
-            // every future cell is reached through the last two antidiagonals, and costs never fall along a path
-            if (wave_min(in_band ? H : EXT_INF) > E) {
+    };
+    // every future cell is reached through the last two antidiagonals, and costs never fall along a path
+    auto band_dead = [&]() __attribute__((always_inline)) -> bool { return wave_min(in_band ? H : EXT_INF) > E; };
+
+    // ---- head: up to the first step at which x advances ((d + W + 1) even)
+    while (d <= d_end && ((d + W + 1u) & 1u)) slow_step();
+    // ---- main phase: blocks of 2 * UNITS steps fed from two 32-bit windows (UNITS bases of x, UNITS of y), no
+    // sentinels and no ends inside a block.  In a unit of two steps x advances first, then y.
+    {
+        const bool c_first = (d & 1u) ? commit_odd : commit_even, c_second = (d & 1u) ? commit_even : commit_odd;
+        auto window = [&](SeqFeed<BITS>& f, uint32_t q0) __attribute__((always_inline)) -> uint32_t {
+            const uint32_t bitpos = (f.first + q0) * BITS;
+            const uint32_t dw = bitpos >> 5, sh = bitpos & 31u;
+            if (dw + 1u - f.tile_dw >= (uint32_t)EXT_TILE) f.stage(dw);   // (tile must hold dw and dw + 1)
+            const uint32_t lo = __builtin_amdgcn_readfirstlane(f.tile[dw - f.tile_dw]);
+            const uint32_t hi = __builtin_amdgcn_readfirstlane(f.tile[dw + 1u - f.tile_dw]);
+            return sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+        };
+        for (;;) {
+            const uint32_t qx0 = ((d + W + 1u) >> 1) - 1u, qy0 = ((d + 1u + 62u - W) >> 1) - 1u;  // first bases this block lets in
+            const uint32_t last = d + 2u * UNITS - 1u;
+            if (last > d_end || last >= first_rec || qx0 + UNITS > rem || qy0 + UNITS > lb) break;
+            uint32_t wx = window(fx, qx0), wy = window(fy, qy0);
+#pragma unroll
+            for (int u = 0; u < UNITS; ++u) {
+                const uint32_t sx = wx & BMASK;
+                wx >>= BITS;
+                shift_x();
+                door(xr, sx, 0);
+                shift_y();
+                cell(c_first);
+                const uint32_t sy = wy & BMASK;
+                wy >>= BITS;
+                shift_x();
+                shift_y();
+                door(yr, sy, 63);
+                cell(c_second);
+            }
+            d += 2u * UNITS;
+            steps += 2u * UNITS;
+            if (band_dead()) {
                 dead = true;
                 break;
             }
         }
+        fx.cur_dw = ~0u;   // (the slow feeds start again from whatever tile is staged)
+        fy.cur_dw = ~0u;
+    }
+    // ---- tail: the last steps, with sentinels and ends
+    while (!dead && d <= d_end) {
+        slow_step();
+        if ((d & 63u) == 0u && band_dead()) dead = true;
     }
     // ---- best end per family: smallest cost, then closest to the main diagonal, then the smaller coordinate
-    const uint32_t off = (uint32_t)(k >= iW ? k - iW : iW - k);
-    const int32_t jA = (int32_t)rem - iW + k;   // column reached on row rem
-    const int32_t iB = (int32_t)lb + iW - k;    // row reached on column lb
+    const uint32_t off = (uint32_t)(dlt >= 0 ? dlt : -dlt);
+    const int32_t jA = (int32_t)rem + dlt;   // column reached on row rem
+    const int32_t iB = (int32_t)lb - dlt;    // row reached on column lb
     const bool okA = canA && in_band && endA <= E && jA >= 1 && jA <= (int32_t)lb;
     const bool okB = canB && in_band && endB <= E && iB >= 1 && iB <= (int32_t)rem;
-    const uint32_t keyA = okA ? ((endA << 8) | (off << 1) | (k > iW ? 1u : 0u)) : 0xFFFFFFFFu;
-    const uint32_t keyB = okB ? ((endB << 8) | (off << 1) | (k < iW ? 1u : 0u)) : 0xFFFFFFFFu;
+    const uint32_t keyA = okA ? ((endA << 8) | (off << 1) | (dlt > 0 ? 1u : 0u)) : 0xFFFFFFFFu;
+    const uint32_t keyB = okB ? ((endB << 8) | (off << 1) | (dlt < 0 ? 1u : 0u)) : 0xFFFFFFFFu;
     const uint32_t bestA = wave_min(keyA), bestB = wave_min(keyB);
     uint32_t t = 0;
     if (bestA != 0xFFFFFFFFu) {

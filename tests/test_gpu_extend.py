@@ -81,7 +81,7 @@ def noisy_reads(rng, n_reads, glen, lo, hi, sub, indel, both_strands):
     return reads
 
 
-@pytest.mark.parametrize("seed,max_diff,band", [(1, 1, 1), (2, 3, 2), (3, 8, 4), (4, 20, 16), (5, 40, 31), (6, 5, 0), (7, 2, 31)])
+@pytest.mark.parametrize("seed,max_diff,band", [(1, 1, 1), (2, 3, 2), (3, 8, 4), (4, 20, 16), (5, 40, 30), (6, 5, 0), (7, 2, 30)])
 def test_inexact_rows_equal_the_cpu_restatement(seed, max_diff, band):
     rng = np.random.default_rng(1000 + seed)
     seqs = noisy_reads(rng, n_reads=40, glen=3000, lo=150, hi=1400, sub=0.01, indel=0.006, both_strands=seed % 2 == 0)
@@ -114,7 +114,7 @@ def test_inexact_mode_on_8bit_reads_and_errors():
     assert ov.stats()["bits_per_base"] == 8
     assert np.array_equal(got, ck.oracle_overlaps_ex(seqs, 30, 4, 3, anchor=8))
     with pytest.raises(ValueError):
-        ov.overlaps_ex_array(30, 4, 32)      # band > 31
+        ov.overlaps_ex_array(30, 4, 31)      # band > 30
     ov.close()
     # sparse non-ACGT bytes on the 2-bit path: exact mode works (exception records), inexact mode refuses
     ov = ExactOverlapper()
