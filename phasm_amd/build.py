@@ -21,6 +21,28 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
+# k_scan_probe waits for its inline-asm loads with hand-counted s_waitcnt; tools/check_scan_isa.py walks the generated
+# code for reads of a register whose load is still in flight.  The walk was validated against the code these hipcc
+# versions generate; another compiler may lay the kernel out differently, so the build says so loudly and the CPU
+# test (tests/test_kernel_resources.py) fails until the checker has been looked at again.
+VALIDATED_HIPCC = ("7.2.26015",)
+
+
+def hipcc_version(hipcc: str = None) -> str:
+    hipcc = hipcc or os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+    for line in out.splitlines():
+        if line.startswith("HIP version:"):
+            return line.split(":", 1)[1].strip().split("-")[0]
+    return "unknown"
+
+
+def check_scan_isa() -> None:
+    """Fails (CalledProcessError) when the generated k_scan_probe reads a landing register before its wait."""
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "check_scan_isa.py"), "--strict"],
+                          stdout=subprocess.DEVNULL)
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
@@ -31,6 +53,16 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    if not os.environ.get("PHASM_SKIP_ISA_CHECK"):
+        try:
+            check_scan_isa()   # a library whose scan pipeline reads in-flight registers must not ship
+        except subprocess.CalledProcessError:
+            os.remove(LIB)
+            raise RuntimeError("k_scan_probe: tools/check_scan_isa.py --strict found a read of an in-flight register; library removed")
+        v = hipcc_version(hipcc)
+        if v not in VALIDATED_HIPCC:
+            print("WARNING: hipcc %s is not one of %s: re-validate tools/check_scan_isa.py against this compiler's code "
+                  "for k_scan_probe" % (v, VALIDATED_HIPCC), file=sys.stderr)
     return LIB
 
 

@@ -739,6 +739,11 @@ constexpr int SCAN_LDS_PER_WAVE = 2 * WAVE * 4 + WAVE * 4;  // queue of position
 #define PO_STAMP(var) do { } while (0)
 #endif
 
+// COMPILER CONTRACT: the landing registers of the asm loads below are "defined" at issue as far as hipcc knows; it must
+// not copy or spill them before the asm wait that retires them.  tools/check_scan_isa.py walks the generated code for
+// that; it runs inside phasm_amd/build.py (a violating library is deleted, not shipped) and in the CPU tests, and was
+// validated against the code of hipcc 7.2.26015 (ROCm 7.2.0, AMD clang 22.0.0git) -- build.py:VALIDATED_HIPCC; the
+// test fails on any other compiler until the walk has been checked against its output.
 template <int BITS, bool FULLK>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  // A stays in SGPRs: never take its address
     constexpr int W = 64 / BITS;

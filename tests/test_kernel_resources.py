@@ -69,3 +69,8 @@ def test_scan_pipeline_never_reads_a_register_whose_load_is_in_flight():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
     assert "0 problem(s)" in out.stdout
+    # the walk is only as good as its reading of the compiler's output: an unknown compiler is a failure, not a pass
+    from phasm_amd import build
+    v = build.hipcc_version(shutil.which("hipcc"))
+    assert v in build.VALIDATED_HIPCC, ("hipcc %s: look at k_scan_probe's generated code again, then add the version to "
+                                        "phasm_amd/build.py:VALIDATED_HIPCC" % v)
