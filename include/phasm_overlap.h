@@ -130,6 +130,13 @@ po_status po_invalidate(po_handle* h);
  * call, :33-36); min_length 0 behaves as 1 (a suffix array has no empty suffix).          */
 po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out);
 
+/* overlaps(min_length) the way the reference returns it -- the whole vector<OverlapT> in host memory
+ * (src/overlapper.cpp:149) -- as ONE pipelined call: po_overlaps + po_result_rows, with the rows of one chunk of a-side
+ * reads travelling device->host (second stream, one page-locked array) while the next chunk is in the kernels.  The
+ * result holds the host array only (po_result_rows returns it at once; po_result_device_rows is NULL; po_layout_edges
+ * would copy the rows back).  Same multiset of rows as po_overlaps, a-major chunk by chunk. */
+po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out);
+
 /* Banded seed-extension mode -- an EXTENSION BEYOND THE REFERENCE, which is exact (src/overlapper.cpp:28-150; CLI help
  * "exact overlaps", phasm/cli/assembler.py:436-439).  Same anchors as po_overlaps (b's K-base prefix found in a); every
  * candidate is extended by a banded edit-distance DP (unit costs, diagonals -band..band, band <= 30, one wavefront per

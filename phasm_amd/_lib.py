@@ -82,6 +82,7 @@ SYMBOLS = [
     ("po_upload", ctypes.c_int, [_P]),
     ("po_invalidate", ctypes.c_int, [_P]),
     ("po_overlaps", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(_P)]),
+    ("po_overlaps_to_host", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_overlaps_ex", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_overlaps_shard", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_candidates_shard", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),

@@ -115,6 +115,10 @@ struct po_handle {
     size_t reg_bytes[2] = {0, 0};
     int poison = -1;       // PHASM_POISON=<byte>: per-call workspaces are filled with it before every call
     // po_overlaps_ex: the verify step is the banded DP of extend.hip.h (set around the call by po_overlaps_ex)
+    // po_overlaps_to_host: a second stream copies chunk k's rows to the host while chunk k + 1 is computed
+    hipStream_t copy_stream = nullptr;
+    DevBuf chunk_rows[4];
+    uint64_t last_host_rows = 0;   // rows of the previous po_overlaps_to_host call (sizes the pinned buffer up front)
     bool ex_on = false;
     uint32_t ex_E = 0, ex_W = 0;
     DevBuf d_end_a, d_end_b, d_dpcnt;
@@ -1609,6 +1613,11 @@ void po_destroy(po_handle* h) {
         if (h->pinned) (void)hipHostFree(h->pinned);
         h->spare_host.release();
         h->scratch_host.release();
+        for (DevBuf& b : h->chunk_rows) b.release();
+        if (h->copy_stream) {
+            (void)hipStreamSynchronize(h->copy_stream);
+            (void)hipStreamDestroy(h->copy_stream);
+        }
         unpin_words(h);
         (void)hipStreamDestroy(h->stream);
     }
@@ -1854,6 +1863,128 @@ po_status po_expand(po_handle* h, const void* candidates_device, uint64_t n_cand
 
 po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out) {
     return po_overlaps_shard(h, min_length, 0, 1, out);
+}
+
+// po_overlaps + po_result_rows in one call, pipelined: the a-side reads are cut into chunks (the shards of
+// po_overlaps_shard), and while chunk k + 1 goes through the kernels on the handle's stream, chunk k's rows travel
+// device -> host on a second stream into ONE page-locked array.  Same rows as po_overlaps as a multiset (sharded
+// calls pick the canonical member of a strand-mirror pair by the scrambled read order), in
+// a-major order chunk by chunk.  The result holds the host array only.
+po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out) {
+    if (!h || !out) return PO_ERR_INVALID;
+    *out = nullptr;
+    if (h->segments_only) return fail(h, PO_ERR_INVALID, "this handle holds GFA segments without sequences: nothing to overlap");
+    // small jobs: nothing to overlap (a chunk costs ~40 kernel launches)
+    uint32_t n_chunks = (h->len.size() >= 8192 && h->total_bases >= (64ull << 20)) ? 4u : 1u;
+    if (const char* e = getenv("PHASM_HOST_CHUNKS")) n_chunks = (uint32_t)std::max(1, std::min(4, atoi(e)));
+    po_result* r = new (std::nothrow) po_result();
+    if (!r) return fail(h, PO_ERR_NOMEM, "out of host memory");
+    r->h = h;
+    po_status st = PO_OK;
+    HostBuf hb;
+    uint64_t total = 0;
+    po_stats sum = {};
+    try {
+        st = upload(h);
+        if (st == PO_OK && !h->copy_stream && hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess)
+            st = fail(h, PO_ERR_HIP, "cannot create the copy stream");
+        if (st == PO_OK && h->spare_host.p) {   // the pinned array of an earlier result, if there is one
+            hb = h->spare_host;
+            h->spare_host = HostBuf();
+        }
+        for (uint32_t k = 0; k < n_chunks && st == PO_OK; ++k) {
+            po_result part;
+            part.h = h;
+            // chunk k emits into its own device buffer (kept on the handle): it must outlive its copy
+            if (h->chunk_rows[k].p) {
+                h->spare_rows.release();
+                h->spare_rows = h->chunk_rows[k];
+                h->chunk_rows[k] = DevBuf();
+            }
+            st = h->bits == 2 ? run_overlaps<2>(h, min_length, k, n_chunks, false, &part)
+                              : run_overlaps<8>(h, min_length, k, n_chunks, false, &part);
+            h->chunk_rows[k] = part.d_rows;   // (run_overlaps returned: this chunk's rows are complete on the device)
+            part.d_rows = DevBuf();
+            if (st != PO_OK) break;
+            const po_stats& S = h->stats;
+            sum.n_candidates += S.n_candidates;
+            sum.n_verified += S.n_verified;
+            sum.n_rows += S.n_rows;
+            sum.sum_overlap_bases += S.sum_overlap_bases;
+            sum.verify_bytes_algo += S.verify_bytes_algo;
+            sum.verify_bytes_exec += S.verify_bytes_exec;
+            sum.n_tiles += S.n_tiles;
+            sum.shard_bases += S.shard_bases;
+            sum.ms_index += S.ms_index;
+            sum.ms_scan_count += S.ms_scan_count;
+            sum.ms_scan_fill += S.ms_scan_fill;
+            sum.ms_verify += S.ms_verify;
+            sum.ms_select += S.ms_select;
+            sum.ms_emit += S.ms_emit;
+            sum.ms_total += S.ms_total;
+            sum.ms_scan_probe += S.ms_scan_probe;
+            sum.ms_verify_kernel += S.ms_verify_kernel;
+            const uint64_t nk = part.count;
+            if (nk == 0) continue;
+            const size_t need = (size_t)(total + nk) * sizeof(po_row);
+            if (need > hb.cap) {
+                // first call, or more rows than last time: guess the whole from what has been seen, move what is there
+                const uint64_t guess = std::max<uint64_t>(h->last_host_rows, (total + nk) * n_chunks / (k + 1));
+                HostBuf bigger;
+                st = ensure_host(h, bigger, std::max<size_t>(need, (size_t)(guess + guess / 8) * sizeof(po_row)));
+                if (st != PO_OK) break;
+                if (hipStreamSynchronize(h->copy_stream) != hipSuccess) { st = fail(h, PO_ERR_HIP, "copy stream"); bigger.release(); break; }
+                if (total) std::memcpy(bigger.p, hb.p, (size_t)total * sizeof(po_row));
+                hb.release();
+                hb = bigger;
+            }
+            if (hipMemcpyAsync(static_cast<char*>(hb.p) + (size_t)total * sizeof(po_row), h->chunk_rows[k].p,
+                               (size_t)nk * sizeof(po_row), hipMemcpyDeviceToHost, h->copy_stream) != hipSuccess) {
+                st = fail(h, PO_ERR_HIP, "row copy device->host");
+                break;
+            }
+            total += nk;
+        }
+    } catch (const std::bad_alloc&) {
+        st = fail(h, PO_ERR_NOMEM, "out of host memory in po_overlaps_to_host");
+    }
+    if (h->dev_ready) (void)hipStreamSynchronize(h->stream);
+    if (h->copy_stream && hipStreamSynchronize(h->copy_stream) != hipSuccess && st == PO_OK) st = fail(h, PO_ERR_HIP, "row copy device->host");
+    if (st != PO_OK) {
+        hb.release();
+        delete r;
+        return st;
+    }
+    // the call's statistics: sums over the chunks (per-call fields from the last chunk)
+    po_stats& S = h->stats;
+    S.n_candidates = sum.n_candidates;
+    S.n_verified = sum.n_verified;
+    S.n_rows = sum.n_rows;
+    S.sum_overlap_bases = sum.sum_overlap_bases;
+    S.verify_bytes_algo = sum.verify_bytes_algo;
+    S.verify_bytes_exec = sum.verify_bytes_exec;
+    S.n_tiles = sum.n_tiles;
+    S.shard_bases = sum.shard_bases;
+    S.ms_index = sum.ms_index;
+    S.ms_scan_count = sum.ms_scan_count;
+    S.ms_scan_fill = sum.ms_scan_fill;
+    S.ms_verify = sum.ms_verify;
+    S.ms_select = sum.ms_select;
+    S.ms_emit = sum.ms_emit;
+    S.ms_total = sum.ms_total;
+    S.ms_scan_probe = sum.ms_scan_probe;
+    S.ms_verify_kernel = sum.ms_verify_kernel;
+    h->last_host_rows = total;
+    r->count = total;
+    if (total) {
+        r->host = hb.p;
+        r->host_cap = hb.cap;
+    } else if (hb.p) {
+        h->spare_host = hb;   // nothing to hand out: keep the buffer
+    }
+    ++h->live_results;
+    *out = r;
+    return PO_OK;
 }
 
 po_status po_overlaps_ex(po_handle* h, uint32_t min_length, uint32_t max_diff, uint32_t band, po_result** out) {

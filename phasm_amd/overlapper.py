@@ -173,6 +173,14 @@ class ExactOverlapper:
         _check(self._h, self._lib.po_overlaps_shard(self._h, m, int(shard), int(nshards), ctypes.byref(r)))
         return OverlapResult(self, r)
 
+    def overlaps_to_host_result(self, min_length: int) -> OverlapResult:
+        """``po_overlaps_to_host``: the rows land in page-locked host memory while later chunks are still being
+        computed; ``rows_view()`` / ``rows()`` of the result cost no further copy from the device."""
+        m = self._min_length(min_length)
+        r = ctypes.c_void_p()
+        _check(self._h, self._lib.po_overlaps_to_host(self._h, m, ctypes.byref(r)))
+        return OverlapResult(self, r)
+
     def overlaps_ex_result(self, min_length: int, max_diff: int = 0, band: int = 0) -> OverlapResult:
         """``po_overlaps_ex``: banded seed-extension DP with up to ``max_diff`` differences (an extension beyond the
         exact reference; ``max_diff = 0`` gives the rows of ``overlaps``)."""
@@ -212,7 +220,7 @@ class ExactOverlapper:
         return OverlapResult(self, r)
 
     def overlaps_array(self, min_length: int) -> np.ndarray:
-        res = self.overlaps_result(min_length)
+        res = self.overlaps_to_host_result(min_length)
         try:
             return res.rows()
         finally:

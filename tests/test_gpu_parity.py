@@ -626,3 +626,34 @@ def test_store1_rebuilt_on_the_device_is_what_the_host_packed(monkeypatch):
     got, st2 = hip_rows(seqs, m)
     assert st2["paired"] == 1 and st2["upload_bytes"] > 1.9 * sum(((len(s) + 31) // 32) * 8 for s in seqs[::2])
     same(got, want)
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 3, 4])
+def test_rows_to_host_pipelined(chunks, monkeypatch):
+    """po_overlaps_to_host: chunks of a-side reads, chunk k's rows copied to the host while chunk k + 1 is computed.
+    Same rows as the goldens whatever the chunk count; the result serves rows(), repeated calls reuse the buffers."""
+    monkeypatch.setenv("PHASM_HOST_CHUNKS", str(chunks))
+    for name in ("ladder_varlen", "cfg2_1k", "cfg3_1k"):
+        _, seqs, m, want = gu.ladder_case(name)
+        ov = ExactOverlapper()
+        for i, s in enumerate(seqs):
+            ov.add_sequence("r%d" % i, s)
+        _last.update(seqs=seqs, m=m)
+        for rep in range(3):
+            res = ov.overlaps_to_host_result(m if rep < 2 else 2 * m)
+            arr = res.rows_view()
+            assert len(arr) == len(res) == ov.stats()["n_rows"]
+            got = oo.sort_rows(oo.struct_to_rows(arr))
+            res.free()
+            if rep < 2:
+                same(got, want, "%s, %d chunks, call %d" % (name, chunks, rep))
+            else:
+                _last.update(seqs=seqs, m=2 * m)
+                same(got, ck.oracle_overlaps(seqs, 2 * m), "%s at 2m" % name)
+                _last.update(seqs=seqs, m=m)
+        # an empty answer and the reference API's list of tuples come through the same path
+        res = ov.overlaps_to_host_result(10_000_000)
+        assert len(res) == 0 and len(res.rows()) == 0
+        res.free()
+        assert len(ov.overlaps(m)) == len(want)
+        ov.close()
