@@ -119,6 +119,13 @@ struct po_handle {
     hipStream_t copy_stream = nullptr;
     DevBuf chunk_rows[4];
     uint64_t last_host_rows = 0;   // rows of the previous po_overlaps_to_host call (sizes the pinned buffer up front)
+    // the anchor index of the last call, reusable while the device copy of the reads and the parameters it was built
+    // for are unchanged (the chunks of po_overlaps_to_host, the shards of a multi-GPU step, repeated calls)
+    uint64_t upload_gen = 0;
+    bool idx_valid = false;
+    uint64_t idx_gen = 0;
+    uint32_t idx_m = 0, idx_tbits = 0, idx_bits = 0;
+    bool idx_wide = false;
     bool ex_on = false;
     uint32_t ex_E = 0, ex_W = 0;
     DevBuf d_end_a, d_end_b, d_dpcnt;
@@ -557,6 +564,7 @@ po_status upload(po_handle* h) {
     (void)hipEventElapsedTime(&ms, h->ev_up0, h->ev_up1);
     h->stats.ms_upload = ms;
     h->stats.upload_bytes = h->upload_bytes;
+    ++h->upload_gen;
     h->dirty = false;
     return PO_OK;
 }
@@ -708,15 +716,26 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         for (DevBuf* b : ws)
             if (b->p) HIP_TRY(h, hipMemsetAsync(b->p, h->poison, b->cap, st));
     }
-    // ---- index: anchor table, chains, Bloom filter
+    // ---- index: anchor table, chains, Bloom filter.  Built per call like the reference builds its suffix array per
+    // call (overlapper.cpp:33-36) -- unless THIS handle built exactly this index for exactly this device copy of the
+    // reads already (same upload, min_length, flavour, size): the chunks of po_overlaps_to_host and the shards of a
+    // multi-GPU step then share one build instead of repeating it (the replicated part of a sharded step).
     HIP_TRY(h, hipEventRecord(h->ev[EV_START], st));
-    {
+    const bool reuse_index = h->idx_valid && h->idx_gen == h->upload_gen && h->idx_m == m && h->idx_wide == wide &&
+                             h->idx_tbits == tbits && h->idx_bits == (uint32_t)BITS && h->poison < 0 && !getenv("PHASM_NO_INDEX_REUSE");
+    S.index_reused = reuse_index ? 1u : 0u;
+    h->idx_valid = false;
+    if (reuse_index) {
+        hipLaunchKernelGGL(po::k_call_reset, dim3(cdiv(std::max(n, 8u), 256)), dim3(256), 0, st, selfrep, n, scalars);
+    } else {
         const uint32_t bloom_words = (uint32_t)(bloom_bytes / 4);
         const uint32_t init_n = std::max(std::max(nslots, n), std::max(bloom_words, 8u));
         hipLaunchKernelGGL(po::k_call_init, dim3(cdiv(init_n, 256)), dim3(256), 0, st, table, nslots, slot_cnt, slot_cur, selfrep, n,
                            bloom, bloom_words, scalars);
     }
-    if (!wide) {
+    if (reuse_index) {
+        // (nothing to build)
+    } else if (!wide) {
         hipLaunchKernelGGL(po::k_table_insert, dim3(cdiv(n, 256)), dim3(256), 0, st, words, woff, len, n, m, kmask, table,
                            tbits, slot_cnt, read_slot, bloom, bloom_log2, (uint32_t)BITS);
         PO_TRY(prefix_sum<uint32_t>(h, slot_cnt, nslots, slot_start, &h->pinned[0]));
@@ -747,6 +766,12 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     // shards -- and settle duplicates inside each read's own candidate list instead (k_select_local, below).
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev[EV_INDEX], st));
+    h->idx_valid = true;
+    h->idx_gen = h->upload_gen;
+    h->idx_m = m;
+    h->idx_wide = wide;
+    h->idx_tbits = tbits;
+    h->idx_bits = (uint32_t)BITS;
 
     // ---- scan, counting pass
     po::ScanArgs A = {};
@@ -979,11 +1004,13 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         // ---- select + row offsets
         po::PairSlot* ptab = nullptr;
         uint32_t pbits = 0;
+        uint32_t* n_deferred = reinterpret_cast<uint32_t*>(scalars + 1) + 1;  // reads k_select_local hands to the global table
+        const uint32_t* gate = nullptr;
         if (nshards > 1 || wide || dpE) {
             static_assert(po::SEL_CAP == 512, "k_select_local hashes to 9 bits");
             hipLaunchKernelGGL(po::k_select_local, dim3(cdiv(r_end - r_begin, 256 / po::WAVE)), dim3(256), 0, st,
                                h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_b, h->d_type.as<uint8_t>(),
-                               r_begin, r_end - r_begin, selfrep);
+                               r_begin, r_end - r_begin, selfrep, n_deferred);
         }
         if (n_selfrep_reads) {
             // some read's prefix recurs inside it (or a read was too repetitive for k_select_local): A candidates
@@ -991,6 +1018,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             uint32_t n_sus;
             if ((nshards > 1 || wide) && n_cand < (4u << 20)) {
                 n_sus = n_cand;  // upper bound: no counting pass, no host round trip (a big call sizes its table exactly)
+                gate = n_deferred;  // ... and nothing of it is touched unless k_select_local handed a read over
             } else {
                 uint32_t* n_suspect = reinterpret_cast<uint32_t*>(scalars + 2) + 1;
                 hipLaunchKernelGGL(po::k_count_suspects, dim3(std::min<uint32_t>(cdiv(n_cand, 256), (uint32_t)h->n_cu * 8)), dim3(256), 0,
@@ -1003,16 +1031,17 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                 pbits = 4;
                 while ((1ull << pbits) < 2ull * n_sus) ++pbits;
                 PO_TRY(ensure(h, h->d_pair_key, ((size_t)1 << pbits) * sizeof(po::PairSlot)));
-                HIP_TRY(h, hipMemsetAsync(h->d_pair_key.p, 0xFF, ((size_t)1 << pbits) * sizeof(po::PairSlot), st));
+                hipLaunchKernelGGL(po::k_fill_gated, dim3((uint32_t)h->n_cu * 8), dim3(256), 0, st, h->d_pair_key.as<uint4>(),
+                                   (uint64_t)((size_t)1 << pbits) * sizeof(po::PairSlot) / 16, 0xFFFFFFFFu, gate);
                 ptab = h->d_pair_key.as<po::PairSlot>();
                 hipLaunchKernelGGL(po::k_select_mark, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_b,
-                                   h->d_type.as<uint8_t>(), n_cand, selfrep, ptab, pbits);
+                                   h->d_type.as<uint8_t>(), n_cand, selfrep, ptab, pbits, gate);
             }
         }
         if (want_cands) PO_TRY(ensure(h, h->d_flag, (size_t)n_cand));
         hipLaunchKernelGGL(po::k_select, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_b,
                            h->d_type.as<uint8_t>(), n_cand, selfrep, ptab, pbits, paired, h->d_rowcnt.as<uint8_t>(),
-                           want_cands ? h->d_flag.as<uint8_t>() : nullptr);
+                           want_cands ? h->d_flag.as<uint8_t>() : nullptr, gate);
         HIP_TRY(h, hipGetLastError());
         // A candidate gives at most 2 rows (4 with their mirrors).  When the row buffer kept from an earlier call
         // holds that many, the rows are emitted without asking the host for their number first (one host round

@@ -266,6 +266,13 @@ __global__ void k_call_init(Slot* tab, uint32_t nslots, uint32_t* slot_cnt, uint
     if (i < 8) scalars[i] = 0;
 }
 
+// the per-call part of k_call_init, for a call that reuses the index of the previous one
+__global__ void k_call_reset(uint32_t* selfrep, uint32_t n_reads, unsigned long long* scalars) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_reads) selfrep[i] = NO_SELFREP;
+    if (i < 8) scalars[i] = 0;
+}
+
 __global__ void k_fill_u32(uint32_t* p, uint64_t n, uint32_t v) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -1658,7 +1665,8 @@ __device__ inline uint32_t pair_slot(uint32_t a, uint32_t b, uint32_t tbits) {
 constexpr uint32_t SEL_CAP = 512;  // LDS table entries per wave (load <= 1/2)
 __global__ __launch_bounds__(256) void k_select_local(const uint32_t* __restrict__ read_tile0, const uint32_t* __restrict__ tile_off,
                                                       const uint32_t* __restrict__ cand_b, uint8_t* __restrict__ type,
-                                                      uint32_t r_begin, uint32_t n_reads, uint32_t* __restrict__ selfrep) {
+                                                      uint32_t r_begin, uint32_t n_reads, uint32_t* __restrict__ selfrep,
+                                                      uint32_t* __restrict__ n_deferred) {
     __shared__ uint32_t s_key[256 / WAVE][SEL_CAP];  // b + 1, 0 = empty
     __shared__ uint32_t s_min[256 / WAVE][SEL_CAP];
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
@@ -1676,6 +1684,7 @@ __global__ __launch_bounds__(256) void k_select_local(const uint32_t* __restrict
     if (n_a > SEL_CAP / 2) {
         for (uint32_t c = seg0 + lane; c < seg1; c += WAVE)
             if (type[c] & 1u) selfrep[cand_b[c]] = 0;  // "may repeat": the global selection handles this read
+        if (lane == 0) atomicAdd(n_deferred, 1u);   // (the global table is only filled and looked at when this is non-zero)
         return;
     }
     uint32_t* key = s_key[wave];
@@ -1724,9 +1733,19 @@ __global__ __launch_bounds__(256) void k_count_suspects(const uint32_t* __restri
     }
 }
 
+// `gate` (may be null = always): the number of reads k_select_local handed over.  Sharded calls size the global
+// (a, b) table for the worst case without asking the host; when no read was handed over -- every data set without
+// tandem repeats -- the table is neither initialised nor filled nor looked at (28 MB of memset per shard otherwise).
+__global__ void k_fill_gated(uint4* __restrict__ p, uint64_t n16, uint32_t v, const uint32_t* __restrict__ gate) {
+    if (gate && *gate == 0u) return;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x)
+        p[i] = uint4{v, v, v, v};
+}
+
 __global__ void k_select_mark(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_b,
                               const uint8_t* __restrict__ type, uint32_t n_cand, const uint32_t* __restrict__ selfrep,
-                              PairSlot* __restrict__ ptab, uint32_t tbits) {
+                              PairSlot* __restrict__ ptab, uint32_t tbits, const uint32_t* __restrict__ gate) {
+    if (gate && *gate == 0u) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_cand || !(type[i] & 1u)) return;
     const uint32_t a = cand_a[i], b = cand_b[i];
@@ -1753,9 +1772,11 @@ __device__ inline uint32_t rows_of(uint32_t t, uint32_t a, uint32_t b, uint32_t 
 __global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_b,
                          uint8_t* __restrict__ type, uint32_t n_cand, const uint32_t* __restrict__ selfrep,
                          const PairSlot* __restrict__ ptab, uint32_t tbits,
-                         uint32_t paired, uint8_t* __restrict__ rowcnt, uint8_t* __restrict__ flag) {
+                         uint32_t paired, uint8_t* __restrict__ rowcnt, uint8_t* __restrict__ flag,
+                         const uint32_t* __restrict__ gate) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_cand) return;
+    if (gate && *gate == 0u) ptab = nullptr;   // nothing was handed to the global table: it was never filled
     uint32_t t = type[i];
     if (t == 0) {
         rowcnt[i] = 0;

@@ -15,6 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
 @pytest.mark.skipif(not glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"), reason="no ASan runtime")
 @pytest.mark.skipif(os.environ.get("PHASM_SKIP_ASAN_TEST") == "1", reason="already inside the sanitizer run")
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "tools", "asan_cpu_suite.sh")),
+                    reason="tools/asan_cpu_suite.sh does not travel to the GPU box (.gpurunignore): sanitizers run on the CPU build only")
 def test_host_paths_are_clean_under_asan_and_ubsan(tmp_path):
     env = dict(os.environ, ASAN_OUT=str(tmp_path))
     out = subprocess.run([os.path.join(ROOT, "tools", "asan_cpu_suite.sh"), "tests/test_host_io.py", "tests/test_abi.py",
