@@ -150,6 +150,9 @@ struct po_result {
     void* host = nullptr;     // host copy of the entries: pinned (hipHostMalloc, host_cap bytes) unless host_malloced
     size_t host_cap = 0;
     bool host_malloced = false;  // po_result_from_rows: plain malloc (works without a GPU)
+    // rows written by this library's paired-strand emission: every (row, strand mirror) group is the only writer of
+    // its twin edge pair -- po_layout_edges needs no dedupe table for them (layout.hip.h, k_layout_winner_adjacent)
+    bool unique_twins = false;
     // po_candidates_shard_into: the caller's buffer the candidates go to when they fit
     void* ext_dst = nullptr;
     uint64_t ext_cap = 0;
@@ -1116,6 +1119,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     HIP_TRY(h, hipStreamSynchronize(st));
     if (rows_late) n_rows64 = h->pinned[2];  // (<= worst_rows < 2^32 by construction of the fast path)
     res->count = n_rows64;
+    res->unique_twins = !want_cands && paired != 0 && !dpE;
     S.n_rows = want_cands ? 0 : n_rows64;
     S.n_verified = want_cands ? n_rows64 : counters[0];
     S.sum_overlap_bases = counters[1];
@@ -1194,6 +1198,7 @@ po_status run_expand(po_handle* h, const void* d_cands, uint64_t n, po_result* r
         n_rows = h->pinned[2];
     }
     res->count = n_rows;
+    res->unique_twins = paired != 0;
     S.n_rows = n_rows;
     S.sum_overlap_bases = h->pinned[5];
     S.verify_bytes_algo = h->pinned[6];
@@ -1281,7 +1286,30 @@ po_status run_layout(po_handle* h, po_result* rows, const po_layout_params& prm,
     L.n_pass = c[po::LC_PASS];
     L.n_contained_reads = c[po::LC_N];
     uint64_t n_edges = 0;
-    if (L.n_pass) {
+    if (L.n_pass && rows->unique_twins && !getenv("PHASM_LAYOUT_TABLE")) {
+        // rows straight from the paired-strand emission: the last row of an adjacent (row, mirror) group owns the pair
+        PO_TRY(ensure(h, h->d_ecnt, (size_t)n_rows));
+        PO_TRY(ensure(h, h->d_ewin, (size_t)n_rows));
+        PO_TRY(ensure(h, h->d_eoff, ((size_t)n_rows + 1) * 4));
+        hipLaunchKernelGGL(po::k_layout_winner_adjacent, dim3(cdiv(n_rows, 256)), dim3(256), 0, st, d_rows, n_rows, d_len,
+                           h->d_rflag.as<uint8_t>(), h->d_removed.as<uint8_t>(), h->d_ecnt.as<uint8_t>(), h->d_ewin.as<uint8_t>());
+        HIP_TRY(h, hipGetLastError());
+        PO_TRY(prefix_sum<uint8_t>(h, h->d_ecnt.as<uint8_t>(), n_rows, h->d_eoff.as<uint32_t>(), &h->pinned[2]));
+        HIP_TRY(h, hipEventRecord(h->ev_lay[2], st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        n_edges = h->pinned[2];
+        if (h->spare_edges.p && h->spare_edges.cap >= n_edges * sizeof(po_edge)) {
+            res->d_rows = h->spare_edges;
+            h->spare_edges = DevBuf();
+        }
+        PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_edges * sizeof(po_edge), 256)));
+        if (n_edges) {
+            hipLaunchKernelGGL(po::k_layout_emit, dim3(cdiv(n_rows, 256)), dim3(256), 0, st, d_rows, n_rows, d_len,
+                               h->d_rflag.as<uint8_t>(), h->d_ewin.as<uint8_t>(), h->d_eoff.as<uint32_t>(),
+                               res->d_rows.as<po::Edge>());
+            HIP_TRY(h, hipGetLastError());
+        }
+    } else if (L.n_pass) {
         // twin pair -> last writer row: 2 slots per surviving row (load <= 1/2; 1/4 when every row has its
         // strand-mirror twin), 16-byte slots
         if (2 * L.n_pass + 64 >= 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "po_layout_edges: too many edges for one call");
@@ -2005,6 +2033,7 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
     S.ms_verify_kernel = sum.ms_verify_kernel;
     h->last_host_rows = total;
     r->count = total;
+    r->unique_twins = h->bits == 2 && h->paired;   // (chunks are a-major and disjoint in a: groups stay adjacent)
     if (total) {
         r->host = hb.p;
         r->host_cap = hb.cap;

@@ -228,6 +228,45 @@ __global__ __launch_bounds__(256) void k_layout_winner(const Row* __restrict__ r
     ecnt[i] = (uint8_t)__popc(win);
 }
 
+// Passes 2 + 3 in one, without the table, for rows that come straight from this library's paired-strand emission
+// (k_emit / k_emit_cands with `paired`): a twin pair {(u, v), (v^1, u^1)} is then written by exactly ONE verified
+// candidate -- A rows are unique per ordered pair, the candidate's strand mirror IS the twin, and k_emit puts the
+// mirror row right behind the row -- so the last writer of a pair is simply the last row of its adjacent group.  No
+// CAS, no atomicMin, no 224 MB table to initialise (0.54 -> 0.1 ms at config 2).
+__global__ __launch_bounds__(256) void k_layout_winner_adjacent(const Row* __restrict__ rows, uint32_t n_rows,
+                                                                const uint32_t* __restrict__ len,
+                                                                const uint8_t* __restrict__ rflag,
+                                                                const uint8_t* __restrict__ removed,
+                                                                uint8_t* __restrict__ ecnt, uint8_t* __restrict__ ewin) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const uint32_t f = rflag[i];
+    uint32_t win = 0;
+    if (f & RF_PASS) {
+        const Row r = rows[i];
+        if (!(removed[r.a_idx >> 1] | removed[r.b_idx >> 1])) {
+            Edge e1, e2;
+            row_edges(r, f & RF_TYPE, len[r.a_idx], len[r.b_idx], e1, e2);
+            bool self_twin;
+            const unsigned long long key = pair_key(e1, e2, self_twin);
+            bool shadowed = false;   // the next row writes the same pair: it is the later writer
+            if (i + 1 < n_rows) {
+                const uint32_t f2 = rflag[i + 1];
+                if (f2 & RF_PASS) {
+                    const Row r2 = rows[i + 1];
+                    Edge g1, g2;
+                    row_edges(r2, f2 & RF_TYPE, len[r2.a_idx], len[r2.b_idx], g1, g2);
+                    bool st2;
+                    shadowed = pair_key(g1, g2, st2) == key;
+                }
+            }
+            if (!shadowed) win = self_twin ? 2u : 3u;
+        }
+    }
+    ewin[i] = (uint8_t)win;
+    ecnt[i] = (uint8_t)__popc(win);
+}
+
 // Pass 4: edges of row i at edges[eoff[i]...], edge 1 before edge 2.
 __global__ __launch_bounds__(256) void k_layout_emit(const Row* __restrict__ rows, uint32_t n_rows,
                                                      const uint32_t* __restrict__ len,

@@ -194,3 +194,32 @@ def test_layout_from_daligner_dumps(case, tmp_path):
     assert cli.main(args + ["-o", str(tmp_path / "g1.gfa")]) == 0
     assert cli.main(["layout-edges", "-a", "20", "-r", "0.3", str(p), "-o", str(tmp_path / "g2.gfa")]) == 0
     assert (tmp_path / "g1.gfa").read_bytes() == (tmp_path / "g2.gfa").read_bytes()
+
+
+@pytest.mark.parametrize("name", ["ladder_varlen", "cfg2_1k", "cfg3_1k"])
+def test_layout_without_the_table_equals_layout_with_it(name, monkeypatch):
+    """Rows straight from the paired-strand emission need no dedupe table (the last row of an adjacent
+    (row, strand mirror) group owns its twin edge pair): the table-free pass, the table pass
+    (PHASM_LAYOUT_TABLE=1) and the oracle agree, whole-set, pipelined-to-host and repeat-rich."""
+    _, seqs, m, _ = gu.ladder_case(name)
+    ov = ExactOverlapper()
+    for i in range(len(seqs) // 2):
+        ov.add_sequence("read%d+" % i, seqs[2 * i])
+        ov.add_sequence("read%d-" % i, seqs[2 * i + 1])
+    outs = []
+    for mode in ("fast", "table", "host"):
+        if mode == "table":
+            monkeypatch.setenv("PHASM_LAYOUT_TABLE", "1")
+        else:
+            monkeypatch.delenv("PHASM_LAYOUT_TABLE", raising=False)
+        res = ov.overlaps_to_host_result(m) if mode == "host" else ov.overlaps_result(m)
+        g = layout.build_assembly_graph(ov, res, min_overlap_length=m + 50)
+        rows = res.rows()
+        res.free()
+        outs.append((edge_array(g.edges), g.contained.tolist()))
+    r6 = np.stack([rows[k] for k in rows.dtype.names], 1).astype(np.int64)
+    want = ck.layout_vectorised(r6, ov.lengths(), min_overlap_length=m + 50)
+    ov.close()
+    for e, c in outs:
+        assert np.array_equal(e, want["edges"]) and c == want["contained"].tolist()
+    assert len(want["edges"]) > 100
