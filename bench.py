@@ -163,7 +163,7 @@ def layout_leg(ov: ExactOverlapper, m: int, with_cpu: bool) -> dict:
     out = {"rows_per_sec": st["n_rows"] / dt, "ms_per_call": dt * 1e3, "device_ms": acc / K,
            "n_rows": st["n_rows"], "n_edges": st["n_edges"], "n_contained_reads": st["n_contained_reads"],
            "stage_ms": {k: round(st[k], 4) for k in ("ms_classify", "ms_dedupe", "ms_emit")},
-           "roofline": {"bound": "hbm", "kernel": "k_layout_insert + k_layout_winner (hash table, random access)",
+           "roofline": {"bound": "hbm", "kernel": "k_layout_classify + k_layout_winner_adjacent + k_layout_emit (streaming: rows in, edges out; no dedupe table for rows of the paired-strand emission)",
                         "achieved": algo / (acc / K * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo / (acc / K * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                         "traffic_GBps": traffic / (acc / K * 1e-3) / 1e9 if traffic else None,
