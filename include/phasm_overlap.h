@@ -176,6 +176,24 @@ po_status po_expand(po_handle* h, const void* candidates_device, uint64_t n_cand
 po_status po_candidates_shard_into(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards,
                                    void* dst_device, uint64_t capacity, int* written, po_result** out);
 
+/* Sliced wide index: the part of a multi-GPU step that used to be replicated.  Large read sets (> 160 k reads of
+ * length >= min_length) use the wide index (W K-mers per read, GBs of table at config 5), and every rank used to build
+ * all of it.  Here the table is n_slices sub-tables by key hash; rank g builds sub-table g only (po_index_slice_build),
+ * copies it and its chain segment into its slot of an exchange buffer (po_index_slice_export: chunk layout and size
+ * from po_index_chunk_bytes), the chunks travel in ONE all-gather (phasm_amd/dist.py: IndexExchange), and the shard
+ * call probes the gathered index (po_candidates_shard_indexed) instead of building one.  *is_wide = 0 means this read
+ * set uses the narrow index (0.06 ms to build: not worth exchanging) -- call po_candidates_shard as before.  The
+ * reference has no counterpart (one process: overlapper.cpp:33-36 builds one suffix array). */
+po_status po_index_slice_build(po_handle* h, uint32_t min_length, uint32_t slice, uint32_t n_slices, uint32_t* is_wide,
+                               uint32_t* slice_bits, uint64_t* chain_entries);
+uint64_t po_index_chunk_bytes(uint32_t slice_bits, uint64_t chain_capacity, uint64_t* chain_offset_bytes);
+po_status po_index_slice_export(po_handle* h, void* dst_device, uint64_t chain_capacity);
+po_status po_candidates_shard_indexed(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards,
+                                      const void* index_device, uint32_t n_slices, uint32_t slice_bits, uint64_t chain_capacity,
+                                      void* dst_device, uint64_t capacity, int* written, po_result** out);
+po_status po_overlaps_shard_indexed(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, const void* index_device,
+                                    uint32_t n_slices, uint32_t slice_bits, uint64_t chain_capacity, po_result** out);
+
 /* The read-index range [*r_begin, *r_end) that po_overlaps_shard(shard, nshards) scans on the
  * a-side.  Pure host logic (no GPU needed). */
 po_status po_shard_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint32_t* r_begin, uint32_t* r_end);

@@ -90,6 +90,15 @@ SYMBOLS = [
     ("po_expand", ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(_P)]),
     ("po_candidates_shard_into", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
                                                ctypes.c_uint64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_P)]),
+    ("po_index_slice_build", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32),
+                                            ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)]),
+    ("po_index_chunk_bytes", ctypes.c_uint64, [ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
+    ("po_index_slice_export", ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64]),
+    ("po_candidates_shard_indexed", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32,
+                                                   ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
+                                                   ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_P)]),
+    ("po_overlaps_shard_indexed", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32,
+                                                 ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(_P)]),
     ("po_shard_range", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
     ("po_result_count", ctypes.c_uint64, [_P]),
     ("po_result_rows", ctypes.c_void_p, [_P]),

@@ -126,6 +126,14 @@ struct po_handle {
     uint64_t idx_gen = 0;
     uint32_t idx_m = 0, idx_tbits = 0, idx_bits = 0;
     bool idx_wide = false;
+    // sliced wide index (multi-GPU, phasm_amd/dist.py IndexExchange): sl_build_n > 1 makes run_overlaps stop after it has
+    // built sub-table sl_build_slice; ext_index makes it probe a gathered sliced index instead of building one
+    uint32_t sl_build_slice = 0, sl_build_n = 0;
+    bool sl_is_wide = false;
+    uint32_t sl_tbits = 0;
+    uint64_t sl_entries = 0;
+    const void* ext_index = nullptr;
+    uint32_t ext_slices = 0, ext_tbits = 0, ext_chunk_slots = 0, ext_chain_off = 0;
     bool ex_on = false;
     uint32_t ex_E = 0, ex_W = 0;
     DevBuf d_end_a, d_end_b, d_dpcnt;
@@ -660,9 +668,18 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         if (!strcmp(e, "narrow")) wide = false;
     }
     S.wide_index = wide ? 1u : 0u;
+    bool WA_ext = false;
+    const bool slice_build = h->sl_build_n > 1;     // build one sub-table of the sliced wide index, then stop
+    const bool ext_idx = h->ext_index != nullptr;   // probe a gathered sliced index
+    if (slice_build) {
+        h->sl_is_wide = wide;
+        if (!wide) return PO_OK;                    // (the narrow index is 0.06 ms: every rank builds its own)
+    }
+    if (ext_idx && !wide) return fail(h, PO_ERR_INVALID, "a sliced index was supplied, but this call uses the narrow index");
     bool rows_late = false;  // rows emitted into a kept buffer before their number reached the host
     bool ver_timed = false;  // the verify kernel ran (there were candidates): its own events are valid
-    const uint64_t n_keys = wide ? n_elig * W : n_elig;
+    uint64_t n_keys = wide ? n_elig * W : n_elig;
+    if (slice_build) n_keys = n_keys / h->sl_build_n + n_keys / (16ull * h->sl_build_n) + 4096;  // (a slice's share + slack)
     // ---- sizes
     uint32_t tbits = 10;
     // narrow: 5-10 slots per key, probed in aligned groups of four (kernels.hip.h PROBE_GROUP).  A probe for an
@@ -671,6 +688,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     double table_mult = wide ? 2.0 : 5.0;
     if (const char* e = getenv("PHASM_TABLE_MULT")) table_mult = std::max(wide ? 2.0 : 1.5, atof(e));
     while ((double)(1ull << tbits) < table_mult * (double)n_keys) ++tbits;
+    if (ext_idx) tbits = h->ext_tbits;
     if (tbits > 30) return fail(h, PO_ERR_CAPACITY, "too many reads for the anchor table");
     // (+1: the slot of the all-ones key; narrow: three more so that a group fetch of that slot stays in bounds)
     const uint32_t nslots = (1u << tbits) + (wide ? 1u : po::PROBE_GROUP);
@@ -679,16 +697,20 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     const size_t bloom_bytes = (size_t)1 << (bloom_log2 - 3);
 
     PO_TRY(ensure(h, h->d_scalars, 64));
-    PO_TRY(ensure(h, h->d_table, (size_t)nslots * sizeof(po::Slot)));
-    PO_TRY(ensure(h, h->d_slot_cnt, (size_t)nslots * 4));
-    PO_TRY(ensure(h, h->d_slot_cur, (size_t)nslots * 4));
-    PO_TRY(ensure(h, h->d_slot_start, ((size_t)nslots + 1) * 4));
     const size_t n_entries = wide ? (size_t)n * W : (size_t)n;     // index entries (slots of read_slot / chain)
     const size_t chain_elem = wide ? 8 : 4;
-    PO_TRY(ensure(h, h->d_read_slot, n_entries * 4));
-    PO_TRY(ensure(h, h->d_chain, n_entries * chain_elem));
-    PO_TRY(ensure(h, h->d_chain_tmp, n_entries * chain_elem));
-    PO_TRY(ensure(h, h->d_long_list, (size_t)nslots * 4));
+    if (!ext_idx) {   // (a supplied index needs none of the build's workspaces)
+        PO_TRY(ensure(h, h->d_table, (size_t)nslots * sizeof(po::Slot)));
+        PO_TRY(ensure(h, h->d_slot_cnt, (size_t)nslots * 4));
+        PO_TRY(ensure(h, h->d_slot_cur, (size_t)nslots * 4));
+        PO_TRY(ensure(h, h->d_slot_start, ((size_t)nslots + 1) * 4));
+        PO_TRY(ensure(h, h->d_read_slot, n_entries * 4));
+        // a slice's chain holds its share of the entries (+ slack; the exact number comes back from the prefix sum)
+        const size_t chain_entries = slice_build ? n_entries / h->sl_build_n + n_entries / (4ull * h->sl_build_n) + 65536 : n_entries;
+        PO_TRY(ensure(h, h->d_chain, std::min(chain_entries, n_entries) * chain_elem));
+        PO_TRY(ensure(h, h->d_chain_tmp, std::min(chain_entries, n_entries) * chain_elem));
+        PO_TRY(ensure(h, h->d_long_list, (size_t)nslots * 4));
+    }
     PO_TRY(ensure(h, h->d_bloom, bloom_bytes));
     PO_TRY(ensure(h, h->d_selfrep, (size_t)n * 4));
     PO_TRY(ensure(h, h->d_tile_count, ((size_t)h->n_tiles + 1) * 4));
@@ -724,11 +746,12 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     // reads already (same upload, min_length, flavour, size): the chunks of po_overlaps_to_host and the shards of a
     // multi-GPU step then share one build instead of repeating it (the replicated part of a sharded step).
     HIP_TRY(h, hipEventRecord(h->ev[EV_START], st));
-    const bool reuse_index = h->idx_valid && h->idx_gen == h->upload_gen && h->idx_m == m && h->idx_wide == wide &&
-                             h->idx_tbits == tbits && h->idx_bits == (uint32_t)BITS && h->poison < 0 && !getenv("PHASM_NO_INDEX_REUSE");
+    const bool reuse_index = !slice_build && !ext_idx && h->idx_valid && h->idx_gen == h->upload_gen && h->idx_m == m &&
+                             h->idx_wide == wide && h->idx_tbits == tbits && h->idx_bits == (uint32_t)BITS && h->poison < 0 &&
+                             !getenv("PHASM_NO_INDEX_REUSE");
     S.index_reused = reuse_index ? 1u : 0u;
     h->idx_valid = false;
-    if (reuse_index) {
+    if (reuse_index || ext_idx) {
         hipLaunchKernelGGL(po::k_call_reset, dim3(cdiv(std::max(n, 8u), 256)), dim3(256), 0, st, selfrep, n, scalars);
     } else {
         const uint32_t bloom_words = (uint32_t)(bloom_bytes / 4);
@@ -736,7 +759,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         hipLaunchKernelGGL(po::k_call_init, dim3(cdiv(init_n, 256)), dim3(256), 0, st, table, nslots, slot_cnt, slot_cur, selfrep, n,
                            bloom, bloom_words, scalars);
     }
-    if (reuse_index) {
+    if (reuse_index || ext_idx) {
         // (nothing to build)
     } else if (!wide) {
         hipLaunchKernelGGL(po::k_table_insert, dim3(cdiv(n, 256)), dim3(256), 0, st, words, woff, len, n, m, kmask, table,
@@ -750,10 +773,17 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         hipLaunchKernelGGL(po::k_table_finalize, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt,
                            slot_start, chain, len);
     } else {
-        uint64_t* chain64 = h->d_chain.as<uint64_t>();
         hipLaunchKernelGGL(po::k_wide_insert<BITS>, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, words, woff, len, n, m,
-                           table, tbits, slot_cnt, read_slot);
+                           table, tbits, slot_cnt, read_slot, slice_build ? h->sl_build_n : 1u, h->sl_build_slice);
         PO_TRY(prefix_sum<uint32_t>(h, slot_cnt, nslots, slot_start, &h->pinned[0]));
+        if (slice_build) {
+            // a sub-table's chain segment was sized for its expected share: learn the real number before anything is
+            // written (repetitive reads put all their entries into one sub-table)
+            HIP_TRY(h, hipStreamSynchronize(st));
+            PO_TRY(ensure(h, h->d_chain, (size_t)h->pinned[0] * chain_elem));
+            PO_TRY(ensure(h, h->d_chain_tmp, (size_t)h->pinned[0] * chain_elem));
+        }
+        uint64_t* chain64 = h->d_chain.as<uint64_t>();
         hipLaunchKernelGGL(po::k_wide_chain_fill<BITS>, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, read_slot,
                            (uint64_t)n_entries, slot_start, slot_cur, chain64);
         hipLaunchKernelGGL(po::k_chain_sort_short<uint64_t>, dim3(cdiv(nslots, 256)), dim3(256), 0, st, slot_cnt, slot_start,
@@ -769,7 +799,18 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     // shards -- and settle duplicates inside each read's own candidate list instead (k_select_local, below).
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev[EV_INDEX], st));
-    h->idx_valid = true;
+    if (slice_build) {
+        // the sub-table and its chain segment are complete in the workspaces: po_index_slice_export copies them out
+        HIP_TRY(h, hipStreamSynchronize(st));
+        h->sl_tbits = tbits;
+        h->sl_entries = h->pinned[0];   // (the prefix sum's total = chain entries of this sub-table)
+        (void)hipEventElapsedTime(&S.ms_index, h->ev[EV_START], h->ev[EV_INDEX]);
+        return PO_OK;
+    }
+    if (ext_idx) {
+        WA_ext = true;
+    }
+    h->idx_valid = !ext_idx;
     h->idx_gen = h->upload_gen;
     h->idx_m = m;
     h->idx_wide = wide;
@@ -813,6 +854,14 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     WA.table = table;
     WA.tbits = tbits;
     WA.chain = h->d_chain.as<uint64_t>();
+    WA.n_slices = 1;
+    if (WA_ext) {   // the gathered sliced index: N chunks of [sub-table | chain segment]
+        WA.table = static_cast<const po::Slot*>(h->ext_index);
+        WA.chain = nullptr;
+        WA.n_slices = h->ext_slices;
+        WA.chunk_slots = h->ext_chunk_slots;
+        WA.chain_off_slots = h->ext_chain_off;
+    }
     WA.len = len;
     WA.paired = paired;
     WA.tile_count = A.tile_count;
@@ -2043,6 +2092,88 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
     ++h->live_results;
     *out = r;
     return PO_OK;
+}
+
+// ---- sliced wide index for multi-GPU steps (phasm_amd/dist.py: IndexExchange) ------------------------------------
+po_status po_index_slice_build(po_handle* h, uint32_t min_length, uint32_t slice, uint32_t n_slices, uint32_t* is_wide,
+                               uint32_t* slice_bits, uint64_t* chain_entries) {
+    if (!h || !is_wide || !slice_bits || !chain_entries) return PO_ERR_INVALID;
+    if (n_slices < 2 || slice >= n_slices) return fail(h, PO_ERR_INVALID, "po_index_slice_build: need 2 or more slices and slice < n_slices");
+    *is_wide = 0;
+    *slice_bits = 0;
+    *chain_entries = 0;
+    h->sl_build_slice = slice;
+    h->sl_build_n = n_slices;
+    h->sl_is_wide = false;
+    po_result* r = nullptr;
+    const po_status st = overlaps_common(h, min_length, 0, 1, false, &r);
+    h->sl_build_n = 0;
+    if (r) po_result_free(r);
+    if (st != PO_OK) return st;
+    *is_wide = h->sl_is_wide ? 1u : 0u;
+    if (h->sl_is_wide) {
+        *slice_bits = h->sl_tbits;
+        *chain_entries = h->sl_entries;
+    }
+    return PO_OK;
+}
+
+uint64_t po_index_chunk_bytes(uint32_t slice_bits, uint64_t chain_capacity, uint64_t* chain_offset_bytes) {
+    // [2^bits + 1 slots of 16 bytes | padding to 256 | chain_capacity entries of 8 bytes | padding to 256]
+    const uint64_t off = ((((1ull << slice_bits) + 1ull) * sizeof(po::Slot)) + 255ull) & ~255ull;
+    if (chain_offset_bytes) *chain_offset_bytes = off;
+    return (off + chain_capacity * 8ull + 255ull) & ~255ull;
+}
+
+po_status po_index_slice_export(po_handle* h, void* dst_device, uint64_t chain_capacity) {
+    if (!h || !dst_device) return PO_ERR_INVALID;
+    if (!h->sl_is_wide || !h->dev_ready) return fail(h, PO_ERR_INVALID, "po_index_slice_export: no sub-table has been built on this handle");
+    if (chain_capacity < h->sl_entries) return fail(h, PO_ERR_INVALID, "po_index_slice_export: chain capacity below this sub-table's entries");
+    uint64_t off = 0;
+    (void)po_index_chunk_bytes(h->sl_tbits, chain_capacity, &off);
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(dst_device, h->d_table.p, ((size_t)(1ull << h->sl_tbits) + 1) * sizeof(po::Slot), hipMemcpyDeviceToDevice, h->stream));
+    if (h->sl_entries)
+        HIP_TRY(h, hipMemcpyAsync(static_cast<char*>(dst_device) + off, h->d_chain.p, (size_t)h->sl_entries * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PO_OK;
+}
+
+po_status po_candidates_shard_indexed(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards,
+                                      const void* index_device, uint32_t n_slices, uint32_t slice_bits, uint64_t chain_capacity,
+                                      void* dst_device, uint64_t capacity, int* written, po_result** out) {
+    if (written) *written = 0;
+    if (!h || !out || !index_device || n_slices < 2) return PO_ERR_INVALID;
+    if (!dst_device && capacity) return PO_ERR_INVALID;
+    uint64_t off = 0;
+    const uint64_t chunk = po_index_chunk_bytes(slice_bits, chain_capacity, &off);
+    if ((chunk / 16) * n_slices >= 0xFFFFFFF0ull) return fail(h, PO_ERR_CAPACITY, "sliced index larger than 64 GB");
+    h->ext_index = index_device;
+    h->ext_slices = n_slices;
+    h->ext_tbits = slice_bits;
+    h->ext_chunk_slots = (uint32_t)(chunk / 16);
+    h->ext_chain_off = (uint32_t)(off / 16);
+    const po_status st = overlaps_common(h, min_length, shard, nshards, true, out, dst_device, capacity);
+    h->ext_index = nullptr;
+    if (st == PO_OK && written) *written = (*out)->wrote_ext ? 1 : 0;
+    return st;
+}
+
+// (test hook: the row form of the same call)
+po_status po_overlaps_shard_indexed(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, const void* index_device,
+                                    uint32_t n_slices, uint32_t slice_bits, uint64_t chain_capacity, po_result** out) {
+    if (!h || !out || !index_device || n_slices < 2) return PO_ERR_INVALID;
+    uint64_t off = 0;
+    const uint64_t chunk = po_index_chunk_bytes(slice_bits, chain_capacity, &off);
+    if ((chunk / 16) * n_slices >= 0xFFFFFFF0ull) return fail(h, PO_ERR_CAPACITY, "sliced index larger than 64 GB");
+    h->ext_index = index_device;
+    h->ext_slices = n_slices;
+    h->ext_tbits = slice_bits;
+    h->ext_chunk_slots = (uint32_t)(chunk / 16);
+    h->ext_chain_off = (uint32_t)(off / 16);
+    const po_status st = overlaps_common(h, min_length, shard, nshards, false, out);
+    h->ext_index = nullptr;
+    return st;
 }
 
 po_status po_overlaps_ex(po_handle* h, uint32_t min_length, uint32_t max_diff, uint32_t band, po_result** out) {

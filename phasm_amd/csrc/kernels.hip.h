@@ -417,10 +417,18 @@ __global__ void k_chain_sort_long(const uint32_t* __restrict__ slot_cnt, const u
 // chains are embedded: start = b, count = SLOT_SINGLE | j << 26 | len[b]  (len < 2^26).
 constexpr uint32_t WIDE_LEN_BITS = 26;
 
+// Sliced wide index (multi-GPU): the table is N sub-tables, a key lives in sub-table wide_slice(key); rank g builds
+// sub-table g only and the sub-tables travel in one all-gather (phasm_amd/dist.py: IndexExchange).  The all-ones key
+// (the CAS sentinel, kept in an extra slot) belongs to sub-table 0.
+__device__ inline uint32_t wide_slice(uint64_t key, uint32_t h2, uint32_t n_slices) {
+    return key == KEY_EMPTY ? 0u : __umulhi(h2, n_slices);
+}
+
 template <int BITS>
 __global__ void k_wide_insert(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
                               const uint32_t* __restrict__ len, uint32_t n_reads, uint32_t m, Slot* tab,
-                              uint32_t tbits, uint32_t* slot_cnt, uint32_t* entry_slot) {
+                              uint32_t tbits, uint32_t* slot_cnt, uint32_t* entry_slot, uint32_t n_slices,
+                              uint32_t my_slice) {
     constexpr uint32_t W = 64 / BITS;
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (uint64_t)n_reads * W) return;
@@ -434,6 +442,10 @@ __global__ void k_wide_insert(const uint64_t* __restrict__ words, const uint64_t
     const uint32_t tmask = (1u << tbits) - 1u;
     uint32_t h1, h2;
     kmer_hash(key, h1, h2);
+    if (n_slices > 1u && wide_slice(key, h2, n_slices) != my_slice) {   // another rank's sub-table
+        entry_slot[e] = 0xFFFFFFFFu;
+        return;
+    }
     uint32_t i;
     if (key == KEY_EMPTY) {
         i = tmask + 1u;
@@ -517,6 +529,9 @@ struct WideArgs {
     const uint64_t* chain;
     const uint32_t* len;
     uint32_t paired;
+    uint32_t n_slices;        // > 1: `table` is a gathered sliced index -- N chunks of chunk_slots 16-byte units, each
+    uint32_t chunk_slots;     //      [2^tbits + 1 slots | padding | chain entries from unit chain_off_slots on]
+    uint32_t chain_off_slots;
     uint32_t* tile_count;
     uint32_t* lane_slot;   // per (tile, lane): slot index + 1 of the word's K-mer, 0 = no candidates
     const uint32_t* tile_off;
@@ -544,18 +559,22 @@ __global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A) {
         if (live) {
             const uint64_t kmer = A.words[rec.wabs + lane];
             const uint32_t tmask = (1u << A.tbits) - 1u;
+            uint32_t h1, h2;
+            kmer_hash(kmer, h1, h2);
+            // (sliced index: the key's sub-table; its slots and its chain segment sit in one chunk)
+            const uint32_t base = A.n_slices > 1u ? wide_slice(kmer, h2, A.n_slices) * A.chunk_slots : 0u;
+            const Slot* __restrict__ tab = A.table + base;
+            const uint64_t* __restrict__ chain = A.n_slices > 1u ? reinterpret_cast<const uint64_t*>(tab + A.chain_off_slots) : A.chain;
             uint32_t i;
             if (kmer == KEY_EMPTY) {
                 i = tmask + 1u;
-                const u32x4 s = *reinterpret_cast<const u32x4*>(&A.table[i]);
+                const u32x4 s = *reinterpret_cast<const u32x4*>(&tab[i]);
                 z = s.z;
                 w = s.w;
             } else {
-                uint32_t h1, h2;
-                kmer_hash(kmer, h1, h2);
                 i = h1 >> (32 - A.tbits);
                 for (;;) {
-                    const u32x4 s = *reinterpret_cast<const u32x4*>(&A.table[i]);
+                    const u32x4 s = *reinterpret_cast<const u32x4*>(&tab[i]);
                     if (s.w == 0) break;
                     if ((((uint64_t)s.y << 32) | s.x) == kmer) {
                         z = s.z;
@@ -566,9 +585,9 @@ __global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A) {
                 }
             }
             if (w) {
-                for_each_candidate_wide<BITS>(A.chain, A.len, A.paired, z, w, a, la, pw, A.m,
+                for_each_candidate_wide<BITS>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
                                               [&](uint32_t, uint32_t, uint32_t) { ++n; });
-                if (n) slot1 = i + 1u;
+                if (n) slot1 = base + i + 1u;
             }
         }
         A.lane_slot[li] = slot1;
@@ -576,17 +595,20 @@ __global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A) {
         if (lane == 0) A.tile_count[t] = tot;
     } else {
         slot1 = A.lane_slot[li];
+        const uint64_t* __restrict__ chain = A.chain;
         if (slot1) {
             const u32x4 s = *reinterpret_cast<const u32x4*>(&A.table[slot1 - 1u]);
             z = s.z;
             w = s.w;
-            for_each_candidate_wide<BITS>(A.chain, A.len, A.paired, z, w, a, la, pw, A.m,
+            if (A.n_slices > 1u)
+                chain = reinterpret_cast<const uint64_t*>(A.table + ((slot1 - 1u) / A.chunk_slots) * A.chunk_slots + A.chain_off_slots);
+            for_each_candidate_wide<BITS>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
                                           [&](uint32_t, uint32_t, uint32_t) { ++n; });
         }
         const uint32_t inc = wave_incl_scan(n);
         uint32_t off = A.tile_off[t] + inc - n;
         if (n) {
-            for_each_candidate_wide<BITS>(A.chain, A.len, A.paired, z, w, a, la, pw, A.m,
+            for_each_candidate_wide<BITS>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
                                           [&](uint32_t b, uint32_t p, uint32_t) {
                                               A.cand_a[off] = a;
                                               A.cand_p[off] = p;

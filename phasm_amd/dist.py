@@ -101,6 +101,69 @@ def expand_candidates(ov, cands: torch.Tensor):
     return res
 
 
+class IndexExchange:
+    """The anchor index of large read sets, built once per node instead of once per rank.
+
+    The wide index (more than 160 k reads of length >= min_length) is GBs of table at BASELINE config 5 and used to
+    be built whole by every rank -- the replicated part of a sharded step (16 of 62 ms there).  Here rank g builds
+    sub-table g of ``world_size`` (keys partitioned by hash, ``po_index_slice_build``), copies it with its chain
+    segment into one chunk (``po_index_slice_export``) and ONE all-gather over RCCL/xGMI hands every rank all chunks;
+    the shard call then probes the gathered index (``po_candidates_shard_indexed``).  Chunk size is agreed with a
+    tiny all-gather of the chain-segment lengths (RCCL has no all-gatherv).  ``get`` caches the gathered index for
+    one ``(min_length, number of reads)``; call ``invalidate`` after adding reads.  Returns None when the read set
+    uses the narrow index (0.06 ms to build: every rank keeps building its own)."""
+
+    def __init__(self, ov, group=None, device: Optional[torch.device] = None):
+        self.ov = ov
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.ws = dist.get_world_size(group) if self.on else 1
+        # the index lives on the GPU whatever carries the collective (gloo rehearsals move the chunks through the host)
+        self.device = device if device is not None and device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+        self.via_host = self.on and dist.get_backend(group) != "nccl"
+        self.key = None
+        self.index = None     # dict(buf=uint8 tensor, n_slices, bits, cap) or None
+        self.n_collectives = 0
+
+    def invalidate(self) -> None:
+        self.key, self.index = None, None
+
+    def get(self, min_length: int):
+        key = (int(min_length), len(self.ov))
+        if key == self.key:
+            return self.index
+        self.key, self.index = key, None
+        if not self.on or self.ws < 2 or not torch.cuda.is_available():
+            return None
+        wire = torch.device("cpu") if self.via_host else self.device
+        wide, bits, entries = self.ov.index_slice_build(min_length, self.rank, self.ws)
+        mine = torch.tensor([entries, bits, 1 if wide else 0], dtype=torch.int64, device=wire)
+        every = torch.empty(3 * self.ws, dtype=torch.int64, device=wire)
+        dist.all_gather_into_tensor(every, mine, group=self.group)
+        self.n_collectives += 1
+        every = every.view(self.ws, 3).cpu()
+        if not bool(every[:, 2].all()):
+            return None        # (same reads on every rank: all wide or none)
+        assert int(every[:, 1].min()) == int(every[:, 1].max()), "ranks disagree on the sub-table size"
+        cap = int(every[:, 0].max())
+        chunk = self.ov.index_chunk_bytes(bits, cap)
+        local = torch.empty(chunk, dtype=torch.uint8, device=self.device)
+        buf = torch.empty(self.ws * chunk, dtype=torch.uint8, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()   # (the library writes on its own stream)
+        self.ov.index_slice_export(local.data_ptr(), cap)
+        if self.via_host:
+            host = torch.empty(self.ws * chunk, dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, local.cpu(), group=self.group)
+            buf.copy_(host)
+        else:
+            dist.all_gather_into_tensor(buf, local, group=self.group)
+        self.n_collectives += 1
+        torch.cuda.current_stream(self.device).synchronize()   # ... and reads the gathered index on its own stream
+        self.index = dict(buf=buf, n_slices=self.ws, bits=bits, cap=cap)
+        return self.index
+
+
 class CandidateExchange:
     """The steady-state form of the N>1 step: shard -> ONE all-gather -> expansion.
 
@@ -124,6 +187,7 @@ class CandidateExchange:
         self.hdr_host = None
         self.filled = 0
         self.n_collectives = 0  # (tests look at this)
+        self.index = IndexExchange(ov, group, self.device) if torch.cuda.is_available() else None   # sliced wide index: built once per node
 
     def _resize(self, need: int) -> None:
         old, old_filled = self.local, self.filled
@@ -146,7 +210,13 @@ class CandidateExchange:
         """All ranks' verified candidates of one step as ``int32[ws * slot, 4]`` (padding and neutralised headers
         are all-zero entries, which ``po_expand`` skips)."""
         written = False
-        if self.on and self.slot and self.device.type == "cuda":
+        idx = self.index.get(min_length) if (self.on and self.index is not None) else None
+        if idx is not None:
+            # large read sets: probe the node-wide sliced index instead of building the whole index on this rank
+            dst, cap = (self.local.data_ptr() + 16, self.slot - 1) if (self.slot and self.device.type == "cuda") else (0, 0)
+            res, written = self.ov.candidates_result_indexed(min_length, self.rank, self.ws, idx["buf"].data_ptr(), idx["n_slices"],
+                                                             idx["bits"], idx["cap"], dst, cap)
+        elif self.on and self.slot and self.device.type == "cuda":
             # steady state: the compaction kernel writes this rank's candidates straight into its slot
             res, written = self.ov.candidates_result_into(min_length, self.rank, self.ws, self.local.data_ptr() + 16,
                                                           self.slot - 1)

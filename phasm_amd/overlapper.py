@@ -213,6 +213,44 @@ class ExactOverlapper:
                                                            int(capacity), ctypes.byref(w), ctypes.byref(r)))
         return OverlapResult(self, r, CAND_DTYPE), bool(w.value)
 
+    # ---- sliced wide index (multi-GPU; phasm_amd/dist.py IndexExchange) -----------------------------------
+    def index_slice_build(self, min_length: int, slice_: int, n_slices: int) -> Tuple[bool, int, int]:
+        """``po_index_slice_build``: build sub-table ``slice_`` of ``n_slices``; (is_wide, slice_bits, chain_entries)."""
+        m = self._min_length(min_length)
+        w, b, e = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()
+        _check(self._h, self._lib.po_index_slice_build(self._h, m, int(slice_), int(n_slices), ctypes.byref(w), ctypes.byref(b), ctypes.byref(e)))
+        return bool(w.value), int(b.value), int(e.value)
+
+    def index_chunk_bytes(self, slice_bits: int, chain_capacity: int) -> int:
+        return int(self._lib.po_index_chunk_bytes(int(slice_bits), int(chain_capacity), None))
+
+    def index_slice_export(self, dst_ptr: int, chain_capacity: int) -> None:
+        _check(self._h, self._lib.po_index_slice_export(self._h, ctypes.c_void_p(dst_ptr), int(chain_capacity)))
+
+    def candidates_result_indexed(self, min_length: int, shard: int, nshards: int, index_ptr: int, n_slices: int, slice_bits: int,
+                                  chain_capacity: int, dst_ptr: int = 0, capacity: int = 0):
+        """``po_candidates_shard_indexed``: the shard call on a gathered sliced index; (result, written)."""
+        m = self._min_length(min_length)
+        r = ctypes.c_void_p()
+        w = ctypes.c_int()
+        _check(self._h, self._lib.po_candidates_shard_indexed(self._h, m, int(shard), int(nshards), ctypes.c_void_p(index_ptr),
+                                                              int(n_slices), int(slice_bits), int(chain_capacity),
+                                                              ctypes.c_void_p(dst_ptr) if dst_ptr else None, int(capacity),
+                                                              ctypes.byref(w), ctypes.byref(r)))
+        return OverlapResult(self, r, CAND_DTYPE), bool(w.value)
+
+    def overlaps_shard_indexed_array(self, min_length: int, shard: int, nshards: int, index_ptr: int, n_slices: int,
+                                     slice_bits: int, chain_capacity: int) -> np.ndarray:
+        m = self._min_length(min_length)
+        r = ctypes.c_void_p()
+        _check(self._h, self._lib.po_overlaps_shard_indexed(self._h, m, int(shard), int(nshards), ctypes.c_void_p(index_ptr),
+                                                            int(n_slices), int(slice_bits), int(chain_capacity), ctypes.byref(r)))
+        res = OverlapResult(self, r)
+        try:
+            return res.rows()
+        finally:
+            res.free()
+
     def expand_result(self, cand_device_ptr: int, n_candidates: int) -> OverlapResult:
         """Rows from a candidate array resident on this handle's device (``po_expand``)."""
         r = ctypes.c_void_p()

@@ -210,3 +210,51 @@ def test_one_hip_runtime_in_the_process():
             if "libamdhip64" in line:
                 paths.add(os.path.realpath(line.split()[-1]))
     assert len(paths) == 1, sorted(paths)
+
+
+_TWO_RANK_CHILD = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import golden_utils as gu
+from oracle import overlap_oracle as oo
+from phasm_amd.dist import CandidateExchange, rows_tensor_to_struct, _result_to_tensor
+from phasm_amd.overlapper import ExactOverlapper
+os.environ["PHASM_INDEX"] = "wide"
+dist.init_process_group("gloo")
+rank, ws = dist.get_rank(), dist.get_world_size()
+try:
+    _, seqs, m, want = gu.ladder_case("cfg3_1k")
+    ov = ExactOverlapper(device=0)
+    for i, s in enumerate(seqs):
+        ov.add_sequence("r%%d" %% i, s)
+    ex = CandidateExchange(ov, device=torch.device("cpu"))          # gloo carries the collectives, one GPU runs both ranks
+    for step in range(2):
+        res = ex.rows(m)
+        rows = oo.sort_rows(oo.struct_to_rows(res.rows()))
+        res.free()
+        assert np.array_equal(rows, want), (rank, step, len(rows), len(want))
+        assert ov.stats()["wide_index"] == 1
+    assert ex.index.index is not None and ex.index.index["n_slices"] == ws      # the sliced index was exchanged ...
+    assert ex.index.n_collectives == 2                                           # ... once: the second step reused it
+    ov.close()
+finally:
+    dist.destroy_process_group()
+print("RANK %%d OK" %% rank)
+"""
+
+
+def test_two_ranks_on_one_gpu_exchange_the_sliced_index(tmp_path):
+    """The N > 1 step end to end with two ranks sharing this GPU (gloo carries the collectives; RCCL refuses two
+    ranks on one device): rank g builds sub-table g of the wide index, the chunks are all-gathered, every rank's
+    shard probes the gathered index, candidates are exchanged and expanded -- both ranks end with the golden rows."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "two_ranks.py"
+    script.write_text(_TWO_RANK_CHILD % {"root": root, "tests": os.path.join(root, "tests")})
+    rc, stdout, stderr = ck.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                                 "--master-addr", "127.0.0.1", "--master-port", "29641", str(script)],
+                                capture_output=True, text=True, timeout=500)
+    assert rc == 0 and "RANK 0 OK" in stdout and "RANK 1 OK" in stdout, stdout[-2000:] + stderr[-3000:]

@@ -657,3 +657,39 @@ def test_rows_to_host_pipelined(chunks, monkeypatch):
         res.free()
         assert len(ov.overlaps(m)) == len(want)
         ov.close()
+
+
+@pytest.mark.parametrize("n_slices", [2, 3, 8])
+def test_sliced_wide_index_equals_the_whole_index(n_slices, monkeypatch):
+    """Multi-GPU index: rank g builds sub-table g (keys partitioned by hash), the chunks are gathered, the shard calls
+    probe the gathered index.  One GPU plays every rank in turn: N sub-tables exported into one buffer (the layout
+    the all-gather produces), then the N shard calls on it -- the union must be the goldens' rows, also for a read
+    set whose repeats crowd one sub-table."""
+    import torch
+    monkeypatch.setenv("PHASM_INDEX", "wide")
+    cases = [gu.ladder_case("cfg3_1k")[1:], gu.ladder_case("ladder_varlen")[1:]] + [c[1:] for c in gu.repeats_cases()[2:]]
+    for seqs, m, want in cases:
+        ov = ExactOverlapper(device=0)
+        for i, s in enumerate(seqs):
+            ov.add_sequence("r%d" % i, s)
+        built = [ov.index_slice_build(m, k, n_slices) for k in range(n_slices)]
+        assert all(w for w, _, _ in built) and len({b for _, b, _ in built}) == 1
+        bits, cap = built[0][1], max(e for _, _, e in built)
+        chunk = ov.index_chunk_bytes(bits, cap)
+        buf = torch.empty(n_slices * chunk, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for k in range(n_slices):
+            w, b, e = ov.index_slice_build(m, k, n_slices)
+            assert (w, b, e) == built[k]
+            ov.index_slice_export(buf.data_ptr() + k * chunk, cap)
+        parts = [ov.overlaps_shard_indexed_array(m, k, n_slices, buf.data_ptr(), n_slices, bits, cap) for k in range(n_slices)]
+        got = oo.sort_rows(oo.struct_to_rows(np.concatenate(parts)))
+        _last.update(seqs=seqs, m=m)
+        same(got, want, "%d slices" % n_slices)
+        # the candidate form (what travels between the GPUs) on the same index, expanded
+        res, written = ov.candidates_result_indexed(m, 0, n_slices, buf.data_ptr(), n_slices, bits, cap)
+        assert not written and ov.stats()["wide_index"] == 1
+        res.free()
+        # and the ordinary call afterwards builds its own whole index again
+        same(oo.sort_rows(oo.struct_to_rows(ov.overlaps_result(m).rows())), want, "whole index after the slices")
+        ov.close()
