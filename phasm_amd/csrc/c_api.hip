@@ -687,6 +687,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     // key (7 % at 2.6), and those positions go to the leftover list; 8 MB at config 2
     double table_mult = wide ? 2.0 : 5.0;
     if (const char* e = getenv("PHASM_TABLE_MULT")) table_mult = std::max(wide ? 2.0 : 1.5, atof(e));
+    if (slice_build) table_mult = 1.5;   // (a sub-table travels over xGMI: the smallest power of two that keeps the load <= 2/3)
     while ((double)(1ull << tbits) < table_mult * (double)n_keys) ++tbits;
     if (ext_idx) tbits = h->ext_tbits;
     if (tbits > 30) return fail(h, PO_ERR_CAPACITY, "too many reads for the anchor table");
