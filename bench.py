@@ -273,8 +273,14 @@ def main() -> int:
         if inclusive:
             # ... and ends in host memory: the row array device -> host (po_result_rows; a view, no second copy)
             t_a = time.perf_counter()
-            rows = res.rows_view()
-            assert len(rows) == n
+            if world == 1:
+                rows = res.rows_view()
+                assert len(rows) == n
+            else:
+                # every rank holds the merged rows on its GPU; the ranks of the node bring them home once between them
+                lo, hi = n * rank // world, n * (rank + 1) // world
+                rows = res.rows_range_view(lo, hi - lo)
+                assert len(rows) == hi - lo
             del rows
             if timed:
                 pcie["d2h_s"] += time.perf_counter() - t_a
@@ -351,7 +357,7 @@ def main() -> int:
                                       cfg.snp, cfg.seed, n_oriented, m),
                        "n_reads": cfg.n_reads, "read_len": cfg.read_len, "min_length": m,
                        "timed_region": "host to host per step: po_invalidate + po_upload (H2D of the packed reads) + po_overlaps_to_host (kernels, D2H of the rows pipelined chunk by chunk) + po_result_rows",
-                       "parallelism": "a-side read shards x%d + one RCCL all-gather of verified candidates (16 B, fixed slots) per step + local row expansion" % world if world > 1
+                       "parallelism": "every rank uploads the packed reads; a-side read shards x%d + one RCCL all-gather of verified candidates (16 B, fixed slots) per step + local row expansion on every rank; each rank copies 1/%d of the merged rows to its host" % (world, world) if world > 1
                                       else "single GPU"},
             "rows_per_step": int(n_rows),
             "read_pairs_per_sec": n_oriented * (n_oriented - 1) / (dt / K),

@@ -203,6 +203,9 @@ uint64_t po_result_count(const po_result* r);
  * library: one DMA, valid until po_result_free); NULL on error.  The counterpart of the reference returning its
  * vector<OverlapT> to the host (src/overlapper.cpp:149). */
 const po_row* po_result_rows(po_result* r);
+/* Host pointer to rows [first, first + count) only (one rank's share of a merged multi-GPU result: the ranks of a node
+ * bring the rows home once between them).  Valid until the next call on the handle; NULL on error or count == 0. */
+const po_row* po_result_rows_range(po_result* r, uint64_t first, uint64_t count);
 /* Device pointer to the same rows (valid until po_result_free). */
 const void* po_result_device_rows(const po_result* r);
 /* Copy the rows device->device into dst (>= count*sizeof(po_row) bytes), e.g. a torch tensor. */

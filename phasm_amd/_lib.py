@@ -102,6 +102,7 @@ SYMBOLS = [
     ("po_shard_range", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
     ("po_result_count", ctypes.c_uint64, [_P]),
     ("po_result_rows", ctypes.c_void_p, [_P]),
+    ("po_result_rows_range", ctypes.c_void_p, [_P, ctypes.c_uint64, ctypes.c_uint64]),
     ("po_result_device_rows", ctypes.c_void_p, [_P]),
     ("po_result_copy_to_device", ctypes.c_int, [_P, ctypes.c_void_p]),
     ("po_result_copy_prefix_to_device", ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64]),

@@ -2232,6 +2232,27 @@ const po_row* po_result_rows(po_result* r) {
     return static_cast<const po_row*>(r->host);
 }
 
+// Rows [first, first + count) only: what ONE rank of a multi-GPU job brings home -- every rank holds the merged rows
+// on its device, the ranks' hosts (one node) together receive them once.
+const po_row* po_result_rows_range(po_result* r, uint64_t first, uint64_t count) {
+    if (!r || first > r->count || count > r->count - first) return nullptr;
+    if (count == 0) return nullptr;
+    if (r->host) return reinterpret_cast<const po_row*>(static_cast<const char*>(r->host) + first * r->elem);
+    po_handle* h = r->h;
+    const char* src = static_cast<const char*>(r->wrote_ext ? r->ext_dst : r->d_rows.p);
+    if (!src || hipSetDevice(h->device) != hipSuccess) return nullptr;
+    const size_t bytes = count * r->elem;
+    if (ensure_host(h, h->scratch_host, bytes) != PO_OK) return nullptr;
+    hipError_t e = hipMemcpyAsync(h->scratch_host.p, src + first * r->elem, bytes, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(h->stream);
+        fail(h, PO_ERR_HIP, std::string("row copy device->host: ") + hipGetErrorString(e));
+        return nullptr;
+    }
+    return static_cast<const po_row*>(h->scratch_host.p);   // (valid until the next call that uses the handle's scratch)
+}
+
 const void* po_result_device_rows(const po_result* r) { return r ? (r->wrote_ext ? r->ext_dst : r->d_rows.p) : nullptr; }
 
 po_status po_result_copy_to_device(po_result* r, void* dst_device) {

@@ -89,6 +89,19 @@ class OverlapResult:
         v.flags.writeable = False
         return v
 
+    def rows_range_view(self, first: int, count: int) -> np.ndarray:
+        """``po_result_rows_range``: rows [first, first + count) in page-locked host memory (a view, valid until the
+        next call on the overlapper) -- one rank's share of a merged multi-GPU result."""
+        if count <= 0:
+            return np.empty(0, dtype=self._dtype)
+        p = self._lib.po_result_rows_range(self._ptr, int(first), int(count))
+        if not p:
+            _check(self._owner._h, _lib.PO_ERR_HIP)
+        buf = (ctypes.c_char * (count * self._dtype.itemsize)).from_address(p)
+        v = np.frombuffer(buf, dtype=self._dtype)
+        v.flags.writeable = False
+        return v
+
     def write_gfa_edges(self, fileobj) -> int:
         """Native bulk writer of the GFA2 ``E`` lines (``po_write_gfa_edges``) to a real file."""
         fileobj.flush()

@@ -693,3 +693,21 @@ def test_sliced_wide_index_equals_the_whole_index(n_slices, monkeypatch):
         # and the ordinary call afterwards builds its own whole index again
         same(oo.sort_rows(oo.struct_to_rows(ov.overlaps_result(m).rows())), want, "whole index after the slices")
         ov.close()
+
+
+def test_row_ranges_of_a_result():
+    _, seqs, m, want = gu.ladder_case("cfg2_1k")
+    ov = ExactOverlapper()
+    for i, s in enumerate(seqs):
+        ov.add_sequence("r%d" % i, s)
+    for res in (ov.overlaps_result(m), ov.overlaps_to_host_result(m)):
+        n = len(res)
+        whole = res.rows()
+        cuts = [0, 1, n // 3, n // 2, n - 1, n]
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            assert np.array_equal(res.rows_range_view(lo, hi - lo), whole[lo:hi])
+        assert len(res.rows_range_view(n, 0)) == 0
+        with pytest.raises(RuntimeError):
+            res.rows_range_view(n - 1, 2)
+        res.free()
+    ov.close()
