@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from phasm_amd import synth  # noqa: E402
-from phasm_amd.dist import CandidateExchange, expand_candidates  # noqa: E402
+from phasm_amd.dist import CandidateExchange, ReadExchange, expand_candidates  # noqa: E402
 from phasm_amd.overlapper import ExactOverlapper  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
@@ -247,6 +247,7 @@ def main() -> int:
     m = args.min_length
 
     exchange = CandidateExchange(ov, device=merge_device) if (world > 1 or args.dist_path) else None
+    read_exchange = ReadExchange(ov, device=device) if world > 1 else None
     stage_keys = ["ms_index", "ms_scan_count", "ms_scan_fill", "ms_verify", "ms_select", "ms_emit", "ms_total", "ms_scan_probe", "ms_verify_kernel"]
     acc = {k: 0.0 for k in stage_keys}
     last = {}
@@ -258,7 +259,10 @@ def main() -> int:
             # the call starts from host memory: packed reads host -> device (po_invalidate + po_upload)
             t_a = time.perf_counter()
             ov.invalidate()
-            ov.upload()
+            if read_exchange is not None:
+                read_exchange.upload()    # N > 1: 1/N of the packed reads over this rank's PCIe link, the rest over xGMI
+            else:
+                ov.upload()
             if timed:
                 pcie["h2d_s"] += time.perf_counter() - t_a
         if world == 1 and not args.dist_path:
@@ -357,7 +361,7 @@ def main() -> int:
                                       cfg.snp, cfg.seed, n_oriented, m),
                        "n_reads": cfg.n_reads, "read_len": cfg.read_len, "min_length": m,
                        "timed_region": "host to host per step: po_invalidate + po_upload (H2D of the packed reads) + po_overlaps_to_host (kernels, D2H of the rows pipelined chunk by chunk) + po_result_rows",
-                       "parallelism": "every rank uploads the packed reads; a-side read shards x%d + one RCCL all-gather of verified candidates (16 B, fixed slots) per step + local row expansion on every rank; each rank copies 1/%d of the merged rows to its host" % (world, world) if world > 1
+                       "parallelism": "each rank uploads 1/N of the packed reads, one RCCL all-gather over xGMI completes every rank's copy; a-side read shards x%d + one RCCL all-gather of verified candidates (16 B, fixed slots) per step + local row expansion on every rank; each rank copies 1/%d of the merged rows to its host" % (world, world) if world > 1
                                       else "single GPU"},
             "rows_per_step": int(n_rows),
             "read_pairs_per_sec": n_oriented * (n_oriented - 1) / (dt / K),

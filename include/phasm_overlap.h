@@ -121,6 +121,16 @@ uint32_t po_get_length(const po_handle* h, uint32_t idx);
  * po_overlaps* call.  Idempotent until the next po_add_sequence.                          */
 po_status po_upload(po_handle* h);
 
+/* Sharded upload for multi-GPU jobs.  Every rank needs the whole read set in its HBM (any read can be a `b`), but not
+ * over its own PCIe link: rank g copies only the words of shard g's even reads host->device, into its slot of an
+ * exchange buffer (po_upload_piece; dst_device == NULL just asks for the piece's length), one all-gather over xGMI hands
+ * every rank all pieces (phasm_amd/dist.py: ReadExchange), and po_upload_assemble puts them in place and finishes the
+ * upload (odd reads rebuilt on the device, tiles, tables).  *ok = 0: the reads are not (x, reverse complement of x)
+ * pairs -- use po_upload.  The reference has no counterpart (one process, reads already in host memory). */
+po_status po_upload_piece(po_handle* h, uint32_t shard, uint32_t nshards, void* dst_device, uint64_t capacity_words,
+                          uint64_t* word_count, int* ok);
+po_status po_upload_assemble(po_handle* h, const void* pieces_device, uint64_t slot_words, uint32_t nshards);
+
 /* Forget the device copy of the read set: the next po_upload / po_overlaps* copies the packed reads host->device
  * again, as the first call of a fresh process does.  The reference's overlaps() starts from the host-side string
  * set on every call (index built from `readset`, src/overlapper.cpp:33-36), so ONE reference call corresponds to

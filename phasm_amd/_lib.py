@@ -82,6 +82,9 @@ SYMBOLS = [
     ("po_get_length", ctypes.c_uint32, [_P, ctypes.c_uint32]),
     ("po_upload", ctypes.c_int, [_P]),
     ("po_invalidate", ctypes.c_int, [_P]),
+    ("po_upload_piece", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
+                                       ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]),
+    ("po_upload_assemble", ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32]),
     ("po_overlaps", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_overlaps_to_host", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_overlaps_ex", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),

@@ -134,6 +134,10 @@ struct po_handle {
     uint64_t sl_entries = 0;
     const void* ext_index = nullptr;
     uint32_t ext_slices = 0, ext_tbits = 0, ext_chunk_slots = 0, ext_chain_off = 0;
+    // sharded upload (multi-GPU): store 0 arrives as nshards pieces that other ranks uploaded and xGMI carried here
+    const uint64_t* asm_pieces = nullptr;
+    uint64_t asm_slot_words = 0;
+    uint32_t asm_n = 0;
     bool ex_on = false;
     uint32_t ex_E = 0, ex_W = 0;
     DevBuf d_end_a, d_end_b, d_dpcnt;
@@ -452,6 +456,20 @@ bool packed_is_revcomp(const po_handle* h, size_t r) {
 
 inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
+void shard_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint32_t* r_begin, uint32_t* r_end, uint64_t* bases);
+
+// words of host store 0 (the even reads) that belong to shard `shard` of `nshards`: [*begin, *begin + *count)
+void store0_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint64_t* begin, uint64_t* count) {
+    uint32_t rb = 0, re = 0;
+    shard_range(h, shard, nshards, &rb, &re, nullptr);
+    const uint32_t n = (uint32_t)h->len.size();
+    const uint32_t e0 = (rb + 1u) & ~1u, e1 = (re + 1u) & ~1u;   // first even read of this shard / of the next one
+    const uint64_t w0 = e0 < n ? h->woff[e0] : h->words[0].size();
+    const uint64_t w1 = e1 < n ? h->woff[e1] : h->words[0].size();
+    *begin = w0;
+    *count = w1 > w0 ? w1 - w0 : 0;
+}
+
 po_status upload(po_handle* h) {
     PO_TRY(init_device(h));
     if (!h->dirty) return PO_OK;
@@ -494,7 +512,16 @@ po_status upload(po_handle* h) {
     HIP_TRY(h, hipMemsetAsync(dw + base1 + h->words[1].size(), 0, 72 * 8, h->stream));
     if (base1 != h->words[0].size()) HIP_TRY(h, hipMemsetAsync(dw + h->words[0].size(), 0, 8, h->stream));
     h->upload_bytes = 0;
-    if (!h->words[0].empty()) {
+    if (h->asm_pieces) {
+        // sharded upload: piece k = the store-0 words of shard k's reads, uploaded by rank k, gathered over xGMI
+        if (!generate) return fail(h, PO_ERR_INVALID, "po_upload_assemble needs reads added as (x, reverse complement of x) pairs");
+        for (uint32_t k = 0; k < h->asm_n; ++k) {
+            uint64_t wb = 0, wc = 0;
+            store0_range(h, k, h->asm_n, &wb, &wc);
+            if (wc > h->asm_slot_words) return fail(h, PO_ERR_INVALID, "po_upload_assemble: a piece is longer than the slot");
+            if (wc) HIP_TRY(h, hipMemcpyAsync(dw + wb, h->asm_pieces + (size_t)k * h->asm_slot_words, wc * 8, hipMemcpyDeviceToDevice, h->stream));
+        }
+    } else if (!h->words[0].empty()) {
         HIP_TRY(h, hipMemcpyAsync(dw, h->words[0].data(), h->words[0].size() * 8, hipMemcpyHostToDevice, h->stream));
         h->upload_bytes += h->words[0].size() * 8;
     }
@@ -1887,6 +1914,55 @@ po_status po_upload(po_handle* h) {
     }
     // (a failed upload may have copies from the host store in flight: nothing returns before they are done)
     if (st != PO_OK && h->dev_ready) (void)hipStreamSynchronize(h->stream);
+    return st;
+}
+
+// ---- sharded upload (multi-GPU): each rank brings 1/N of the packed reads over ITS PCIe link, xGMI does the rest ----
+po_status po_upload_piece(po_handle* h, uint32_t shard, uint32_t nshards, void* dst_device, uint64_t capacity_words,
+                          uint64_t* word_count, int* ok) {
+    if (!h || !word_count || !ok || nshards == 0 || shard >= nshards) return PO_ERR_INVALID;
+    *ok = 0;
+    *word_count = 0;
+    const uint32_t n = (uint32_t)h->len.size();
+    // only when store 1 can be rebuilt on the device (every odd read the reverse complement of its even partner)
+    if (!(h->bits == 2 && n >= 2 && (n % 2) == 0 && h->all_pairs_rc && h->exc_pos.empty()) || h->segments_only) return PO_OK;
+    PO_TRY(init_device(h));
+    uint64_t wb = 0, wc = 0;
+    try {
+        store0_range(h, shard, nshards, &wb, &wc);
+    } catch (const std::bad_alloc&) {
+        return fail(h, PO_ERR_NOMEM, "out of host memory");
+    }
+    *word_count = wc;
+    *ok = 1;
+    if (!dst_device) return PO_OK;   // (a query: how many words is this shard's piece?)
+    if (wc > capacity_words) return fail(h, PO_ERR_INVALID, "po_upload_piece: the piece does not fit the destination");
+    pin_words(h, 0);
+    if (wc) HIP_TRY(h, hipMemcpyAsync(dst_device, h->words[0].data() + wb, wc * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->upload_bytes = wc * 8;
+    return PO_OK;
+}
+
+po_status po_upload_assemble(po_handle* h, const void* pieces_device, uint64_t slot_words, uint32_t nshards) {
+    if (!h || !pieces_device || nshards == 0) return PO_ERR_INVALID;
+    h->asm_pieces = static_cast<const uint64_t*>(pieces_device);
+    h->asm_slot_words = slot_words;
+    h->asm_n = nshards;
+    h->dirty = true;
+    const uint64_t piece_bytes = h->upload_bytes;
+    po_status st;
+    try {
+        st = upload(h);
+    } catch (const std::bad_alloc&) {
+        st = fail(h, PO_ERR_NOMEM, "out of host memory in po_upload_assemble");
+    }
+    h->asm_pieces = nullptr;
+    if (st != PO_OK && h->dev_ready) (void)hipStreamSynchronize(h->stream);
+    if (st == PO_OK) {
+        h->upload_bytes += piece_bytes;   // (what THIS rank moved over PCIe: its piece + the per-read tables)
+        h->stats.upload_bytes = h->upload_bytes;
+    }
     return st;
 }
 

@@ -293,6 +293,16 @@ class ExactOverlapper:
     def upload(self) -> None:
         _check(self._h, self._lib.po_upload(self._h))
 
+    def upload_piece(self, shard: int, nshards: int, dst_ptr: int = 0, capacity_words: int = 0) -> Tuple[bool, int]:
+        """``po_upload_piece``: (ok, words of the piece); with ``dst_ptr`` the piece is copied host->device there."""
+        n, ok = ctypes.c_uint64(), ctypes.c_int()
+        _check(self._h, self._lib.po_upload_piece(self._h, int(shard), int(nshards), ctypes.c_void_p(dst_ptr) if dst_ptr else None,
+                                                  int(capacity_words), ctypes.byref(n), ctypes.byref(ok)))
+        return bool(ok.value), int(n.value)
+
+    def upload_assemble(self, pieces_ptr: int, slot_words: int, nshards: int) -> None:
+        _check(self._h, self._lib.po_upload_assemble(self._h, ctypes.c_void_p(pieces_ptr), int(slot_words), int(nshards)))
+
     def invalidate(self) -> None:
         """``po_invalidate``: the next upload / overlaps call copies the packed reads to the device again."""
         _check(self._h, self._lib.po_invalidate(self._h))

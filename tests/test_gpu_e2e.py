@@ -230,6 +230,9 @@ try:
     ov = ExactOverlapper(device=0)
     for i, s in enumerate(seqs):
         ov.add_sequence("r%%d" %% i, s)
+    from phasm_amd.dist import ReadExchange
+    rx = ReadExchange(ov)
+    assert rx.upload() is True and rx.n_collectives == 1            # each rank uploaded its half, the other half came over the wire
     ex = CandidateExchange(ov, device=torch.device("cpu"))          # gloo carries the collectives, one GPU runs both ranks
     for step in range(2):
         res = ex.rows(m)

@@ -711,3 +711,36 @@ def test_row_ranges_of_a_result():
             res.rows_range_view(n - 1, 2)
         res.free()
     ov.close()
+
+
+@pytest.mark.parametrize("nshards", [2, 3, 8])
+def test_sharded_upload_pieces_assemble_to_the_same_read_set(nshards, monkeypatch):
+    """Multi-GPU upload: rank g uploads the words of shard g's even reads, the pieces are gathered, po_upload_assemble
+    puts them in place and rebuilds the odd reads.  One GPU plays every rank; PHASM_VERIFY_GENERATED compares the
+    rebuilt odd store with the host's word by word (a misplaced piece cannot pass), and the rows are the goldens'."""
+    import torch
+    monkeypatch.setenv("PHASM_VERIFY_GENERATED", "1")
+    for name in ("ladder_varlen", "cfg2_1k"):
+        _, seqs, m, want = gu.ladder_case(name)
+        ov = ExactOverlapper(device=0)
+        for i, s in enumerate(seqs):
+            ov.add_sequence("r%d" % i, s)
+        sizes = [ov.upload_piece(k, nshards) for k in range(nshards)]
+        assert all(ok for ok, _ in sizes)
+        slot = max(n for _, n in sizes) + 1
+        buf = torch.zeros(nshards * slot, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        for k in range(nshards):
+            ok, n = ov.upload_piece(k, nshards, buf.data_ptr() + 8 * k * slot, slot)
+            assert ok and n == sizes[k][1]
+        ov.upload_assemble(buf.data_ptr(), slot, nshards)
+        _last.update(seqs=seqs, m=m)
+        same(oo.sort_rows(oo.struct_to_rows(ov.overlaps_result(m).rows())), want, "%s, %d pieces" % (name, nshards))
+        assert ov.stats()["paired"] == 1 and ov.stats()["upload_bytes"] < 8 * (sizes[0][1] + slot) + 16 * len(seqs) + 4096
+        ov.close()
+    # reads that are not strand pairs: no sharded upload
+    ov = ExactOverlapper(device=0)
+    ov.add_sequence("a", "ACGTACGTTGCA" * 10)
+    ov.add_sequence("b", "TTGCAACGTAGG" * 10)
+    assert ov.upload_piece(0, 2) == (False, 0)
+    ov.close()
