@@ -360,12 +360,15 @@ def main() -> int:
                                    % (args.config, cfg.n_reads, cfg.read_len, cfg.genome_len, cfg.ploidy,
                                       cfg.snp, cfg.seed, n_oriented, m),
                        "n_reads": cfg.n_reads, "read_len": cfg.read_len, "min_length": m,
-                       "timed_region": "host to host per step: po_invalidate + po_upload (H2D of the packed reads) + po_overlaps_to_host (kernels, D2H of the rows pipelined chunk by chunk) + po_result_rows",
+                       "timed_region": ("host to host per step: po_invalidate + po_upload (H2D of the packed reads) + po_overlaps_to_host (kernels, D2H of the rows pipelined chunk by chunk) + po_result_rows"
+                                        if world == 1 and not args.dist_path else
+                                        "host to host per step, every rank: po_invalidate + sharded upload (po_upload_piece: 1/N of the packed reads over this rank's PCIe link, "
+                                        "one all-gather over xGMI, po_upload_assemble) + po_candidates_shard + one all-gather of verified candidates + po_expand (all rows on every GPU) "
+                                        "+ po_result_rows_range (1/N of the merged rows to this rank's host)"),
                        "parallelism": "each rank uploads 1/N of the packed reads, one RCCL all-gather over xGMI completes every rank's copy; a-side read shards x%d + one RCCL all-gather of verified candidates (16 B, fixed slots) per step + local row expansion on every rank; each rank copies 1/%d of the merged rows to its host" % (world, world) if world > 1
                                       else "single GPU"},
             "rows_per_step": int(n_rows),
             "read_pairs_per_sec": n_oriented * (n_oriented - 1) / (dt / K),
-            "timed_region": "po_invalidate + po_upload (H2D packed reads) + po_overlaps_to_host (kernels with the D2H of the rows pipelined behind them) + po_result_rows, per step",
             "resident": {"overlaps_per_sec": n_rows / (dt_res / K), "ms_per_step": dt_res / K * 1e3,
                          "stage_ms": {k: round(v, 4) for k, v in avg_res.items()},
                          "note": "same step with the packed reads already in HBM and the rows left in HBM"},
