@@ -124,3 +124,44 @@ def test_inexact_mode_on_8bit_reads_and_errors():
     with pytest.raises(ValueError):
         ov.overlaps_ex_array(20, 2, 2)
     ov.close()
+
+
+def test_inexact_fuzz_small_anchors_short_reads_and_edge_bands():
+    """More of the same against the CPU restatement: min_length below the word size (short anchors), reads shorter
+    than the band, identical and contained reads, unpaired and odd-sized read sets, max_diff from 1 to far more than
+    any read can differ by."""
+    rng = np.random.default_rng(4711)
+    rc = bytes.maketrans(b"ACGT", b"TGCA")
+    for trial in range(24):
+        glen = int(rng.integers(200, 1500))
+        genome = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=glen))
+        reads = []
+        for _ in range(int(rng.integers(3, 30))):
+            ln = int(rng.integers(5, min(glen, 400)))
+            st = int(rng.integers(0, glen - ln + 1))
+            r = bytearray(genome[st:st + ln])
+            for _e in range(int(rng.integers(0, 4))):
+                pos = int(rng.integers(0, len(r)))
+                kind = rng.integers(3)
+                if kind == 0:
+                    r[pos] = b"ACGT"[int(rng.integers(4))]
+                elif kind == 1 and len(r) > 6:
+                    del r[pos]
+                else:
+                    r.insert(pos, b"ACGT"[int(rng.integers(4))])
+            r = bytes(r)
+            reads.append(r if rng.random() < 0.5 else r.translate(rc)[::-1])
+            if rng.random() < 0.15:
+                reads.append(reads[-1])
+        if rng.random() < 0.5:
+            seqs = []
+            for r in reads:
+                seqs += [r, r.translate(rc)[::-1]]
+        else:
+            seqs = reads
+        m = int(rng.choice([5, 8, 12, 31, 32, 33, 50]))
+        max_diff = int(rng.choice([1, 2, 5, 30, 1000]))
+        band = int(rng.choice([0, 1, 3, 9, 30]))
+        got, st = ex_rows(seqs, m, max_diff, band)
+        want = ck.oracle_overlaps_ex(seqs, m, max_diff, band, anchor=32)
+        assert np.array_equal(got, want), (trial, m, max_diff, band, len(seqs), len(got), len(want))

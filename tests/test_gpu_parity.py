@@ -744,3 +744,25 @@ def test_sharded_upload_pieces_assemble_to_the_same_read_set(nshards, monkeypatc
     ov.add_sequence("b", "TTGCAACGTAGG" * 10)
     assert ov.upload_piece(0, 2) == (False, 0)
     ov.close()
+
+
+def test_rows_to_host_on_unpaired_odd_and_8bit_read_sets(monkeypatch):
+    monkeypatch.setenv("PHASM_HOST_CHUNKS", "3")
+    rng = np.random.default_rng(31337)
+    genome = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=5000))
+    reads = [genome[int(s):int(s) + int(l)] for s, l in zip(rng.integers(0, 4000, size=41), rng.integers(60, 900, size=41))]
+    alpha = np.frombuffer(b"ACGTNacgt", dtype=np.uint8)
+    g8 = alpha[rng.integers(0, len(alpha), size=4000)].tobytes()
+    reads8 = [g8[int(s):int(s) + int(l)] for s, l in zip(rng.integers(0, 3000, size=37), rng.integers(40, 700, size=37))]
+    for seqs, m, bits in ((reads, 40, 2), (reads8, 20, 8)):
+        ov = ExactOverlapper()
+        for i, s in enumerate(seqs):
+            ov.add_sequence("r%d" % i, s)
+        res = ov.overlaps_to_host_result(m)
+        got = oo.sort_rows(oo.struct_to_rows(res.rows()))
+        res.free()
+        st = ov.stats()
+        ov.close()
+        assert st["bits_per_base"] == bits and st["paired"] == 0
+        _last.update(seqs=seqs, m=m)
+        same(got, ck.oracle_overlaps(seqs, m), "%d-bit, %d reads, 3 chunks" % (bits, len(seqs)))

@@ -33,11 +33,29 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--max-diff", type=int, default=-1, help=">= 0: po_overlaps_ex (banded DP) with this many differences")
     ap.add_argument("--band", type=int, default=0)
+    ap.add_argument("--host", action="store_true", help="time one host-to-host call: invalidate + upload + po_overlaps_to_host + rows")
     a = ap.parse_args()
     cfg = synth.CONFIGS[a.config]
     if a.reads:
         cfg = synth.scaled(cfg, a.reads)
     ov = load(cfg)
+    if a.host:
+        for it in range(a.iters + 1):
+            t0 = time.perf_counter()
+            ov.invalidate()
+            ov.upload()
+            t1 = time.perf_counter()
+            res = ov.overlaps_to_host_result(a.min_length)
+            n = len(res.rows_view())
+            t2 = time.perf_counter()
+            st = ov.stats()
+            res.free()
+            if it:
+                print(json.dumps({"rows": n, "upload_ms": round((t1 - t0) * 1e3, 3), "upload_MB": round(st["upload_bytes"] / 1e6, 1),
+                                  "kernels_plus_d2h_ms": round((t2 - t1) * 1e3, 3), "step_ms": round((t2 - t0) * 1e3, 3),
+                                  "overlaps_per_sec": round(n / (t2 - t0)), "kernel_ms_sum": round(st["ms_total"], 3),
+                                  "index_ms": round(st["ms_index"], 3), "wide": st["wide_index"]}))
+        sys.exit(0)
     for it in range(a.iters):
         t0 = time.time()
         res = ov.overlaps_result(a.min_length) if a.max_diff < 0 else ov.overlaps_ex_result(a.min_length, a.max_diff, a.band)
