@@ -986,6 +986,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         // ---- verify
         if (dp) {
             // banded seed-extension DP, one wave per candidate (extend.hip.h); max_diff = 0 gives the packed compare's answer
+            if (2ull * h->max_len + 64ull >= (1ull << 30))   // (the kernel's "infinity" plus the longest sweep must fit 32 bits)
+                return fail(h, PO_ERR_CAPACITY, "po_overlaps_ex: reads of 2^29 bases or more are beyond the DP kernel");
             PO_TRY(ensure(h, h->d_end_a, (size_t)n_cand * 4));
             PO_TRY(ensure(h, h->d_end_b, (size_t)n_cand * 4));
             PO_TRY(ensure(h, h->d_dpcnt, 64));

@@ -54,7 +54,7 @@ struct ExtArgs {
     unsigned long long* counters;  // [0] DP steps executed (antidiagonals), [1] candidates stopped early
 };
 
-constexpr uint32_t EXT_INF = 1u << 24;
+constexpr uint32_t EXT_INF = 1u << 30;   // (never clamped: the host refuses sweeps of 2^30 antidiagonals or more)
 constexpr int EXT_TILE = 64;  // dwords per LDS tile
 
 __device__ __forceinline__ uint32_t dpp_from_lower(uint32_t fill, uint32_t v) {   // lane k <- lane k-1; lane 0 <- fill
@@ -176,11 +176,33 @@ __global__ __launch_bounds__(256) void k_extend_dp(const ExtArgs A) {
 
     // one antidiagonal: neighbours of the previous step through whole-wave DPP shifts, own value from two steps back
     auto cell = [&](bool commit) __attribute__((always_inline)) {
+#ifdef PO_DP_PLAIN_CELL
         const uint32_t up1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H, 0x130, 0xf, 0xf, true) + one;    // D[i-1][j] + 1: lane kk+1
         const uint32_t left1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H, 0x138, 0xf, 0xf, true) + one;  // D[i][j-1] + 1: lane kk-1
         const uint32_t diag = H + min(xr ^ yr, one);                                                          // D[i-1][j-1] + mismatch
         const uint32_t nw = min(min(diag, up1), min(left1, EXT_INF));
         H = commit ? nw : H;
+#else
+        // the same, spelled as the instructions it should be (tools/ubench.hip measured what each costs on this chip:
+        // v_add/v_xor/v_and/v_or/v_mov/v_lshrrev/v_bitop3 issue in 2.1-2.4 cycles, every DPP form, v_min/v_max, v_cmp,
+        // v_addc and the VOP3 forms in 4.1, and v_cndmask through VCC in 20): the neighbour reads are DPP operands of
+        // the adds, the commit is ONE v_bitop3 select against a per-lane all-ones / all-zeros mask instead of a
+        // v_cndmask, and the clamp at INF is gone (INF + the longest sweep stays below 2^32, checked on the host).
+        // H was last written eight or more instructions ago: no DPP read-after-write wait states needed.
+        const uint32_t m = commit ? 0xFFFFFFFFu : 0u;
+        uint32_t t0, t1, t2;
+        asm volatile(
+            "v_add_u32_dpp %[up], %[H], %[one] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   // D[i-1][j] + 1: lane kk+1
+            "v_add_u32_dpp %[lf], %[H], %[one] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   // D[i][j-1] + 1: lane kk-1
+            "v_cmp_ne_u32 vcc, %[x], %[y]\n\t"
+            "v_addc_co_u32 %[dg], vcc, 0, %[H], vcc\n\t"                                               // D[i-1][j-1] + mismatch
+            "v_min_u32 %[up], %[up], %[lf]\n\t"
+            "v_min_u32 %[up], %[up], %[dg]\n\t"
+            "v_bitop3_b32 %[H], %[up], %[m], %[H] bitop3:0xe2"                                         // (m & new) | (~m & H)   [src0 = 0xf0, src1 = 0xcc, src2 = 0xaa]
+            : [H] "+v"(H), [up] "=&v"(t0), [lf] "=&v"(t1), [dg] "=&v"(t2)
+            : [one] "v"(one), [x] "v"(xr), [y] "v"(yr), [m] "v"(m)
+            : "vcc");
+#endif
     };
     auto shift_x = [&]() __attribute__((always_inline)) {   // lane kk <- lane kk-1; lane 0 keeps its base
         xr = (uint32_t)__builtin_amdgcn_update_dpp((int)xr, (int)xr, 0x138, 0xf, 0xf, false);

@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void k_valu(uint32_t* out, int iters, uint32_t
     uint32_t a0 = threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3, a4 = a0 * 11 + 4, a5 = a0 * 13 + 5,
              a6 = a0 * 17 + 6, a7 = a0 * 19 + 7;
     const uint32_t c = blockIdx.x * 2654435761u + 12345u;
+    const uint64_t m64 = 0x5555555555555555ull ^ (uint64_t)sh;
     if (threadIdx.x == 1023) dyn_lds[0] = 0;  // (keeps the dynamic LDS request alive)
     for (int i = 0; i < iters; ++i) {
 #define STEP(r)                                                                                              \
@@ -39,7 +40,24 @@ __global__ __launch_bounds__(256) void k_valu(uint32_t* out, int iters, uint32_t
     else if (OP == 11) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x80" : "+v"(r) : "v"(c), "v"(sh));  \
     else if (OP == 12) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r) : "s"(sh));                             \
     else if (OP == 13) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "s"(sh));                \
-    else asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(sh));
+    else if (OP == 14) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(sh));             \
+    else if (OP == 15) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r));   \
+    else if (OP == 16) asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r));  \
+    else if (OP == 17) asm volatile("v_add_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(r) : "v"(c)); \
+    else if (OP == 18) asm volatile("v_add_u32_dpp %0, %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(r) : "v"(c)); \
+    else if (OP == 19) asm volatile("v_min_u32 %0, %0, %1" : "+v"(r) : "v"(c));                               \
+    else if (OP == 20) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r) : "v"(c) : "vcc");             \
+    else if (OP == 21) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r) : "v"(c), "s"(m64));         \
+    else if (OP == 22) asm volatile("v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(r) : : "vcc");                 \
+    else if (OP == 23) asm volatile("v_cmp_ne_u32 vcc, %0, %1\n\tv_xor_b32 %0, %0, %1" : "+v"(r) : "v"(c) : "vcc"); \
+    else if (OP == 24) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r) : "v"(c));                               \
+    else if (OP == 25) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r) : "v"(c));                               \
+    else if (OP == 26) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r) : "v"(c));                               \
+    else if (OP == 27) asm volatile("v_or_b32 %0, %0, %1" : "+v"(r) : "v"(c));                                \
+    else if (OP == 28) asm volatile("v_max_u32 %0, %0, %1" : "+v"(r) : "v"(c));                               \
+    else if (OP == 29) asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(r) : "v"(sh));                          \
+    else if (OP == 30) asm volatile("v_mov_b32 %0, %1" : "+v"(r) : "v"(c));                                   \
+    else asm volatile("v_min_i32 %0, %0, %1" : "+v"(r) : "v"(c));
         STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
         STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
 #undef STEP
@@ -107,8 +125,11 @@ double ub_valu(int op, int waves_per_simd, int iters) {
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     void (*kerns[])(uint32_t*, int, uint32_t) = {k_valu<0>, k_valu<1>, k_valu<2>, k_valu<3>, k_valu<4>, k_valu<5>, k_valu<6>, k_valu<7>,
-                                                 k_valu<8>, k_valu<9>, k_valu<10>, k_valu<11>, k_valu<12>, k_valu<13>, k_valu<14>};
-    if (op < 0 || op > 14) return -1.0;
+                                                 k_valu<8>, k_valu<9>, k_valu<10>, k_valu<11>, k_valu<12>, k_valu<13>, k_valu<14>,
+                                                 k_valu<15>, k_valu<16>, k_valu<17>, k_valu<18>, k_valu<19>, k_valu<20>,
+                                                 k_valu<21>, k_valu<22>, k_valu<23>, k_valu<24>, k_valu<25>, k_valu<26>, k_valu<27>,
+                                                 k_valu<28>, k_valu<29>, k_valu<30>, k_valu<31>};
+    if (op < 0 || op > 31) return -1.0;
     auto kern = kerns[op];
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, out, iters / 8, 7u);

@@ -41,7 +41,10 @@ def measure(quick=False):
     out = {"valu": {}, "lds_random_b64_TBps": {}, "l2_hit_dwordx4_TBps": {}}
     ops = ("v_alignbit_b32 v,v,v", "v_xor_b32", "v_lshrrev_b32", "v_alignbit_b32 v,v,imm", "v_alignbit_b32 v,v,s",
            "v_or3_b32 v,v,v", "v_and_or_b32 v,v,v", "v_lshl_or_b32 v,imm,v", "v_bfe_u32 v,imm,imm", "v_add3_u32 v,v,v",
-           "v_perm_b32 v,v,v", "v_bitop3_b32 v,v,v", "v_and_b32 v,s", "v_or3_b32 v,v,s", "v_mad_u32_u24 v,v,v")
+           "v_perm_b32 v,v,v", "v_bitop3_b32 v,v,v", "v_and_b32 v,s", "v_or3_b32 v,v,s", "v_mad_u32_u24 v,v,v",
+           "v_mov_b32_dpp row_shr:1", "v_mov_b32_dpp wave_shr:1", "v_add_u32_dpp row_shr:1", "v_add_u32_dpp wave_shl:1",
+           "v_min_u32", "v_cndmask_b32 vcc", "v_cndmask_b32_e64 sgpr mask", "v_addc_co_u32 vcc", "v_cmp_ne_u32 + v_xor_b32 (2 instr)",
+           "v_add_u32", "v_sub_u32", "v_and_b32 v,v", "v_or_b32 v,v", "v_max_u32", "v_lshlrev_b32", "v_mov_b32", "v_min_i32")
     for op, name in enumerate(ops):
         out["valu"][name] = {}
         for w in ((1, 2, 4, 8) if op < 3 else (2, 8)):
