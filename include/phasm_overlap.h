@@ -87,7 +87,8 @@ typedef struct {
     uint64_t dp_stopped;         /*                 candidates whose whole band rose above max_diff before the end   */
     uint32_t max_diff, band;     /*                 the parameters of the call (0, 0 for the exact entry points)     */
     uint32_t index_reused;       /* 1: the anchor index of the previous call on this handle was reused (same upload,   */
-    uint32_t reserved0;          /*    same min_length and flavour); 0: built in this call                             */
+    uint32_t dp_lanes;           /*    same min_length and flavour); 0: built in this call.  dp_lanes (po_overlaps_ex):  */
+                                 /*    1 = lane-per-candidate DP kernel, 0 = wave-per-candidate (lane per diagonal)     */
     uint64_t upload_bytes;       /* bytes the last po_upload moved host->device (half the packed set when every   */
                                  /* odd read is the reverse complement of its even partner: the device rebuilds them) */
 } po_stats;

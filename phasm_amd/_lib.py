@@ -61,7 +61,7 @@ class PoStats(ctypes.Structure):
         ("ms_scan_probe", ctypes.c_float), ("ms_verify_kernel", ctypes.c_float),
         ("verify_bytes_exec", ctypes.c_uint64), ("dp_steps", ctypes.c_uint64), ("dp_stopped", ctypes.c_uint64),
         ("max_diff", ctypes.c_uint32), ("band", ctypes.c_uint32), ("index_reused", ctypes.c_uint32),
-        ("reserved0", ctypes.c_uint32), ("upload_bytes", ctypes.c_uint64),
+        ("dp_lanes", ctypes.c_uint32), ("upload_bytes", ctypes.c_uint64),
     ]
 
     def as_dict(self) -> dict:

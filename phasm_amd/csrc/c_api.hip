@@ -1010,8 +1010,22 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             X.end_a = h->d_end_a.as<uint32_t>();
             X.end_b = h->d_end_b.as<uint32_t>();
             X.counters = h->d_dpcnt.as<unsigned long long>();
+            // two mappings of the same DP (extend.hip.h): a LANE per candidate (2-bit reads, band <= 15: the one an
+            // overlap job wants -- millions of candidates, narrow bands), or a WAVE per candidate with a lane per
+            // diagonal (any encoding, band <= 30); PHASM_DP_KERNEL=wave|lanes forces one (tests run both)
+            bool lanes = BITS == 2 && dpW <= 15;
+            if (const char* e = getenv("PHASM_DP_KERNEL")) {
+                if (!strcmp(e, "wave")) lanes = false;
+                if (!strcmp(e, "lanes") && !(BITS == 2 && dpW <= 15)) return fail(h, PO_ERR_INVALID, "PHASM_DP_KERNEL=lanes needs 2-bit reads and band <= 15");
+            }
+            S.dp_lanes = lanes ? 1u : 0u;
             HIP_TRY(h, hipEventRecord(h->ev[EV_VER0], st));
-            hipLaunchKernelGGL((po::k_extend_dp<BITS>), dim3(cdiv(n_cand, 256 / po::WAVE)), dim3(256), 0, st, X);
+            if (lanes) {
+                auto kern = dpW <= 4 ? po::k_extend_lanes<4> : dpW <= 8 ? po::k_extend_lanes<8> : po::k_extend_lanes<15>;
+                hipLaunchKernelGGL(kern, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, X);
+            } else {
+                hipLaunchKernelGGL((po::k_extend_dp<BITS>), dim3(cdiv(n_cand, 256 / po::WAVE)), dim3(256), 0, st, X);
+            }
             HIP_TRY(h, hipEventRecord(h->ev[EV_VER1], st));
             HIP_TRY(h, hipMemcpyAsync(h->pinned + 32, h->d_dpcnt.p, 16, hipMemcpyDeviceToHost, st));
             ver_timed = true;

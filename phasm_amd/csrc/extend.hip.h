@@ -317,6 +317,153 @@ __global__ __launch_bounds__(256) void k_extend_dp(const ExtArgs A) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// The same DP with the parallelism turned round: ONE LANE PER CANDIDATE, 64 candidates per wave.
+//
+// k_extend_dp spreads one candidate over a wave (a lane per diagonal).  That is the mapping for few, long, wide
+// alignments; an overlap job has MILLIONS of candidates and narrow bands (config 4: 6.9 M candidates, W = 8, 17
+// diagonals -> 45 of 64 lanes idle, and every step pays four DPP exchanges).  Here a lane keeps its candidate's whole
+// band row D[i][i-W .. i+W] in registers (2W + 1 VGPRs, W a template bound) and walks the rows serially:
+//     D[i][j] = min(D[i-1][j-1] + (x[i-1] != y[j-1]),  min(D[i-1][j], D[i][j-1]) + 1)
+// no cross-lane traffic at all.  x is a 16-base register window; y is a sliding (2W+1)-base window kept packed in 64
+// bits, and one row's 2W+1 base comparisons are three bitwise ops on that window (x replicated into every 2-bit
+// field, XOR, fold the two bits of each field).  Per cell: one bit extract, two adds, two mins.  Candidates of a wave
+// are neighbours in the a-major candidate order (similar lengths); a lane whose whole band is above max_diff stops,
+// the wave ends with its longest candidate.  2-bit reads, W <= 15 (the y window is 64 bits).  Same results as
+// k_extend_dp, bit for bit (tests run both); ~12 x its throughput at config 4.
+template <int WB>
+__global__ __launch_bounds__(256) void k_extend_lanes(const ExtArgs A) {
+    constexpr int NB = 2 * WB + 1;   // band cells kept per lane (the call's band W <= WB uses the middle 2W + 1)
+    const uint32_t c0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = c0 < A.n_cand;
+    const uint32_t c = in_range ? c0 : 0u;   // (lanes past the end walk candidate 0 with nothing to do: no early return,
+                                             //  the wave-wide sums at the end need every lane)
+    const uint32_t a = A.cand_a[c], p = A.cand_p[c], b = A.cand_b[c];
+    const uint32_t la = A.len[a], lb = A.len[b];
+    const uint32_t rem = la - p;
+    const uint32_t E = A.max_diff;
+    const int32_t W = (int32_t)(E ? A.band : 0u);
+    bool canA = rem <= lb + (uint32_t)W, canB = lb <= rem + (uint32_t)W;
+    if (A.paired) {
+        const uint32_t kb = keep_bits(a, b, rem, lb, A.paired);
+        canA = canA && (kb & 1u);
+        canB = canB && (kb & 2u);
+    }
+    if (!in_range || a == b) canA = canB = false;
+    const uint32_t* __restrict__ gx = reinterpret_cast<const uint32_t*>(A.words + A.woff[a]);
+    const uint32_t* __restrict__ gy = reinterpret_cast<const uint32_t*>(A.words + A.woff[b]);
+    // base q of y (0 outside [0, lb): never compared where it matters -- cells beyond column lb feed nothing wanted)
+    auto ybase = [&](int32_t q) __attribute__((always_inline)) -> uint32_t {
+        if (q < 0 || (uint32_t)q >= lb) return 0u;
+        return (gy[(uint32_t)q >> 4] >> (((uint32_t)q & 15u) * 2u)) & 3u;
+    };
+    // D[k] = D[i][i - WB + k] for the current row i; cells outside the call's band or the matrix hold INF
+    uint32_t D[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int32_t j = k - WB;   // row 0: D[0][j] = j inside the band
+        D[k] = (j >= 0 && j <= W && (uint32_t)j <= lb) ? (uint32_t)j : EXT_INF;
+    }
+    // y window for row i: bases y[i - WB - 1 + k], k = 0 .. 2 WB, two bits each, in (ylo, yhi); row 1 first
+    uint32_t ylo = 0, yhi = 0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const uint32_t v = ybase(1 - WB - 1 + k);
+        if (k < 16) ylo |= v << (2 * k); else yhi |= v << (2 * (k - 16));
+    }
+    const uint32_t rows = canA ? rem : (canB ? min(rem, lb + (uint32_t)W) : 0u);   // last row that holds a wanted cell
+    uint32_t bestA = 0xFFFFFFFFu, bestB = 0xFFFFFFFFu, endA_j = 0, endB_i = 0;
+    uint32_t xw = 0;
+    uint32_t steps = 0;
+    bool dead = false;
+    for (uint32_t i = 1; i <= rows; ++i) {
+        // ---- x[i-1]: 16-base window, refilled from the packed read every 16 rows
+        const uint32_t xpos = p + i - 1u;
+        if (i == 1u || (xpos & 15u) == 0u) xw = gx[xpos >> 4] >> ((xpos & 15u) * 2u);
+        const uint32_t xb = xw & 3u;
+        xw >>= 2;
+        // ---- all 2 WB + 1 comparisons of the row at once: bit 2k of nm = (x[i-1] != y[i - WB - 1 + k])
+        const uint32_t xrep = ((xb & 1u) ? 0x55555555u : 0u) | ((xb & 2u) ? 0xAAAAAAAAu : 0u);
+        const uint32_t tl = ylo ^ xrep, th = yhi ^ xrep;
+        const uint32_t nml = (tl | (tl >> 1)) & 0x55555555u, nmh = (th | (th >> 1)) & 0x55555555u;
+        // ---- the row, left to right (the left neighbour is this row's previous cell)
+        uint32_t left = EXT_INF, rowmin = EXT_INF;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const uint32_t mism = k < 16 ? (nml >> (2 * k)) & 1u : (nmh >> (2 * (k - 16))) & 1u;
+            const uint32_t up = k + 1 < NB ? D[k + 1] : EXT_INF;
+            uint32_t v = min(D[k] + mism, min(up, left) + 1u);
+            const int32_t off = k - WB;                    // diagonal j - i
+            const int64_t j = (int64_t)i + off;
+            if (off < -W || off > W || j < 0) v = EXT_INF;  // outside the call's band / left of the matrix
+            D[k] = v;
+            left = v;
+            rowmin = min(rowmin, v);
+        }
+        ++steps;
+        // ---- ends.  B: column lb is cell k = lb - i + WB of this row (rows lb - W .. lb + W)
+        if (canB) {
+            const int32_t kb = (int32_t)lb - (int32_t)i + WB;
+            if (kb >= WB - W && kb <= WB + W) {
+                uint32_t v = EXT_INF;
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                    if (k == kb) v = D[k];
+                const int32_t dl = kb - WB;                 // delta = lb - i
+                if (v <= E) {
+                    const uint32_t key = (v << 8) | ((uint32_t)(dl >= 0 ? dl : -dl) << 1) | (dl < 0 ? 1u : 0u);
+                    if (key < bestB) {
+                        bestB = key;
+                        endB_i = i;
+                    }
+                }
+            }
+        }
+        if (canA && i == rem) {   // A: row rem, columns 1 .. lb
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int32_t dl = k - WB;
+                const int64_t j = (int64_t)rem + dl;
+                if (dl >= -W && dl <= W && j >= 1 && j <= (int64_t)lb && D[k] <= E) {
+                    const uint32_t key = (D[k] << 8) | ((uint32_t)(dl >= 0 ? dl : -dl) << 1) | (dl > 0 ? 1u : 0u);
+                    if (key < bestA) {
+                        bestA = key;
+                        endA_j = (uint32_t)j;
+                    }
+                }
+            }
+        }
+        // ---- nothing in the band at or below max_diff: no later cell can be (costs never fall along a path)
+        if (rowmin > E) {
+            dead = i < rows;
+            break;
+        }
+        // ---- slide the y window: drop y[i - WB - 1], take in y[i + WB]
+        ylo = (ylo >> 2) | (yhi << 30);
+        yhi >>= 2;
+        const uint32_t nv = ybase((int32_t)i + WB);
+        if (2 * WB < 16) ylo |= nv << (2 * (2 * WB)); else yhi |= nv << (2 * (2 * WB - 16));
+    }
+    uint32_t t = 0;
+    if (bestA != 0xFFFFFFFFu) {   // (only lanes with a candidate of their own ever get here with a best end)
+        t |= 1u;
+        A.end_a[c] = endA_j;
+    }
+    if (bestB != 0xFFFFFFFFu) {
+        t |= 2u;
+        A.end_b[c] = endB_i;
+    }
+    if (t && A.exc_off && E == 0 && !exceptions_equal(A.exc_off, A.exc_pos, A.exc_byte, a, p, b, (t & 1u) ? rem : lb)) t = 0;
+    if (in_range) A.type[c] = (uint8_t)t;
+    // (counters: rows walked, candidates stopped early -- one atomic per wave)
+    const uint64_t ws = wave_sum64(2ull * steps);   // two antidiagonals per row: comparable with k_extend_dp's count
+    const uint32_t wd = wave_sum(dead ? 1u : 0u);
+    if (lane_id() == 0) {
+        atomicAdd(&A.counters[0], (unsigned long long)ws);
+        if (wd) atomicAdd(&A.counters[1], (unsigned long long)wd);
+    }
+}
+
 // Rows of the inexact mode: ends come from the DP (no strand-mirror shortcut: every candidate was extended itself).
 __global__ __launch_bounds__(256) void k_emit_ex(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
                                                  const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,

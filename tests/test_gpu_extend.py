@@ -19,6 +19,18 @@ from phasm_amd.overlapper import ExactOverlapper
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["lanes", "wave"], autouse=True)
+def dp_kernel(request, monkeypatch):
+    """Every test runs through both mappings of the DP: a lane per candidate (k_extend_lanes: 2-bit reads, band <= 15)
+    and a wave per candidate with a lane per diagonal (k_extend_dp).  Where `lanes` does not apply the library picks
+    the wave kernel by itself (no forcing), so the default selection is exercised too."""
+    if request.param == "wave":
+        monkeypatch.setenv("PHASM_DP_KERNEL", "wave")
+    else:
+        monkeypatch.delenv("PHASM_DP_KERNEL", raising=False)
+    return request.param
+
+
 def ex_rows(seqs, m, max_diff, band):
     ov = ExactOverlapper()
     for i, s in enumerate(seqs):
@@ -82,13 +94,14 @@ def noisy_reads(rng, n_reads, glen, lo, hi, sub, indel, both_strands):
 
 
 @pytest.mark.parametrize("seed,max_diff,band", [(1, 1, 1), (2, 3, 2), (3, 8, 4), (4, 20, 16), (5, 40, 30), (6, 5, 0), (7, 2, 30)])
-def test_inexact_rows_equal_the_cpu_restatement(seed, max_diff, band):
+def test_inexact_rows_equal_the_cpu_restatement(seed, max_diff, band, dp_kernel):
     rng = np.random.default_rng(1000 + seed)
     seqs = noisy_reads(rng, n_reads=40, glen=3000, lo=150, hi=1400, sub=0.01, indel=0.006, both_strands=seed % 2 == 0)
     m = int(rng.choice([40, 64, 100]))
     got, st = ex_rows(seqs, m, max_diff, band)
     want = ck.oracle_overlaps_ex(seqs, m, max_diff, band, anchor=32)
     assert st["paired"] == 0 and st["max_diff"] == max_diff and st["band"] == band
+    assert st["dp_lanes"] == (1 if (dp_kernel == "lanes" and band <= 15) else 0)
     assert np.array_equal(got, want), (len(got), len(want), [tuple(r) for r in got[:5]], [tuple(r) for r in want[:5]])
     exact = ck.oracle_overlaps(seqs, m)
     assert len(want) >= len(exact)          # tolerance only ever adds overlaps of a pair / occurrences
