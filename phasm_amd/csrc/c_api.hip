@@ -1021,8 +1021,33 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             S.dp_lanes = lanes ? 1u : 0u;
             HIP_TRY(h, hipEventRecord(h->ev[EV_VER0], st));
             if (lanes) {
+                // candidates ordered by the rows they need, so that the 64 lanes of a wave finish together
+                const uint32_t* perm = nullptr;
+                bool sorted = n_cand >= 4096;
+                if (const char* e = getenv("PHASM_DP_SORT")) sorted = atoi(e) != 0;   // (tests force it on small inputs)
+                if (sorted) {
+                    const uint32_t max_bins = (uint32_t)((std::min<size_t>(h->lds_max, 160 * 1024) - 1024) / 4);
+                    const uint32_t max_rows = h->max_len + dpW;
+                    uint32_t shift = 0;
+                    while ((max_rows >> shift) + 1 > max_bins) ++shift;
+                    const uint32_t n_bins = (max_rows >> shift) + 1;
+                    const size_t sort_lds = ((size_t)n_bins + po::SORT_BLOCK / 64) * 4;
+                    PO_TRY(ensure(h, h->d_vlabel, (size_t)n_cand * 4));
+                    PO_TRY(ensure(h, h->d_vrank, (size_t)n_cand * 4));
+                    PO_TRY(ensure(h, h->d_vperm, (size_t)n_cand * 4));
+                    hipLaunchKernelGGL(po::k_dp_rows, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_p, A.cand_b, len, n_cand,
+                                       dpW, h->d_vlabel.as<uint32_t>());
+                    if (sort_lds > 48 * 1024)
+                        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_read_sort),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+                    hipLaunchKernelGGL(po::k_read_sort, dim3(1), dim3(po::SORT_BLOCK), sort_lds, st, h->d_vlabel.as<uint32_t>(), n_cand,
+                                       shift, n_bins, h->d_vrank.as<uint32_t>());
+                    hipLaunchKernelGGL(po::k_read_invert, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, h->d_vrank.as<uint32_t>(), n_cand, 0u,
+                                       h->d_vperm.as<uint32_t>());
+                    perm = h->d_vperm.as<uint32_t>();
+                }
                 auto kern = dpW <= 4 ? po::k_extend_lanes<4> : dpW <= 8 ? po::k_extend_lanes<8> : po::k_extend_lanes<15>;
-                hipLaunchKernelGGL(kern, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, X);
+                hipLaunchKernelGGL(kern, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, X, perm);
             } else {
                 hipLaunchKernelGGL((po::k_extend_dp<BITS>), dim3(cdiv(n_cand, 256 / po::WAVE)), dim3(256), 0, st, X);
             }

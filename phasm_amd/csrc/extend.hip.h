@@ -331,18 +331,33 @@ __global__ __launch_bounds__(256) void k_extend_dp(const ExtArgs A) {
 // are neighbours in the a-major candidate order (similar lengths); a lane whose whole band is above max_diff stops,
 // the wave ends with its longest candidate.  2-bit reads, W <= 15 (the y window is 64 bits).  Same results as
 // k_extend_dp, bit for bit (tests run both); ~12 x its throughput at config 4.
+// rows the lane kernel will walk for candidate c (its sort key: a wave's 64 lanes should finish together)
+__global__ void k_dp_rows(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
+                          const uint32_t* __restrict__ cand_b, const uint32_t* __restrict__ len, uint32_t n_cand,
+                          uint32_t band, uint32_t* __restrict__ rows) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cand) return;
+    const uint32_t rem = len[cand_a[c]] - cand_p[c], lb = len[cand_b[c]];
+    rows[c] = min(rem, lb + band);
+}
+
 template <int WB>
-__global__ __launch_bounds__(256) void k_extend_lanes(const ExtArgs A) {
+__global__ __launch_bounds__(256) void k_extend_lanes(const ExtArgs A, const uint32_t* __restrict__ perm) {
     constexpr int NB = 2 * WB + 1;   // band cells kept per lane (the call's band W <= WB uses the middle 2W + 1)
     const uint32_t c0 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = c0 < A.n_cand;
-    const uint32_t c = in_range ? c0 : 0u;   // (lanes past the end walk candidate 0 with nothing to do: no early return,
-                                             //  the wave-wide sums at the end need every lane)
+    // Candidates come a-major with ascending p: the 64 consecutive candidates of a wave would span one read's whole
+    // list, overlap lengths from 15 kb down to 1 kb, and the wave would run as long as its longest lane (53 % of the
+    // lane-rows idle at config 4).  `perm` lists the candidates by the number of rows they need (counting sort,
+    // k_dp_rows + k_read_sort): a wave's lanes then finish together.
+    const uint32_t c = in_range ? (perm ? perm[c0] : c0) : 0u;   // (lanes past the end walk candidate 0 with nothing to
+                                                                 //  do: no early return, the wave sums at the end need every lane)
     const uint32_t a = A.cand_a[c], p = A.cand_p[c], b = A.cand_b[c];
     const uint32_t la = A.len[a], lb = A.len[b];
     const uint32_t rem = la - p;
     const uint32_t E = A.max_diff;
-    const int32_t W = (int32_t)(E ? A.band : 0u);
+    // (readfirstlane: the band tests below are then scalar compares and branches, not lane masks)
+    const int32_t W = (int32_t)__builtin_amdgcn_readfirstlane(E ? A.band : 0u);
     bool canA = rem <= lb + (uint32_t)W, canB = lb <= rem + (uint32_t)W;
     if (A.paired) {
         const uint32_t kb = keep_bits(a, b, rem, lb, A.paired);
@@ -371,34 +386,36 @@ __global__ __launch_bounds__(256) void k_extend_lanes(const ExtArgs A) {
         const uint32_t v = ybase(1 - WB - 1 + k);
         if (k < 16) ylo |= v << (2 * k); else yhi |= v << (2 * (k - 16));
     }
+    uint32_t ob[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) ob[k] = __builtin_amdgcn_readfirstlane((k - WB < -W || k - WB > W) ? EXT_INF : 0u);
     const uint32_t rows = canA ? rem : (canB ? min(rem, lb + (uint32_t)W) : 0u);   // last row that holds a wanted cell
     uint32_t bestA = 0xFFFFFFFFu, bestB = 0xFFFFFFFFu, endA_j = 0, endB_i = 0;
-    uint32_t xw = 0;
+    uint32_t xw = 0, yw = 0;
     uint32_t steps = 0;
     bool dead = false;
     for (uint32_t i = 1; i <= rows; ++i) {
-        // ---- x[i-1]: 16-base window, refilled from the packed read every 16 rows
-        const uint32_t xpos = p + i - 1u;
+        // ---- x[i-1] and the base that enters the y window after this row, y[i + WB]: 16-base register windows,
+        // refilled from the packed reads every 16 rows (past a read's end come guard words / the next read: a base
+        // beyond column lb only ever reaches cells beyond column lb, which feed nothing that is wanted)
+        const uint32_t xpos = p + i - 1u, ypos = i + (uint32_t)WB;
         if (i == 1u || (xpos & 15u) == 0u) xw = gx[xpos >> 4] >> ((xpos & 15u) * 2u);
+        if (i == 1u || (ypos & 15u) == 0u) yw = gy[ypos >> 4] >> ((ypos & 15u) * 2u);
         const uint32_t xb = xw & 3u;
         xw >>= 2;
         // ---- all 2 WB + 1 comparisons of the row at once: bit 2k of nm = (x[i-1] != y[i - WB - 1 + k])
         const uint32_t xrep = ((xb & 1u) ? 0x55555555u : 0u) | ((xb & 2u) ? 0xAAAAAAAAu : 0u);
         const uint32_t tl = ylo ^ xrep, th = yhi ^ xrep;
         const uint32_t nml = (tl | (tl >> 1)) & 0x55555555u, nmh = (th | (th >> 1)) & 0x55555555u;
-        // ---- the row, left to right (the left neighbour is this row's previous cell)
-        uint32_t left = EXT_INF, rowmin = EXT_INF;
+        // ---- the row, left to right (the left neighbour is this row's previous cell).  Diagonals outside the call's
+        // band are pinned at INF by OR-ing a per-diagonal scalar (branches on the band made hipcc rebuild lane masks in
+        // every cell); cells left of the matrix (j < 0) need no test: everything they are computed from is INF.
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const uint32_t mism = k < 16 ? (nml >> (2 * k)) & 1u : (nmh >> (2 * (k - 16))) & 1u;
             const uint32_t up = k + 1 < NB ? D[k + 1] : EXT_INF;
-            uint32_t v = min(D[k] + mism, min(up, left) + 1u);
-            const int32_t off = k - WB;                    // diagonal j - i
-            const int64_t j = (int64_t)i + off;
-            if (off < -W || off > W || j < 0) v = EXT_INF;  // outside the call's band / left of the matrix
-            D[k] = v;
-            left = v;
-            rowmin = min(rowmin, v);
+            const uint32_t left = k > 0 ? D[k - 1] : EXT_INF;   // (this row's value already)
+            D[k] = min(D[k] + mism, min(up, left) + 1u) | ob[k];   // ob: INF on the diagonals outside the call's band
         }
         ++steps;
         // ---- ends.  B: column lb is cell k = lb - i + WB of this row (rows lb - W .. lb + W)
@@ -433,15 +450,22 @@ __global__ __launch_bounds__(256) void k_extend_lanes(const ExtArgs A) {
                 }
             }
         }
-        // ---- nothing in the band at or below max_diff: no later cell can be (costs never fall along a path)
-        if (rowmin > E) {
-            dead = i < rows;
-            break;
+        // ---- every 16 rows: nothing in the band at or below max_diff means no later cell can be (costs never fall
+        // along a path, and every path to a later row crosses this one)
+        if ((i & 15u) == 0u) {
+            uint32_t rowmin = EXT_INF;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) rowmin = min(rowmin, D[k]);
+            if (rowmin > E) {
+                dead = i < rows;
+                break;
+            }
         }
         // ---- slide the y window: drop y[i - WB - 1], take in y[i + WB]
         ylo = (ylo >> 2) | (yhi << 30);
         yhi >>= 2;
-        const uint32_t nv = ybase((int32_t)i + WB);
+        const uint32_t nv = yw & 3u;
+        yw >>= 2;
         if (2 * WB < 16) ylo |= nv << (2 * (2 * WB)); else yhi |= nv << (2 * (2 * WB - 16));
     }
     uint32_t t = 0;

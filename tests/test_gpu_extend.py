@@ -28,6 +28,7 @@ def dp_kernel(request, monkeypatch):
         monkeypatch.setenv("PHASM_DP_KERNEL", "wave")
     else:
         monkeypatch.delenv("PHASM_DP_KERNEL", raising=False)
+        monkeypatch.setenv("PHASM_DP_SORT", "1")     # candidates ordered by length (what large calls do), also on small inputs
     return request.param
 
 
