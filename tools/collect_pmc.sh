@@ -27,8 +27,13 @@ run_pass sq3    "$P" --config cfg2 --iters 3 --pmc-- SQ_ACTIVE_INST_VALU SQ_ACTI
 run_pass sq4    "$P" --config cfg2 --iters 3 --pmc-- SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH
 run_pass tcc    "$P" --config cfg2 --iters 3 --pmc-- TCC_HIT_sum TCC_MISS_sum
 # config 4 through the banded DP (po_overlaps_ex): where does k_extend_dp spend its cycles?
+# (both mappings: the lane-per-candidate kernel is the default, PHASM_DP_KERNEL=wave selects the wave-per-candidate one)
 run_pass dp_sq1 "$P" --config cfg4 --iters 1 --max-diff 400 --band 8 --pmc-- SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CU_CYCLES
 run_pass dp_sq2 "$P" --config cfg4 --iters 1 --max-diff 400 --band 8 --pmc-- SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES
+export PHASM_DP_KERNEL=wave
+run_pass dp_wave_sq1 "$P" --config cfg4 --iters 1 --max-diff 400 --band 8 --pmc-- SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CU_CYCLES
+run_pass dp_wave_sq2 "$P" --config cfg4 --iters 1 --max-diff 400 --band 8 --pmc-- SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES
+unset PHASM_DP_KERNEL
 run_pass lfetch "$L" --config cfg2 --iters 3 --pmc-- FETCH_SIZE
 run_pass lwrite "$L" --config cfg2 --iters 3 --pmc-- WRITE_SIZE
 echo done >&2
