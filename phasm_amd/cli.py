@@ -57,7 +57,12 @@ def overlap(args) -> int:
             args.output.write(gfa.gfa_line("S", name, len(seq), "*"))
             overlapper.add_sequence(name + "+", seq)
             overlapper.add_sequence(name + "-", reverse_complement(seq))
-    res = overlapper.overlaps_result(args.min_length)
+    max_diff = int(getattr(args, "max_diff", 0) or 0)
+    if max_diff > 0:
+        # beyond the reference (which is exact, assembler.py:436-439): banded seed-extension DP, po_overlaps_ex
+        res = overlapper.overlaps_ex_result(args.min_length, max_diff, int(getattr(args, "band", 0) or 0))
+    else:
+        res = overlapper.overlaps_to_host_result(args.min_length)   # rows travel to the host while later chunks are computed
     logger.info("Writing %d overlaps to GFA2...", len(res))
     try:
         try:
@@ -167,6 +172,10 @@ def main(argv=None) -> int:
                    help="Output file (default: stdout)")
     p.add_argument("--device", type=int, default=None, help="HIP device ordinal (default 0)")
     p.add_argument("--python-ingest", action="store_true", help="parse the FASTA in Python instead of po_add_fasta")
+    p.add_argument("--max-diff", type=int, default=0,
+                   help="(extension beyond the exact reference) accept overlaps with up to this many differences: banded "
+                        "seed-extension DP on the GPU; 0 = exact, the reference's behaviour (default)")
+    p.add_argument("--band", type=int, default=8, help="with --max-diff: diagonals each side of the anchor's diagonal (<= 30; default 8)")
     p.add_argument("fasta_input", help="FASTA file with reads")
     p.set_defaults(func=overlap)
     # option names and defaults of `phasm layout`, assembler.py:469-489

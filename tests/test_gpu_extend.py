@@ -179,3 +179,23 @@ def test_inexact_fuzz_small_anchors_short_reads_and_edge_bands():
         got, st = ex_rows(seqs, m, max_diff, band)
         want = ck.oracle_overlaps_ex(seqs, m, max_diff, band, anchor=32)
         assert np.array_equal(got, want), (trial, m, max_diff, band, len(seqs), len(got), len(want))
+
+
+def test_cli_overlap_with_max_diff_writes_the_extension_rows(tmp_path):
+    """`overlap --max-diff E --band W` writes the rows of po_overlaps_ex; without the option the file is the exact one."""
+    from phasm_amd import cli
+    from phasm_amd.io import gfa
+    rng = np.random.default_rng(2024)
+    reads = noisy_reads(rng, n_reads=30, glen=2500, lo=300, hi=1200, sub=0.01, indel=0.004, both_strands=False)
+    named = [("read%d" % i, r) for i, r in enumerate(reads)]
+    fa = tmp_path / "reads.fasta"
+    synth.write_fasta(str(fa), named, width=60)
+    seqs = [s for _, s in synth.oriented(named)]
+    ids = [n for n, _ in synth.oriented(named)]
+    for extra, want in (([], ck.oracle_overlaps(seqs, 50)), (["--max-diff", "6", "--band", "3"], ck.oracle_overlaps_ex(seqs, 50, 6, 3))):
+        out = tmp_path / ("out%d.gfa" % len(extra))
+        assert cli.main(["overlap", str(fa), "-l", "50", "-o", str(out)] + extra) == 0
+        e_lines = sorted(l for l in out.read_text().splitlines(keepends=True) if l.startswith("E\t"))
+        want_lines = sorted(gfa.gfa_line("E", "*", ids[a], ids[b], s, e, bs, be, "*") for a, b, s, e, bs, be in want.tolist())
+        assert e_lines == want_lines
+        assert len(want_lines) > 10
