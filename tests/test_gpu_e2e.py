@@ -249,15 +249,16 @@ print("RANK %%d OK" %% rank)
 """
 
 
-def test_two_ranks_on_one_gpu_exchange_the_sliced_index(tmp_path):
-    """The N > 1 step end to end with two ranks sharing this GPU (gloo carries the collectives; RCCL refuses two
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_two_ranks_on_one_gpu_exchange_the_sliced_index(nproc, tmp_path):
+    """The N > 1 step end to end with two (and four) ranks sharing this GPU (gloo carries the collectives; RCCL refuses two
     ranks on one device): rank g builds sub-table g of the wide index, the chunks are all-gathered, every rank's
     shard probes the gathered index, candidates are exchanged and expanded -- both ranks end with the golden rows."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "two_ranks.py"
     script.write_text(_TWO_RANK_CHILD % {"root": root, "tests": os.path.join(root, "tests")})
-    rc, stdout, stderr = ck.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                                 "--master-addr", "127.0.0.1", "--master-port", "29641", str(script)],
+    rc, stdout, stderr = ck.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc,
+                                 "--master-addr", "127.0.0.1", "--master-port", str(29641 + nproc), str(script)],
                                 capture_output=True, text=True, timeout=500)
-    assert rc == 0 and "RANK 0 OK" in stdout and "RANK 1 OK" in stdout, stdout[-2000:] + stderr[-3000:]
+    assert rc == 0 and all("RANK %d OK" % r in stdout for r in range(nproc)), stdout[-2000:] + stderr[-3000:]
