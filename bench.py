@@ -198,6 +198,7 @@ def main() -> int:
     ap.add_argument("--cpu-sample-reads", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tuples", action="store_true", help="skip the Python tuple materialisation leg")
+    ap.add_argument("--no-stream", action="store_true", help="N=1: upload the whole read set first (po_upload), then call po_overlaps_to_host (the unstreamed form of the step)")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the config-4 leg (exact path + banded DP)")
     ap.add_argument("--dist-path", action="store_true",
                     help="dev: run the N>1 code path (shard + RCCL all-gather + expansion) even with one rank")
@@ -262,8 +263,9 @@ def main() -> int:
             ov.invalidate()
             if read_exchange is not None:
                 read_exchange.upload()    # N > 1: 1/N of the packed reads over this rank's PCIe link, the rest over xGMI
-            else:
-                ov.upload()
+            elif args.no_stream or args.dist_path:
+                ov.upload()               # (the unstreamed form: the whole read set first, then the kernels)
+            # else: po_overlaps_to_host finds the read set changed and streams it up itself, piece by piece under the kernels
             if timed:
                 pcie["h2d_s"] += time.perf_counter() - t_a
         if world == 1 and not args.dist_path:
@@ -303,6 +305,9 @@ def main() -> int:
         if timed:
             for k in stage_keys:
                 acc[k] += st[k]
+            if inclusive and st.get("streamed"):
+                pcie["h2d_s"] += st["ms_upload"] * 1e-3   # first piece's copy starts -> last piece has landed (device events)
+                pcie["streamed_steps"] = pcie.get("streamed_steps", 0) + 1
         last.update(st)
         return n
 
@@ -361,7 +366,10 @@ def main() -> int:
                                    % (args.config, cfg.n_reads, cfg.read_len, cfg.genome_len, cfg.ploidy,
                                       cfg.snp, cfg.seed, n_oriented, m),
                        "n_reads": cfg.n_reads, "read_len": cfg.read_len, "min_length": m,
-                       "timed_region": ("host to host per step: po_invalidate + po_upload (H2D of the packed reads) + po_overlaps_to_host (kernels, D2H of the rows pipelined chunk by chunk) + po_result_rows"
+                       "timed_region": (("host to host per step: po_invalidate + po_overlaps_to_host (the changed read set is streamed host -> device piece by piece while "
+                                         "the pieces that have arrived go through the kernels and their rows travel device -> host) + po_result_rows"
+                                         if not args.no_stream else
+                                         "host to host per step: po_invalidate + po_upload (H2D of the packed reads) + po_overlaps_to_host (kernels, D2H of the rows pipelined chunk by chunk) + po_result_rows")
                                         if world == 1 and not args.dist_path else
                                         "host to host per step, every rank: po_invalidate + sharded upload (po_upload_piece: 1/N of the packed reads over this rank's PCIe link, "
                                         "one all-gather over xGMI, po_upload_assemble) + po_candidates_shard + one all-gather of verified candidates + po_expand (all rows on every GPU) "
@@ -469,9 +477,19 @@ def main() -> int:
                            "d2h_alone_ms_at_measured_h2d_rate": d2h_bytes / (h2d_bytes / (pcie["h2d_s"] / K)) * 1e3 if pcie["h2d_s"] > 0 else None,
                            "peak_GBps_per_direction": 64.0,
                            "pcie_floor_ms": (h2d_bytes + d2h_bytes) / 64e9 * 1e3,
-                           "note": "h2d = wall time of po_upload inside the timed region; the D2H of the rows is pipelined behind the "
-                                   "kernels inside po_overlaps_to_host (chunk k travels while chunk k + 1 is computed); "
-                                   "PCIe Gen5 x16 = 64 GB/s per direction, pcie_floor = both transfers at that rate, back to back"}
+                           "pcie_floor_duplex_ms": max(h2d_bytes, d2h_bytes) / 64e9 * 1e3,
+                           "streamed": bool(pcie.get("streamed_steps")),
+                           "deferred_containments": int(last.get("n_deferred", 0)),
+                           "note": ("streamed step: the packed reads go up piece by piece (h2d_ms = first copy starts -> last piece landed, device events) "
+                                    "while the pieces that have arrived are scanned, verified and emitted and their rows travel home -- PCIe carries both "
+                                    "directions at once, so kernels_plus_d2h_ms overlaps h2d_ms and the two do not add up to ms_per_step. "
+                                    if pcie.get("streamed_steps") else
+                                    "h2d = wall time of po_upload inside the timed region; the D2H of the rows is pipelined behind the "
+                                    "kernels inside po_overlaps_to_host (chunk k travels while chunk k + 1 is computed); ") +
+                                   "PCIe Gen5 x16 = 64 GB/s per direction; pcie_floor = both transfers at that rate back to back, pcie_floor_duplex = the longer of the two alone"}
+            if pcie.get("streamed_steps"):
+                out["pcie"]["kernels_plus_d2h_ms"] = None
+                out["pcie"]["after_upload_ms"] = dt / K * 1e3 - pcie["h2d_s"] / K * 1e3   # what is left of a step once the last piece has landed
             if not args.no_tuples:
                 # what the reference API returns: a list of (id_a, id_b, astart, aend, bstart, bend) tuples
                 t1 = time.perf_counter()

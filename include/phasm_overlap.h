@@ -91,6 +91,8 @@ typedef struct {
                                  /*    1 = lane-per-candidate DP kernel, 0 = wave-per-candidate (lane per diagonal)     */
     uint64_t upload_bytes;       /* bytes the last po_upload moved host->device (half the packed set when every   */
                                  /* odd read is the reverse complement of its even partner: the device rebuilds them) */
+    uint32_t streamed;           /* po_overlaps_to_host: 1 = streamed step (reads uploaded piece by piece under the      */
+    uint32_t n_deferred;         /*    kernels); n_deferred = containment candidates that waited for a later piece       */
 } po_stats;
 
 /* ExactOverlapper()  -- src/overlapper.cpp:19, py::init at src/phasm.cpp:13. */

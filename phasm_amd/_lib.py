@@ -62,6 +62,7 @@ class PoStats(ctypes.Structure):
         ("verify_bytes_exec", ctypes.c_uint64), ("dp_steps", ctypes.c_uint64), ("dp_stopped", ctypes.c_uint64),
         ("max_diff", ctypes.c_uint32), ("band", ctypes.c_uint32), ("index_reused", ctypes.c_uint32),
         ("dp_lanes", ctypes.c_uint32), ("upload_bytes", ctypes.c_uint64),
+        ("streamed", ctypes.c_uint32), ("n_deferred", ctypes.c_uint32),
     ]
 
     def as_dict(self) -> dict:

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -55,6 +56,8 @@ struct HostBuf {
 enum { EV_START = 0, EV_INDEX, EV_COUNT, EV_FILL, EV_VERIFY, EV_SELECT, EV_EMIT, EV_PROBE0, EV_PROBE1, EV_VER0, EV_VER1, EV_N };
 
 }  // namespace
+
+constexpr int PO_MAX_PIECES = 16;
 
 struct po_handle {
     int device = 0;
@@ -117,7 +120,24 @@ struct po_handle {
     // po_overlaps_ex: the verify step is the banded DP of extend.hip.h (set around the call by po_overlaps_ex)
     // po_overlaps_to_host: a second stream copies chunk k's rows to the host while chunk k + 1 is computed
     hipStream_t copy_stream = nullptr;
-    DevBuf chunk_rows[4];
+    DevBuf chunk_rows[PO_MAX_PIECES + 1];
+    // streamed step (po_overlaps_to_host on a changed read set): the packed reads cross PCIe piece by piece on
+    // up_stream while the pieces that have arrived go through the kernels and their rows travel back
+    hipStream_t up_stream = nullptr;
+    hipEvent_t ev_piece[PO_MAX_PIECES] = {};
+    HostBuf first_host;            // first packed word of every read (pinned), valid for first_n reads
+    uint32_t first_n = 0;
+    // per-read metadata of the upload, kept page-locked while the read set is unchanged (reads are only ever appended):
+    // [woff x n | len x n | first tile x (n + 1)]; meta_n = reads it covers, meta_bits = encoding it was counted for
+    HostBuf meta_host;
+    uint32_t meta_n = 0xFFFFFFFFu;
+    int meta_bits = 0;
+    uint64_t elig_n = ~0ull, elig_val = 0;   // reads of length >= elig_m among the first elig_n (cache of a 100 k-iteration loop)
+    uint32_t elig_m = 0;
+    DevBuf d_first, d_defer;
+    uint32_t defer_need = 0;       // deferred containment candidates the last streamed call produced
+    bool st_on = false;            // run_overlaps works on piece [st_r_begin, st_r_end) of a streamed step
+    uint32_t st_r_begin = 0, st_r_end = 0, st_defer_cap = 0;
     uint64_t last_host_rows = 0;   // rows of the previous po_overlaps_to_host call (sizes the pinned buffer up front)
     // the anchor index of the last call, reusable while the device copy of the reads and the parameters it was built
     // for are unchanged (the chunks of po_overlaps_to_host, the shards of a multi-GPU step, repeated calls)
@@ -456,6 +476,19 @@ bool packed_is_revcomp(const po_handle* h, size_t r) {
 
 inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// reads that can take part in an overlap of m bases or more
+uint64_t count_eligible(po_handle* h, uint32_t m) {
+    const uint64_t n = h->len.size();
+    if (h->elig_n != n || h->elig_m != m) {
+        uint64_t c = 0;
+        for (uint64_t r = 0; r < n; ++r) c += h->len[r] >= m;
+        h->elig_n = n;
+        h->elig_m = m;
+        h->elig_val = c;
+    }
+    return h->elig_val;
+}
+
 void shard_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint32_t* r_begin, uint32_t* r_end, uint64_t* bases);
 
 // words of host store 0 (the even reads) that belong to shard `shard` of `nshards`: [*begin, *begin + *count)
@@ -470,25 +503,39 @@ void store0_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint64_t
     *count = w1 > w0 ? w1 - w0 : 0;
 }
 
-po_status upload(po_handle* h) {
-    PO_TRY(init_device(h));
-    if (!h->dirty) return PO_OK;
+// Everything of an upload but the packed words themselves: scan tiles counted, device buffers sized, per-read
+// offsets / lengths / tile numbers copied, tile records built on the device (they need no read data).
+po_status upload_meta(po_handle* h, bool* generate_out) {
     const uint32_t n = (uint32_t)h->len.size();
     const size_t per = 64 / h->bits;
     // tiles: 64 words each, never spanning reads.  The host only counts them (first tile of every read); the
-    // 32-byte records are written on the device (k_build_tiles) instead of travelling over PCIe (25 MB at config 2)
-    h->h_read_tile0.assign((size_t)n + 1, 0);
-    h->max_len = 0;
-    uint64_t nt = 0;
-    for (uint32_t r = 0; r < n; ++r) {
-        h->h_read_tile0[r] = (uint32_t)nt;
-        h->max_len = std::max(h->max_len, h->len[r]);
-        const size_t nw = (h->len[r] + per - 1) / per;
-        nt += (nw + po::TILE_WORDS - 1) / po::TILE_WORDS;
-        if (nt > 0x7FFFFF00ull / po::WAVE) return fail(h, PO_ERR_CAPACITY, "too many scan tiles");
+    // 32-byte records are written on the device (k_build_tiles) instead of travelling over PCIe (25 MB at config 2).
+    // Counted once per state of the read set, together with a page-locked copy of the per-read arrays (an async copy
+    // out of a std::vector goes through the runtime's staging buffer, synchronously).
+    if (h->meta_n != n || h->meta_bits != h->bits || !h->meta_host.p) {
+        h->h_read_tile0.assign((size_t)n + 1, 0);
+        h->max_len = 0;
+        uint64_t nt = 0;
+        for (uint32_t r = 0; r < n; ++r) {
+            h->h_read_tile0[r] = (uint32_t)nt;
+            h->max_len = std::max(h->max_len, h->len[r]);
+            const size_t nw = (h->len[r] + per - 1) / per;
+            nt += (nw + po::TILE_WORDS - 1) / po::TILE_WORDS;
+            if (nt > 0x7FFFFF00ull / po::WAVE) return fail(h, PO_ERR_CAPACITY, "too many scan tiles");
+        }
+        h->h_read_tile0[n] = (uint32_t)nt;
+        h->n_tiles = (uint32_t)nt;
+        PO_TRY(ensure_host(h, h->meta_host, (size_t)n * 16 + 64));
+        char* mh = static_cast<char*>(h->meta_host.p);
+        if (n) {
+            std::memcpy(mh, h->woff.data(), (size_t)n * 8);
+            std::memcpy(mh + (size_t)n * 8, h->len.data(), (size_t)n * 4);
+        }
+        std::memcpy(mh + (size_t)n * 12, h->h_read_tile0.data(), ((size_t)n + 1) * 4);
+        h->meta_n = n;
+        h->meta_bits = h->bits;
     }
-    h->h_read_tile0[n] = (uint32_t)nt;
-    h->n_tiles = (uint32_t)nt;
+    const char* mh = static_cast<const char*>(h->meta_host.p);
 
     // Device buffer: [store 0 | store 1 | 72 zero words] (a scan tile may read 64+1 words past a read's start).
     // Only store 0 travels when every odd read is the reverse complement of its even partner: store 1 is then
@@ -497,6 +544,7 @@ po_status upload(po_handle* h) {
     const uint64_t nwords = base1 + h->words[1].size() + 72;
     const bool generate = h->bits == 2 && n >= 2 && (n % 2) == 0 && h->all_pairs_rc && h->exc_pos.empty() &&
                           !getenv("PHASM_FULL_UPLOAD");
+    *generate_out = generate;
     h->base1 = base1;
     h->dev_words = nwords;
     pin_words(h, 0);
@@ -512,6 +560,31 @@ po_status upload(po_handle* h) {
     HIP_TRY(h, hipMemsetAsync(dw + base1 + h->words[1].size(), 0, 72 * 8, h->stream));
     if (base1 != h->words[0].size()) HIP_TRY(h, hipMemsetAsync(dw + h->words[0].size(), 0, 8, h->stream));
     h->upload_bytes = 0;
+    if (n) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_woff.p, mh, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_len.p, mh + (size_t)n * 8, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+        h->upload_bytes += (size_t)n * 12;
+        // store-relative offsets -> offsets into the device buffer
+        hipLaunchKernelGGL(po::k_abs_woff, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, h->d_woff.as<uint64_t>(), n, base1);
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_read_tile0.p, mh + (size_t)n * 12, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, h->stream));
+    h->upload_bytes += ((size_t)n + 1) * 4;
+    if (h->n_tiles) {
+        hipLaunchKernelGGL(po::k_build_tiles, dim3(cdiv(h->n_tiles, 256)), dim3(256), 0, h->stream, h->d_woff.as<uint64_t>(),
+                           h->d_len.as<uint32_t>(), h->d_read_tile0.as<uint32_t>(), n, h->n_tiles, h->d_tiles.as<po::TileRec>());
+    }
+    HIP_TRY(h, hipGetLastError());
+    return PO_OK;
+}
+
+po_status upload(po_handle* h) {
+    PO_TRY(init_device(h));
+    if (!h->dirty) return PO_OK;
+    const uint32_t n = (uint32_t)h->len.size();
+    bool generate = false;
+    PO_TRY(upload_meta(h, &generate));
+    uint64_t* dw = h->d_words.as<uint64_t>();
+    const uint64_t base1 = h->base1;
     if (h->asm_pieces) {
         // sharded upload: piece k = the store-0 words of shard k's reads, uploaded by rank k, gathered over xGMI
         if (!generate) return fail(h, PO_ERR_INVALID, "po_upload_assemble needs reads added as (x, reverse complement of x) pairs");
@@ -529,18 +602,9 @@ po_status upload(po_handle* h) {
         HIP_TRY(h, hipMemcpyAsync(dw + base1, h->words[1].data(), h->words[1].size() * 8, hipMemcpyHostToDevice, h->stream));
         h->upload_bytes += h->words[1].size() * 8;
     }
-    if (n) {
-        HIP_TRY(h, hipMemcpyAsync(h->d_woff.p, h->woff.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->d_len.p, h->len.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-        h->upload_bytes += (size_t)n * 12;
-        // store-relative offsets -> offsets into the device buffer
-        hipLaunchKernelGGL(po::k_abs_woff, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, h->d_woff.as<uint64_t>(), n, base1);
-    }
-    HIP_TRY(h, hipMemcpyAsync(h->d_read_tile0.p, h->h_read_tile0.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, h->stream));
-    h->upload_bytes += ((size_t)n + 1) * 4;
     if (generate) {
         hipLaunchKernelGGL(po::k_revcomp_store, dim3(cdiv((uint64_t)(n / 2) * 64, 256)), dim3(256), 0, h->stream, dw,
-                           h->d_woff.as<uint64_t>(), h->d_len.as<uint32_t>(), n / 2);
+                           h->d_woff.as<uint64_t>(), h->d_len.as<uint32_t>(), 0u, n / 2);
         if (getenv("PHASM_VERIFY_GENERATED") && !h->words[1].empty()) {
             // test mode: the host's own store 1 is uploaded next to the generated one and compared word by word
             DevBuf tmp;
@@ -557,10 +621,6 @@ po_status upload(po_handle* h) {
                 return fail(h, PO_ERR_HIP, "generated reverse-complement store differs from the host's in " +
                                                std::to_string(h->pinned[0]) + " words");
         }
-    }
-    if (h->n_tiles) {
-        hipLaunchKernelGGL(po::k_build_tiles, dim3(cdiv(h->n_tiles, 256)), dim3(256), 0, h->stream, h->d_woff.as<uint64_t>(),
-                           h->d_len.as<uint32_t>(), h->d_read_tile0.as<uint32_t>(), n, h->n_tiles, h->d_tiles.as<po::TileRec>());
     }
     HIP_TRY(h, hipGetLastError());
     // exception records (2-bit mode only; usually none)
@@ -665,7 +725,12 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     const bool dp = h->ex_on;
     const uint32_t dpE = dp ? h->ex_E : 0u, dpW = dp && h->ex_E ? h->ex_W : 0u;
     // (inexact extension: every candidate is extended itself, no strand-mirror shortcut)
-    const uint32_t paired = (BITS == 2 && h->paired && dpE == 0) ? (nshards > 1 ? 2u : 1u) : 0u;
+    // 3 = reversed index order, a piece of a streamed step (kernels.hip.h, mirror_rank): the scan keeps containment
+    // candidates of any b, the verify kernel only those whose b has arrived (b < st_r_end)
+    const bool streamed = h->st_on;
+    const uint32_t paired = (BITS == 2 && h->paired && dpE == 0) ? (streamed ? po::PAIRED_STREAM_ALL : nshards > 1 ? 2u : 1u) : 0u;
+    const uint32_t paired_ver = streamed ? po::paired_stream(h->st_r_end) : paired;
+    if (streamed && (!paired || want_cands)) return fail(h, PO_ERR_INVALID, "streamed step without strand pairs");
     S.paired = paired ? 1u : 0u;
     S.max_diff = dpE;
     S.band = dpW;
@@ -675,13 +740,19 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
 
     uint32_t r_begin = 0, r_end = n;
     S.shard_bases = h->total_bases;
-    if (nshards > 1) shard_range(h, shard, nshards, &r_begin, &r_end, &S.shard_bases);
+    if (streamed) {
+        r_begin = h->st_r_begin;
+        r_end = h->st_r_end;
+        S.shard_bases = 0;
+        for (uint32_t r = r_begin; r < r_end; ++r) S.shard_bases += h->len[r];
+    } else if (nshards > 1) {
+        shard_range(h, shard, nshards, &r_begin, &r_end, &S.shard_bases);
+    }
     const uint32_t tile_begin = h->h_read_tile0[r_begin], tile_end = h->h_read_tile0[r_end];
     const uint32_t ntiles = tile_end - tile_begin;
     S.n_tiles = ntiles;
 
-    uint64_t n_elig = 0;
-    for (uint32_t r = 0; r < n; ++r) n_elig += h->len[r] >= m;
+    const uint64_t n_elig = count_eligible(h, m);
     S.n_eligible = n_elig;
     res->count = 0;
     if (n == 0 || n_elig == 0 || ntiles == 0) return PO_OK;
@@ -694,6 +765,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         if (!strcmp(e, "wide")) wide = m >= 2 * W - 1;
         if (!strcmp(e, "narrow")) wide = false;
     }
+    if (streamed && wide) return fail(h, PO_ERR_INVALID, "streamed step with the wide index");
     S.wide_index = wide ? 1u : 0u;
     bool WA_ext = false;
     const bool slice_build = h->sl_build_n > 1;     // build one sub-table of the sliced wide index, then stop
@@ -902,10 +974,12 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     } else {
         const size_t scan_lds = (size_t)scan_waves * po::SCAN_LDS_PER_WAVE + bloom_bytes;
         if (scan_lds > h->lds_max) return fail(h, PO_ERR_HIP, "device LDS too small for the scan kernel");
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan_probe<BITS, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_scan_probe<BITS, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
+        // (a streamed step -- 2-bit reads only -- has its own instantiations: the reversed pair order is a compile-time choice)
+        constexpr bool CAN_STREAM = BITS == 2;
+        auto probe_full = streamed ? po::k_scan_probe<BITS, true, CAN_STREAM> : po::k_scan_probe<BITS, true, false>;
+        auto probe_part = streamed ? po::k_scan_probe<BITS, false, CAN_STREAM> : po::k_scan_probe<BITS, false, false>;
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(probe_full), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(probe_part), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
         const uint32_t n_scan_waves = scan_grid * scan_waves;
         PO_TRY(ensure(h, h->d_left, (size_t)n_scan_waves * po::LEFT_CAP * sizeof(uint2)));
         PO_TRY(ensure(h, h->d_left_cnt, (size_t)n_scan_waves * 4));
@@ -916,12 +990,10 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         A.left_cnt = h->d_left_cnt.as<uint32_t>();
         A.tile_extra = h->d_tile_extra.as<uint32_t>();
         HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE0], st));
-        if (K == W)
-            hipLaunchKernelGGL((po::k_scan_probe<BITS, true>), dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
-        else
-            hipLaunchKernelGGL((po::k_scan_probe<BITS, false>), dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
+        hipLaunchKernelGGL(K == W ? probe_full : probe_part, dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
         HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
-        hipLaunchKernelGGL((po::k_scan_fixup<BITS>), dim3(n_scan_waves), dim3(256), 0, st, A, n_scan_waves);
+        auto fixup = streamed ? po::k_scan_fixup<BITS, CAN_STREAM> : po::k_scan_fixup<BITS, false>;
+        hipLaunchKernelGGL(fixup, dim3(n_scan_waves), dim3(256), 0, st, A, n_scan_waves);
         hipLaunchKernelGGL(po::k_add_extra, dim3(cdiv(ntiles, 256)), dim3(256), 0, st, A.tile_count, A.tile_extra, tile_begin,
                            tile_end);
         if (getenv("PHASM_DEBUG_LEFT")) {  // how many positions did the scan waves defer to k_scan_fixup?
@@ -955,7 +1027,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     HIP_TRY(h, hipStreamSynchronize(st));
     const uint64_t n_cand64 = h->pinned[1];
     uint32_t n_selfrep_reads = (uint32_t)h->pinned[8];
-    if (nshards > 1 || wide || dpE) n_selfrep_reads |= 1u;  // k_select_local may hand repetitive reads to the global selection
+    if (nshards > 1 || streamed || wide || dpE) n_selfrep_reads |= 1u;  // k_select_local may hand repetitive reads to the global selection
     S.n_candidates = n_cand64;
     if (n_cand64 >= 0xFFFFFF00ull)
         return fail(h, PO_ERR_CAPACITY, "candidate count " + std::to_string(n_cand64) + " exceeds one call's capacity (2^32)");
@@ -979,7 +1051,13 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             WA.cand_b = A.cand_b;
             hipLaunchKernelGGL((po::k_wide_scan<BITS, true>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA);
         } else {
-            hipLaunchKernelGGL((po::k_scan_fill<BITS>), dim3(cdiv(ntiles, 4 * po::FILL_TILES)), dim3(256), 0, st, A);
+            auto fill = streamed ? po::k_scan_fill<BITS, BITS == 2> : po::k_scan_fill<BITS, false>;
+            hipLaunchKernelGGL(fill, dim3(cdiv(ntiles, 4 * po::FILL_TILES)), dim3(256), 0, st, A);
+        }
+        if (streamed && r_end < n) {
+            // containment candidates whose b has not arrived: onto the deferred list (the verify kernel skips them)
+            hipLaunchKernelGGL(po::k_defer_split, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_p, A.cand_b, n_cand,
+                               r_end, h->d_defer.as<po::Cand>(), h->st_defer_cap, h->d_defer.as<uint32_t>() + (size_t)h->st_defer_cap * 4);
         }
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(h->ev[EV_FILL], st));
@@ -1094,6 +1172,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             if (const char* e = getenv("PHASM_VERIFY_STAGED")) staged = staged && atoi(e) != 0;
             auto verify = paired == 2u ? (staged ? po::k_verify_a<BITS, true, true> : po::k_verify_a<BITS, true, false>)
                                        : (staged ? po::k_verify_a<BITS, false, true> : po::k_verify_a<BITS, false, false>);
+            if (streamed) verify = staged ? po::k_verify_a<BITS, false, true, BITS == 2> : po::k_verify_a<BITS, false, false, BITS == 2>;
             const uint32_t lds_words = (lds_words_raw + 1u) & ~1u;  // even: the records behind a sit on a 16-byte boundary
             const size_t ver_lds = (size_t)lds_words * 8 + (size_t)po::VREC_CAP * sizeof(po::VRec) + 16;
             if (ver_lds > 48 * 1024)
@@ -1101,7 +1180,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             HIP_TRY(h, hipEventRecord(h->ev[EV_VER0], st));
             hipLaunchKernelGGL(verify, dim3(ver_grid), dim3(po::VER_BLOCK), ver_lds, st,
                                words, woff, len, h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_p,
-                               A.cand_b, r_begin, lds_words, paired,
+                               A.cand_b, r_begin, lds_words, paired_ver,
                                h->n_exc_uploaded ? h->d_exc_off.as<uint32_t>() : nullptr, h->d_exc_pos.as<uint32_t>(),
                                h->d_exc_byte.as<uint8_t>(), h->d_type.as<uint8_t>(), perm, n_a);
             HIP_TRY(h, hipEventRecord(h->ev[EV_VER1], st));
@@ -1127,7 +1206,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         uint32_t pbits = 0;
         uint32_t* n_deferred = reinterpret_cast<uint32_t*>(scalars + 1) + 1;  // reads k_select_local hands to the global table
         const uint32_t* gate = nullptr;
-        if (nshards > 1 || wide || dpE) {
+        if (nshards > 1 || streamed || wide || dpE) {
             static_assert(po::SEL_CAP == 512, "k_select_local hashes to 9 bits");
             hipLaunchKernelGGL(po::k_select_local, dim3(cdiv(r_end - r_begin, 256 / po::WAVE)), dim3(256), 0, st,
                                h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_b, h->d_type.as<uint8_t>(),
@@ -1137,7 +1216,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             // some read's prefix recurs inside it (or a read was too repetitive for k_select_local): A candidates
             // of such b may be non-longest duplicates
             uint32_t n_sus;
-            if ((nshards > 1 || wide) && n_cand < (4u << 20)) {
+            if ((nshards > 1 || streamed || wide) && n_cand < (4u << 20)) {
                 n_sus = n_cand;  // upper bound: no counting pass, no host round trip (a big call sizes its table exactly)
                 gate = n_deferred;  // ... and nothing of it is touched unless k_select_local handed a read over
             } else {
@@ -1789,6 +1868,16 @@ void po_destroy(po_handle* h) {
         h->spare_host.release();
         h->scratch_host.release();
         for (DevBuf& b : h->chunk_rows) b.release();
+        h->d_first.release();
+        h->d_defer.release();
+        h->first_host.release();
+        h->meta_host.release();
+        if (h->up_stream) {
+            (void)hipStreamSynchronize(h->up_stream);
+            (void)hipStreamDestroy(h->up_stream);
+        }
+        for (hipEvent_t e : h->ev_piece)
+            if (e) (void)hipEventDestroy(e);
         if (h->copy_stream) {
             (void)hipStreamSynchronize(h->copy_stream);
             (void)hipStreamDestroy(h->copy_stream);
@@ -2089,11 +2178,292 @@ po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out) {
     return po_overlaps_shard(h, min_length, 0, 1, out);
 }
 
-// po_overlaps + po_result_rows in one call, pipelined: the a-side reads are cut into chunks (the shards of
-// po_overlaps_shard), and while chunk k + 1 goes through the kernels on the handle's stream, chunk k's rows travel
-// device -> host on a second stream into ONE page-locked array.  Same rows as po_overlaps as a multiset (sharded
-// calls pick the canonical member of a strand-mirror pair by the scrambled read order), in
-// a-major order chunk by chunk.  The result holds the host array only.
+// po_overlaps + po_result_rows in one call, pipelined.  Two forms:
+//
+// * the reads are on the device already: the a-side reads are cut into chunks (the shards of po_overlaps_shard), and
+//   while chunk k + 1 goes through the kernels on the handle's stream, chunk k's rows travel device -> host on a
+//   second stream into ONE page-locked array;
+// * the read set changed since the last upload (what the reference's overlaps() faces every time: the reads are host
+//   memory, overlapper.cpp:22-36): the STREAMED step.  The packed reads cross PCIe in pieces, in index order, on a
+//   third stream; as soon as piece k is there, its reads are scanned against the whole index (built from every read's
+//   first word, which travels ahead: 8 bytes per read), and the pairs whose b-side read has arrived are verified
+//   and emitted -- the reversed index order of kernels.hip.h (mirror_rank, mode 3) picks the member of every
+//   strand-mirror pair whose b lies at or below its a, so every suffix-prefix candidate of piece k is of that kind --
+//   and piece k's rows travel back while piece k + 1 is still coming in: PCIe carries both directions at once.
+//   Containments of a read that has not arrived are the only candidates that must wait (the deferred list).
+//
+// Same rows as po_overlaps as a multiset (which member of a strand-mirror pair is computed differs, the emitted
+// pair of rows does not), a-major chunk by chunk.  The result holds the host array only.
+namespace {
+
+struct HostRows {
+    HostBuf hb;
+    uint64_t total = 0;
+};
+
+// rows of one chunk: room in the page-locked array, then the copy on the copy stream (dev must stay untouched
+// until that stream has been synchronised)
+po_status append_rows(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t nk, uint32_t k, uint32_t n_chunks) {
+    if (nk == 0) return PO_OK;
+    const size_t need = (size_t)(R.total + nk) * sizeof(po_row);
+    if (need > R.hb.cap) {
+        // first call, or more rows than last time: guess the whole from what has been seen, move what is there
+        const uint64_t guess = std::max<uint64_t>(h->last_host_rows, (R.total + nk) * n_chunks / (k + 1));
+        HostBuf bigger;
+        PO_TRY(ensure_host(h, bigger, std::max<size_t>(need, (size_t)(guess + guess / 8) * sizeof(po_row))));
+        if (hipStreamSynchronize(h->copy_stream) != hipSuccess) {
+            bigger.release();
+            return fail(h, PO_ERR_HIP, "copy stream");
+        }
+        if (R.total) std::memcpy(bigger.p, R.hb.p, (size_t)R.total * sizeof(po_row));
+        R.hb.release();
+        R.hb = bigger;
+    }
+    HIP_TRY(h, hipMemcpyAsync(static_cast<char*>(R.hb.p) + (size_t)R.total * sizeof(po_row), dev.p, (size_t)nk * sizeof(po_row),
+                              hipMemcpyDeviceToHost, h->copy_stream));
+    R.total += nk;
+    return PO_OK;
+}
+
+void add_stats(po_stats& sum, const po_stats& S) {
+    sum.n_candidates += S.n_candidates;
+    sum.n_verified += S.n_verified;
+    sum.n_rows += S.n_rows;
+    sum.sum_overlap_bases += S.sum_overlap_bases;
+    sum.verify_bytes_algo += S.verify_bytes_algo;
+    sum.verify_bytes_exec += S.verify_bytes_exec;
+    sum.n_tiles += S.n_tiles;
+    sum.shard_bases += S.shard_bases;
+    sum.ms_index += S.ms_index;
+    sum.ms_scan_count += S.ms_scan_count;
+    sum.ms_scan_fill += S.ms_scan_fill;
+    sum.ms_verify += S.ms_verify;
+    sum.ms_select += S.ms_select;
+    sum.ms_emit += S.ms_emit;
+    sum.ms_total += S.ms_total;
+    sum.ms_scan_probe += S.ms_scan_probe;
+    sum.ms_verify_kernel += S.ms_verify_kernel;
+}
+
+// chunk k of a call emits into its own device buffer (kept on the handle): it must outlive its copy
+po_status run_chunk(po_handle* h, uint32_t min_length, uint32_t k, uint32_t n_chunks, uint64_t* nk) {
+    po_result part;
+    part.h = h;
+    if (h->chunk_rows[k].p) {
+        h->spare_rows.release();
+        h->spare_rows = h->chunk_rows[k];
+        h->chunk_rows[k] = DevBuf();
+    }
+    const po_status st = h->bits == 2 ? run_overlaps<2>(h, min_length, k, n_chunks, false, &part)
+                                      : run_overlaps<8>(h, min_length, k, n_chunks, false, &part);
+    h->chunk_rows[k] = part.d_rows;   // (run_overlaps returned: this chunk's rows are complete on the device)
+    part.d_rows = DevBuf();
+    *nk = part.count;
+    return st;
+}
+
+// May this call take the streamed form?  (the index flavour is decided as run_overlaps decides it)
+bool stream_eligible(const po_handle* h, uint32_t min_length) {
+    const uint32_t n = (uint32_t)h->len.size();
+    if (!h->dirty || h->bits != 2 || n < 4 || (n % 2) != 0 || !h->all_pairs_rc || !h->exc_pos.empty()) return false;
+    if (h->asm_pieces || h->ex_on || h->sl_build_n > 1 || h->ext_index) return false;
+    if (getenv("PHASM_FULL_UPLOAD") || getenv("PHASM_NO_MIRROR") || h->poison >= 0) return false;   // (poison mode rebuilds the index per call)
+    bool want = n >= 8192 && h->total_bases >= (64ull << 20);
+    if (const char* e = getenv("PHASM_STREAM")) want = atoi(e) != 0;
+    if (!want) return false;
+    const uint32_t m = min_length ? min_length : 1;
+    const uint64_t n_elig = count_eligible(const_cast<po_handle*>(h), m);
+    if (n_elig == 0) return false;
+    bool wide = n_elig > 160000 && m >= 2 * 32 - 1;
+    if (const char* e = getenv("PHASM_INDEX")) {
+        if (!strcmp(e, "wide")) wide = m >= 2 * 32 - 1;
+        if (!strcmp(e, "narrow")) wide = false;
+    }
+    return !wide;
+}
+
+// piece boundaries (even read indices, first 0, last n): cut points in thousandths of the packed store.  Pair (a, b)
+// can be computed once both reads are there, so the work released by a piece grows with its position -- the last
+// pieces are made small, their rows are what is left to send home after the upload has ended.
+std::vector<uint32_t> stream_bounds(const po_handle* h) {
+    const uint32_t n = (uint32_t)h->len.size();
+    std::vector<uint32_t> cuts = {180, 340, 480, 600, 700, 790, 870, 940};
+    if (const char* e = getenv("PHASM_STREAM_CUTS")) {
+        cuts.clear();
+        for (const char* q = e; *q;) {
+            char* endp = nullptr;
+            const long v = strtol(q, &endp, 10);
+            if (endp == q) break;
+            if (v > 0 && v < 1000 && (cuts.empty() || (uint32_t)v > cuts.back()) && cuts.size() + 1 < (size_t)PO_MAX_PIECES) cuts.push_back((uint32_t)v);
+            q = *endp ? endp + 1 : endp;
+        }
+    }
+    std::vector<uint32_t> b{0};
+    const uint64_t total = h->words[0].size();
+    for (uint32_t c : cuts) {
+        const uint64_t target = total * c / 1000;
+        uint32_t lo = 0, hi = n / 2;   // smallest pair i with woff[2 i] >= target
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) / 2;
+            if (h->woff[2 * (size_t)mid] >= target) hi = mid; else lo = mid + 1;
+        }
+        if (2 * lo > b.back() && 2 * lo < n) b.push_back(2 * lo);
+    }
+    b.push_back(n);
+    return b;
+}
+
+// start of a streamed step: everything but the packed words goes up, the pieces are queued on up_stream (one event
+// each), every read's first word is put in place for the index
+po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
+    const uint32_t n = (uint32_t)h->len.size();
+    const uint32_t P = (uint32_t)bounds.size() - 1;
+    bool generate = false;
+    PO_TRY(upload_meta(h, &generate));
+    if (!generate) return fail(h, PO_ERR_INVALID, "streamed step on reads that are not (x, reverse complement of x) pairs");
+    if (!h->up_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
+    for (uint32_t k = 0; k < P; ++k)
+        if (!h->ev_piece[k]) HIP_TRY(h, hipEventCreate(&h->ev_piece[k]));
+    uint64_t* dw = h->d_words.as<uint64_t>();
+    HIP_TRY(h, hipEventRecord(h->ev_up0, h->up_stream));
+    for (uint32_t k = 0; k < P; ++k) {
+        const uint64_t wb = bounds[k] < n ? h->woff[bounds[k]] : h->words[0].size();
+        const uint64_t we = bounds[k + 1] < n ? h->woff[bounds[k + 1]] : h->words[0].size();
+        if (we > wb) {
+            HIP_TRY(h, hipMemcpyAsync(dw + wb, h->words[0].data() + wb, (we - wb) * 8, hipMemcpyHostToDevice, h->up_stream));
+            h->upload_bytes += (we - wb) * 8;
+        }
+        HIP_TRY(h, hipEventRecord(h->ev_piece[k], h->up_stream));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_up1, h->up_stream));
+    // first words (both strands: the host packed store 1 too, it just does not travel)
+    if (h->first_n != n || !h->first_host.p) {
+        PO_TRY(ensure_host(h, h->first_host, (size_t)n * 8));
+        uint64_t* f = static_cast<uint64_t*>(h->first_host.p);
+        for (uint32_t r = 0; r < n; ++r) f[r] = h->words[r & 1][h->woff[r]];   // (an empty read: its guard word, zero)
+        h->first_n = n;
+    }
+    PO_TRY(ensure(h, h->d_first, (size_t)n * 8));
+    HIP_TRY(h, hipMemcpyAsync(h->d_first.p, h->first_host.p, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    h->upload_bytes += (size_t)n * 8;
+    hipLaunchKernelGGL(po::k_scatter_first, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, dw, h->d_woff.as<uint64_t>(),
+                       h->d_first.as<uint64_t>(), n);
+    HIP_TRY(h, hipGetLastError());
+    // deferred containment list: [Cand x cap | counter]
+    h->st_defer_cap = std::max<uint32_t>(1u << 16, h->defer_need + h->defer_need / 2);
+    if (const char* e = getenv("PHASM_DEFER_CAP")) h->st_defer_cap = (uint32_t)std::max(1, atoi(e));   // (tests: force the overflow path)
+    PO_TRY(ensure(h, h->d_defer, (size_t)h->st_defer_cap * sizeof(po::Cand) + 16));
+    if (!getenv("PHASM_DEFER_CAP")) h->st_defer_cap = (uint32_t)std::min<size_t>((h->d_defer.cap - 16) / sizeof(po::Cand), 0xFFFFFF00u);
+    HIP_TRY(h, hipMemsetAsync(h->d_defer.as<char>() + (size_t)h->st_defer_cap * sizeof(po::Cand), 0, 16, h->stream));
+    h->n_exc_uploaded = 0;
+    h->paired = true;   // (checked word by word on the host as the reads arrived: all_pairs_rc)
+    ++h->upload_gen;
+    h->dirty = false;
+    return PO_OK;
+}
+
+// The streamed step.  *overflow: the deferred list was too small (nothing was handed out; the reads are resident now,
+// the caller takes the chunked form, and the next streamed call sizes the list by what this one counted).
+po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_stats& sum, bool* overflow) {
+    *overflow = false;
+    const uint32_t n = (uint32_t)h->len.size();
+    const std::vector<uint32_t> bounds = stream_bounds(h);
+    const uint32_t P = (uint32_t)bounds.size() - 1;
+    const bool trace = getenv("PHASM_STREAM_TRACE") != nullptr;   // developer aid: host-clock marks of the pipeline on stderr
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    PO_TRY(stream_begin(h, bounds));
+    if (trace) std::fprintf(stderr, "[stream] %u pieces queued at %.3f ms\n", P, since());
+    uint64_t* dw = h->d_words.as<uint64_t>();
+    po_status st = PO_OK;
+    for (uint32_t k = 0; k < P && st == PO_OK; ++k) {
+        // piece k has landed -> its odd reads (reverse complements) are written next to it
+        if (hipStreamWaitEvent(h->stream, h->ev_piece[k], 0) != hipSuccess) { st = fail(h, PO_ERR_HIP, "hipStreamWaitEvent"); break; }
+        const uint32_t p0 = bounds[k] / 2, p1 = bounds[k + 1] / 2;
+        hipLaunchKernelGGL(po::k_revcomp_store, dim3(cdiv((uint64_t)(p1 - p0) * 64, 256)), dim3(256), 0, h->stream, dw,
+                           h->d_woff.as<uint64_t>(), h->d_len.as<uint32_t>(), p0, p1);
+        h->st_on = true;
+        h->st_r_begin = bounds[k];
+        h->st_r_end = bounds[k + 1];
+        uint64_t nk = 0;
+        st = run_chunk(h, min_length, k, P, &nk);
+        h->st_on = false;
+        if (st != PO_OK) break;
+        add_stats(sum, h->stats);
+        st = append_rows(h, R, h->chunk_rows[k], nk, k, P);
+        if (trace) {
+            float up = 0;
+            (void)hipEventElapsedTime(&up, h->ev_up0, h->ev_piece[k]);
+            std::fprintf(stderr, "[stream] piece %u reads [%u, %u): landed %.3f ms after the first copy started, kernels done at %.3f ms (device %.3f ms: scan %.3f verify %.3f), %llu rows (%.1f MB) queued for home\n",
+                         k, bounds[k], bounds[k + 1], up, since(), h->stats.ms_total, h->stats.ms_scan_count + h->stats.ms_scan_fill,
+                         h->stats.ms_verify, (unsigned long long)nk, nk * 24e-6);
+        }
+    }
+    if (st != PO_OK) {
+        (void)hipStreamSynchronize(h->up_stream);
+        h->dirty = true;   // (a piece may be missing on the device)
+        return st;
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, h->ev_up0, h->ev_up1);   // (every piece was waited for: both events have happened)
+    h->stats.ms_upload = ms;
+    // ---- the deferred containments: every read is there now
+    HIP_TRY(h, hipMemcpyAsync(h->pinned + 40, h->d_defer.as<char>() + (size_t)h->st_defer_cap * sizeof(po::Cand), 8,
+                              hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const uint32_t n_def = (uint32_t)h->pinned[40];
+    h->defer_need = n_def;
+    if (n_def > h->st_defer_cap) {
+        *overflow = true;
+        return PO_OK;
+    }
+    if (n_def) {
+        hipStream_t s = h->stream;
+        po::Cand* list = h->d_defer.as<po::Cand>();
+        PO_TRY(ensure(h, h->d_rowcnt, (size_t)n_def));
+        PO_TRY(ensure(h, h->d_row_off, ((size_t)n_def + 1) * 4));
+        HIP_TRY(h, hipEventRecord(h->ev[EV_START], s));
+        hipLaunchKernelGGL(po::k_verify_flat, dim3(cdiv((uint64_t)n_def * 64, 256)), dim3(256), 0, s, dw, h->d_woff.as<uint64_t>(),
+                           h->d_len.as<uint32_t>(), list, n_def);
+        hipLaunchKernelGGL(po::k_deferred_rowcnt, dim3(cdiv(n_def, 256)), dim3(256), 0, s, list, n_def, 1u, h->d_rowcnt.as<uint8_t>());
+        HIP_TRY(h, hipGetLastError());
+        PO_TRY(prefix_sum<uint8_t>(h, h->d_rowcnt.as<uint8_t>(), n_def, h->d_row_off.as<uint32_t>(), &h->pinned[2]));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        const uint64_t n_rows = h->pinned[2];
+        if (n_rows) {
+            PO_TRY(ensure(h, h->chunk_rows[P], n_rows * sizeof(po_row)));
+            unsigned long long* scalars = h->d_scalars.as<unsigned long long>();
+            HIP_TRY(h, hipMemsetAsync(scalars + 4, 0, 32, s));
+            hipLaunchKernelGGL(po::k_emit_cands, dim3(std::min<uint32_t>(cdiv(n_def, 256), (uint32_t)h->n_cu * 16)), dim3(256), 0, s,
+                               list, h->d_rowcnt.as<uint8_t>(), h->d_row_off.as<uint32_t>(), n_def, h->d_len.as<uint32_t>(),
+                               h->chunk_rows[P].as<po::Row>(), 2u, 1u, scalars + 4);
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipMemcpyAsync(h->pinned + 4, scalars + 4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipEventRecord(h->ev[EV_EMIT], s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+            float ms_def = 0;
+            (void)hipEventElapsedTime(&ms_def, h->ev[EV_START], h->ev[EV_EMIT]);
+            sum.n_verified += h->pinned[4];
+            sum.sum_overlap_bases += h->pinned[5];
+            sum.verify_bytes_algo += h->pinned[6];
+            sum.verify_bytes_exec += h->pinned[7];
+            sum.n_rows += n_rows;
+            sum.ms_verify += ms_def;
+            sum.ms_total += ms_def;
+            PO_TRY(append_rows(h, R, h->chunk_rows[P], n_rows, P, P + 1));
+        }
+    }
+    (void)n;
+    if (trace) {
+        std::fprintf(stderr, "[stream] deferred list settled at %.3f ms (%u candidates)\n", since(), n_def);
+        (void)hipStreamSynchronize(h->copy_stream);
+        std::fprintf(stderr, "[stream] last row home at %.3f ms\n", since());
+    }
+    return PO_OK;
+}
+
+}  // namespace
+
 po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out) {
     if (!h || !out) return PO_ERR_INVALID;
     *out = nullptr;
@@ -2105,77 +2475,48 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
     if (!r) return fail(h, PO_ERR_NOMEM, "out of host memory");
     r->h = h;
     po_status st = PO_OK;
-    HostBuf hb;
-    uint64_t total = 0;
+    HostRows R;
     po_stats sum = {};
+    bool streamed = false;
+    float ms_upload = 0;
     try {
-        st = upload(h);
+        st = init_device(h);
         if (st == PO_OK && !h->copy_stream && hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess)
             st = fail(h, PO_ERR_HIP, "cannot create the copy stream");
         if (st == PO_OK && h->spare_host.p) {   // the pinned array of an earlier result, if there is one
-            hb = h->spare_host;
+            R.hb = h->spare_host;
             h->spare_host = HostBuf();
         }
-        for (uint32_t k = 0; k < n_chunks && st == PO_OK; ++k) {
-            po_result part;
-            part.h = h;
-            // chunk k emits into its own device buffer (kept on the handle): it must outlive its copy
-            if (h->chunk_rows[k].p) {
-                h->spare_rows.release();
-                h->spare_rows = h->chunk_rows[k];
-                h->chunk_rows[k] = DevBuf();
+        if (st == PO_OK && stream_eligible(h, min_length)) {
+            bool overflow = false;
+            st = overlaps_streamed(h, min_length, R, sum, &overflow);
+            ms_upload = h->stats.ms_upload;
+            if (st == PO_OK && !overflow) {
+                streamed = true;
+            } else if (st == PO_OK) {
+                // (rare: more containments of later reads than the list holds -- the reads are resident now)
+                if (hipStreamSynchronize(h->copy_stream) != hipSuccess) st = fail(h, PO_ERR_HIP, "copy stream");
+                R.total = 0;
+                sum = po_stats();
             }
-            st = h->bits == 2 ? run_overlaps<2>(h, min_length, k, n_chunks, false, &part)
-                              : run_overlaps<8>(h, min_length, k, n_chunks, false, &part);
-            h->chunk_rows[k] = part.d_rows;   // (run_overlaps returned: this chunk's rows are complete on the device)
-            part.d_rows = DevBuf();
+        }
+        if (st == PO_OK && !streamed) st = upload(h);
+        for (uint32_t k = 0; k < n_chunks && st == PO_OK && !streamed; ++k) {
+            uint64_t nk = 0;
+            st = run_chunk(h, min_length, k, n_chunks, &nk);
             if (st != PO_OK) break;
-            const po_stats& S = h->stats;
-            sum.n_candidates += S.n_candidates;
-            sum.n_verified += S.n_verified;
-            sum.n_rows += S.n_rows;
-            sum.sum_overlap_bases += S.sum_overlap_bases;
-            sum.verify_bytes_algo += S.verify_bytes_algo;
-            sum.verify_bytes_exec += S.verify_bytes_exec;
-            sum.n_tiles += S.n_tiles;
-            sum.shard_bases += S.shard_bases;
-            sum.ms_index += S.ms_index;
-            sum.ms_scan_count += S.ms_scan_count;
-            sum.ms_scan_fill += S.ms_scan_fill;
-            sum.ms_verify += S.ms_verify;
-            sum.ms_select += S.ms_select;
-            sum.ms_emit += S.ms_emit;
-            sum.ms_total += S.ms_total;
-            sum.ms_scan_probe += S.ms_scan_probe;
-            sum.ms_verify_kernel += S.ms_verify_kernel;
-            const uint64_t nk = part.count;
-            if (nk == 0) continue;
-            const size_t need = (size_t)(total + nk) * sizeof(po_row);
-            if (need > hb.cap) {
-                // first call, or more rows than last time: guess the whole from what has been seen, move what is there
-                const uint64_t guess = std::max<uint64_t>(h->last_host_rows, (total + nk) * n_chunks / (k + 1));
-                HostBuf bigger;
-                st = ensure_host(h, bigger, std::max<size_t>(need, (size_t)(guess + guess / 8) * sizeof(po_row)));
-                if (st != PO_OK) break;
-                if (hipStreamSynchronize(h->copy_stream) != hipSuccess) { st = fail(h, PO_ERR_HIP, "copy stream"); bigger.release(); break; }
-                if (total) std::memcpy(bigger.p, hb.p, (size_t)total * sizeof(po_row));
-                hb.release();
-                hb = bigger;
-            }
-            if (hipMemcpyAsync(static_cast<char*>(hb.p) + (size_t)total * sizeof(po_row), h->chunk_rows[k].p,
-                               (size_t)nk * sizeof(po_row), hipMemcpyDeviceToHost, h->copy_stream) != hipSuccess) {
-                st = fail(h, PO_ERR_HIP, "row copy device->host");
-                break;
-            }
-            total += nk;
+            add_stats(sum, h->stats);
+            st = append_rows(h, R, h->chunk_rows[k], nk, k, n_chunks);
         }
     } catch (const std::bad_alloc&) {
         st = fail(h, PO_ERR_NOMEM, "out of host memory in po_overlaps_to_host");
     }
+    h->st_on = false;
     if (h->dev_ready) (void)hipStreamSynchronize(h->stream);
+    if (h->up_stream) (void)hipStreamSynchronize(h->up_stream);
     if (h->copy_stream && hipStreamSynchronize(h->copy_stream) != hipSuccess && st == PO_OK) st = fail(h, PO_ERR_HIP, "row copy device->host");
     if (st != PO_OK) {
-        hb.release();
+        R.hb.release();
         delete r;
         return st;
     }
@@ -2198,14 +2539,20 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
     S.ms_total = sum.ms_total;
     S.ms_scan_probe = sum.ms_scan_probe;
     S.ms_verify_kernel = sum.ms_verify_kernel;
-    h->last_host_rows = total;
-    r->count = total;
+    S.streamed = streamed ? 1u : 0u;
+    S.n_deferred = streamed ? h->defer_need : 0u;
+    if (streamed) {
+        S.ms_upload = ms_upload;
+        S.upload_bytes = h->upload_bytes;
+    }
+    h->last_host_rows = R.total;
+    r->count = R.total;
     r->unique_twins = h->bits == 2 && h->paired;   // (chunks are a-major and disjoint in a: groups stay adjacent)
-    if (total) {
-        r->host = hb.p;
-        r->host_cap = hb.cap;
-    } else if (hb.p) {
-        h->spare_host = hb;   // nothing to hand out: keep the buffer
+    if (R.total) {
+        r->host = R.hb.p;
+        r->host_cap = R.hb.cap;
+    } else if (R.hb.p) {
+        h->spare_host = R.hb;   // nothing to hand out: keep the buffer
     }
     ++h->live_results;
     *out = r;

@@ -182,15 +182,30 @@ __device__ inline uint32_t mirror_rank(uint32_t x, uint32_t paired) {
 __device__ inline bool canonical_pair(uint32_t a, uint32_t c, uint32_t paired) {
     return mirror_rank(a, paired) <= mirror_rank(c, paired);
 }
+//   3  REVERSED index order, a >= c (streamed calls, po_overlaps_to_host on reads that are still travelling to the
+//      device piece by piece in index order): the kept member of a pair has its b-side read at or below a | 1, i.e.
+//      in a piece that has arrived when a's piece is scanned.  Containments (B) can name any b: the bits above the
+//      mode carry b_limit = (paired >> 2), the first read NOT on the device yet; a B candidate at or beyond it is
+//      kept by the scan (limit = all ones there), dropped by the verify kernel (limit = end of the piece) and
+//      settled from the deferred list once every piece has arrived (k_defer_split, k_verify_flat).
+//      A compile-time choice (STREAM) in every kernel that evaluates it: the hand-scheduled scan kernel must keep the
+//      code it has for orders 1 and 2 (tools/check_scan_isa.py).
+constexpr uint32_t PAIRED_STREAM_ALL = 0xFFFFFFFFu;  // mode 3, no limit
+__device__ __host__ inline uint32_t paired_stream(uint32_t b_limit) { return 3u | (b_limit << 2); }
 
 // Which rows can candidate (a, p, b) give, and is it the member of its strand-mirror pair that this
 // library computes?  bit0: A (suffix of a = prefix of b; needs la-p <= lb), bit1: B (b inside a;
 // needs la-p >= lb).  Paired mode keeps A only for the canonical member and B only for a on the + strand;
 // k_emit writes the mirrored rows.  A read never pairs with itself (overlapper.cpp:72,:103).
+template <bool STREAM = false>
 __device__ inline uint32_t keep_bits(uint32_t a, uint32_t b, uint32_t rem, uint32_t lb, uint32_t paired) {
     if (a == b) return 0;
-    return ((rem <= lb && (!paired || canonical_pair(a, b ^ 1u, paired))) ? 1u : 0u) |
-           ((rem >= lb && (!paired || (a & 1u) == 0u)) ? 2u : 0u);
+    if constexpr (STREAM) {
+        return ((rem <= lb && a >= (b ^ 1u)) ? 1u : 0u) | ((rem >= lb && (a & 1u) == 0u && b < (paired >> 2)) ? 2u : 0u);
+    } else {
+        return ((rem <= lb && (!paired || canonical_pair(a, b ^ 1u, paired))) ? 1u : 0u) |
+               ((rem >= lb && (!paired || (a & 1u) == 0u)) ? 2u : 0u);
+    }
 }
 
 // The narrow anchor table is probed in aligned groups of PROBE_GROUP slots (64 bytes: one fetch settles a probe
@@ -730,18 +745,18 @@ __device__ inline uint32_t filter_tile(const uint32_t* __restrict__ s_bloom, uin
 // Candidates of one position p of read a, given the slot its K-mer found (z = start/read, w = count
 // word).  Calls f(b, lb, keep) for every chain entry that survives keep_bits().
 // (pointers by value: a reference to the kernel-argument struct would force it into scratch)
-template <typename F>
+template <bool STREAM = false, typename F>
 __device__ inline void for_each_candidate(const uint32_t* __restrict__ chain, const uint32_t* __restrict__ len,
                                           uint32_t paired, uint32_t z, uint32_t w, uint32_t a, uint32_t rem, F&& f) {
     if (w & SLOT_SINGLE) {
         const uint32_t lb = w & ~SLOT_SINGLE;
-        const uint32_t k = keep_bits(a, z, rem, lb, paired);
+        const uint32_t k = keep_bits<STREAM>(a, z, rem, lb, paired);
         if (k) f(z, lb, k);
     } else {
         for (uint32_t j = 0; j < w; ++j) {
             const uint32_t b = chain[z + j];
             const uint32_t lb = len[b];
-            const uint32_t k = keep_bits(a, b, rem, lb, paired);
+            const uint32_t k = keep_bits<STREAM>(a, b, rem, lb, paired);
             if (k) f(b, lb, k);
         }
     }
@@ -773,7 +788,7 @@ constexpr int SCAN_LDS_PER_WAVE = 2 * WAVE * 4 + WAVE * 4;  // queue of position
 // that; it runs inside phasm_amd/build.py (a violating library is deleted, not shipped) and in the CPU tests, and was
 // validated against the code of hipcc 7.2.26015 (ROCm 7.2.0, AMD clang 22.0.0git) -- build.py:VALIDATED_HIPCC; the
 // test fails on any other compiler until the walk has been checked against its output.
-template <int BITS, bool FULLK>
+template <int BITS, bool FULLK, bool STREAM = false>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  // A stays in SGPRs: never take its address
     constexpr int W = 64 / BITS;
     extern __shared__ uint64_t smem[];
@@ -825,7 +840,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
                     if (chain[s.z + j] == a) note_selfrep(selfrep, a, p, n_selfrep);
             }
         }
-        for_each_candidate(chain, len, paired, s.z, s.w, a, la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
+        for_each_candidate<STREAM>(chain, len, paired, s.z, s.w, a, la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
         return n;
     };
     // Leftover list: a dependent load in the steady state would force `s_waitcnt vmcnt(0)` and drain the
@@ -1079,7 +1094,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
 // Settle the positions the scan waves deferred (k_scan_probe: third table slot needed, chain of several
 // reads, more than NPEND survivors in a lane): one thread each, ordinary dependent loads, results
 // added to the tile's truemask bit and candidate count.  Runs after k_scan_probe has retired every tile.
-template <int BITS>
+template <int BITS, bool STREAM = false>
 __global__ void k_scan_fixup(const ScanArgs A, uint32_t n_waves) {
     constexpr int W = 64 / BITS;
     // one workgroup of 256 threads per scan wave's list: every position is a chain of dependent loads, so the
@@ -1109,7 +1124,7 @@ __global__ void k_scan_fixup(const ScanArgs A, uint32_t n_waves) {
             }
         }
         uint32_t n = 0;
-        for_each_candidate(A.chain, A.len, A.paired, z, w, a, rec.la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
+        for_each_candidate<STREAM>(A.chain, A.len, A.paired, z, w, a, rec.la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
         if (n) {
             atomicOr(&A.truemask[(size_t)t * WAVE + ln], 1u << sft);
             atomicAdd(&A.tile_count[t], n);
@@ -1133,7 +1148,7 @@ __global__ void k_add_extra(uint32_t* __restrict__ tile_count, const uint32_t* _
 #endif
 constexpr int FILL_TILES = PO_FILL_TILES;
 
-template <int BITS>
+template <int BITS, bool STREAM = false>
 __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
     constexpr int W = 64 / BITS;
     __shared__ uint32_t q_src[4 * WAVE];
@@ -1185,11 +1200,11 @@ __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
         const uint32_t a = rec.read, la = rec.la;
         const uint32_t p = (rec.word0 + ln) * W + sft;
         uint32_t n = 0;
-        if (w) for_each_candidate(A.chain, A.len, A.paired, z, w, a, la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
+        if (w) for_each_candidate<STREAM>(A.chain, A.len, A.paired, z, w, a, la - p, [&](uint32_t, uint32_t, uint32_t) { ++n; });
         const uint32_t inc = wave_incl_scan(n);
         uint32_t off = out + inc - n;
         if (n) {
-            for_each_candidate(A.chain, A.len, A.paired, z, w, a, la - p, [&](uint32_t b, uint32_t, uint32_t) {
+            for_each_candidate<STREAM>(A.chain, A.len, A.paired, z, w, a, la - p, [&](uint32_t b, uint32_t, uint32_t) {
                 A.cand_a[off] = a;
                 A.cand_p[off] = p;
                 A.cand_b[off] = b;
@@ -1220,14 +1235,17 @@ __global__ __launch_bounds__(256) void k_read_label(const uint32_t* __restrict__
     if (i >= n_reads) return;  // (whole 16-lane groups leave together)
     const uint32_t a = r_begin + i;
     const uint32_t seg0 = tile_off[read_tile0[a]], seg1 = tile_off[read_tile0[a + 1]];
-    uint32_t best = mirror_rank(a, paired);
-    for (uint32_t c = seg0 + sub; c < seg1; c += 16) best = max(best, mirror_rank(cand_b[c] ^ 1u, paired));
+    const bool reversed = (paired & 3u) == 3u;   // (a streamed step's order: ~index)
+    auto rank = [&](uint32_t x) { return reversed ? ~x : mirror_rank(x, paired); };
+    uint32_t best = rank(a);
+    for (uint32_t c = seg0 + sub; c < seg1; c += 16) best = max(best, rank(cand_b[c] ^ 1u));
 #pragma unroll
     for (int o = 8; o >= 1; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o, 16));
     // the label is the top-ranked READ, whatever order ranked it: a scrambled rank (sharded calls) is turned back
     // into the read index, so that the sort's bins hold a few neighbouring indices in both modes -- binning the
     // scrambled rank's top bits put the 256 reads of an index block into one bin and lost the locality
     if (paired == 2u) best = (__brev(best & 0xFFFFFF00u) << 8) | (best & 0xFFu);
+    if (reversed) best = ~best;
     if (sub == 0) label[i] = best;
 }
 
@@ -1399,7 +1417,7 @@ __device__ __forceinline__ uint32_t group_bcast0(uint32_t v, uint32_t gshift) {
     }
 }
 
-template <int BITS, bool SCRAMBLED, bool IN_LDS, bool STAGED>
+template <int BITS, bool SCRAMBLED, bool IN_LDS, bool STAGED, bool STREAM = false>
 __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
                                            const uint32_t* __restrict__ len, const uint32_t* __restrict__ cand_p,
                                            const uint32_t* __restrict__ cand_b, uint32_t paired,
@@ -1487,7 +1505,7 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
             nbits = (lb & 0x7FFFFFFFu) * BITS;
         } else {
             const uint32_t rem = la - p;
-            keep = keep_bits(a, b, rem, lb, SCRAMBLED ? 2u : (paired ? 1u : 0u));
+            keep = STREAM ? keep_bits<true>(a, b, rem, lb, paired) : keep_bits(a, b, rem, lb, SCRAMBLED ? 2u : (paired ? 1u : 0u));
             const uint32_t n = rem < lb ? rem : lb;
             nbits = keep ? n * BITS : 0;
         }
@@ -1576,7 +1594,7 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
     })
 }
 
-template <int BITS, bool SCRAMBLED, bool STAGED>
+template <int BITS, bool SCRAMBLED, bool STAGED, bool STREAM = false>
 __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
                                                          const uint32_t* __restrict__ len,
                                                          const uint32_t* __restrict__ read_tile0,
@@ -1628,17 +1646,18 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
             for (uint32_t i = threadIdx.x; i < nb; i += VER_BLOCK) {
                 const uint32_t p = cand_p[batch0 + i], b = cand_b[batch0 + i];
                 const uint32_t lb = len[b], rem = la - p;
-                const uint32_t keep = keep_bits(a, b, rem, lb, SCRAMBLED ? 2u : (paired ? 1u : 0u));
+                const uint32_t keep = STREAM ? keep_bits<true>(a, b, rem, lb, paired)
+                                             : keep_bits(a, b, rem, lb, SCRAMBLED ? 2u : (paired ? 1u : 0u));
                 const uint32_t n = rem < lb ? rem : lb;
                 s_rec[i] = VRec{p | ((keep & 1u) << 31), b, keep ? (n | ((keep >> 1) << 31)) : 0u, (uint32_t)woff[b]};
             }
             if (threadIdx.x == 0) *s_next = batch0 + NGROUPS;  // the first candidate of every group is its position
             __syncthreads();
             if (in_lds)
-                verify_run<BITS, SCRAMBLED, true, true>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type,
+                verify_run<BITS, SCRAMBLED, true, true, STREAM>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type,
                                                         s_a, ga32, s_rec, s_next, a, la, batch0, batch0 + nb VST(, vt_start, vt));
             else
-                verify_run<BITS, SCRAMBLED, false, true>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type,
+                verify_run<BITS, SCRAMBLED, false, true, STREAM>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type,
                                                          s_a, ga32, s_rec, s_next, a, la, batch0, batch0 + nb VST(, vt_start, vt));
         }
     } else {
@@ -1646,10 +1665,10 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
         if (threadIdx.x == 0) *s_next = seg0 + 2 * NGROUPS;
         __syncthreads();
         if (in_lds)
-            verify_run<BITS, SCRAMBLED, true, false>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type,
+            verify_run<BITS, SCRAMBLED, true, false, STREAM>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type,
                                                      s_a, ga32, s_rec, s_next, a, la, seg0, seg1 VST(, vt_start, vt));
         else
-            verify_run<BITS, SCRAMBLED, false, false>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type,
+            verify_run<BITS, SCRAMBLED, false, false, STREAM>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type,
                                                       s_a, ga32, s_rec, s_next, a, la, seg0, seg1 VST(, vt_start, vt));
     }
 }
@@ -2008,8 +2027,8 @@ __global__ __launch_bounds__(256) void k_paired_check(const uint64_t* __restrict
 // of read 2i+1 = the matching window of read 2i reversed (bit reverse + swap the two bits of every base) and
 // complemented (~), bits beyond the read's end cleared, plus the zero guard word -- bit for bit what the host packs.
 __global__ __launch_bounds__(256) void k_revcomp_store(uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
-                                                       const uint32_t* __restrict__ len, uint32_t n_pairs) {
-    const uint32_t pair = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                                                       const uint32_t* __restrict__ len, uint32_t pair0, uint32_t n_pairs) {
+    const uint32_t pair = pair0 + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6);   // pairs [pair0, n_pairs)
     if (pair >= n_pairs) return;
     const uint32_t lane = lane_id();
     const uint32_t L = len[2 * pair];
@@ -2037,6 +2056,62 @@ __global__ __launch_bounds__(256) void k_revcomp_store(uint64_t* __restrict__ wo
         }
         S[w] = out;
     }
+}
+
+// ---- streamed step (po_overlaps_to_host while the reads are still crossing PCIe piece by piece) ----------------
+// The index only needs every read's first word (its prefix K-mer, K <= 32 bases of a word-aligned read): those
+// travel first, 8 bytes per read, and are put where the reads will land.  The pieces later bring the same values.
+__global__ void k_scatter_first(uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
+                                const uint64_t* __restrict__ first, uint32_t n) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) words[woff[r]] = first[r];
+}
+
+// Containment candidates (B) whose b-side read has not arrived yet: the verify kernel leaves them alone
+// (keep_bits with the piece's b_limit); they are copied to one list and settled after the last piece.
+// counter[0] keeps counting past `cap`, so that the host learns how much room the list needed.
+__global__ void k_defer_split(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
+                              const uint32_t* __restrict__ cand_b, uint32_t n_cand, uint32_t b_limit, Cand* __restrict__ out,
+                              uint32_t cap, uint32_t* __restrict__ counter) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cand) return;
+    const uint32_t b = cand_b[i];
+    if (b < b_limit) return;
+    const uint32_t k = atomicAdd(counter, 1u);
+    if (k < cap) out[k] = Cand{cand_a[i], cand_p[i], b, 0u};
+}
+
+// The deferred list, once every read is on the device: is b (all of it) equal to a[p, p + len b)?  One wave per
+// candidate, lane l compares words l, l + 64, ... of b with the window of a behind p.  2-bit reads without exception
+// records only (the streamed step's precondition).  type = 2 (B row) or 0.
+__global__ __launch_bounds__(256) void k_verify_flat(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
+                                                     const uint32_t* __restrict__ len, Cand* __restrict__ cands, uint32_t n) {
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= n) return;   // (whole waves leave together)
+    const uint32_t lane = lane_id();
+    const Cand c = cands[i];
+    const uint32_t la = len[c.a], lb = len[c.b];
+    bool bad = c.p > la || la - c.p < lb || c.a == c.b || (c.a & 1u);   // (not a containment of this mode: no row)
+    if (!bad) {
+        const uint64_t* __restrict__ A = words + woff[c.a] + (c.p >> 5);
+        const uint64_t* __restrict__ B = words + woff[c.b];
+        const uint32_t sh = (c.p & 31u) * 2u, nw = (lb + 31u) >> 5;
+        for (uint32_t w = lane; w < nw; w += WAVE) {
+            uint64_t d = funnel(A[w], A[w + 1], sh) ^ B[w];   // (a's guard word keeps A[w + 1] in bounds)
+            if (w == nw - 1 && (lb & 31u)) d &= (1ull << ((lb & 31u) * 2u)) - 1ull;
+            bad |= d != 0;
+        }
+    }
+    const bool any_bad = __any(bad);
+    if (lane == 0) cands[i].type = any_bad ? 0u : 2u;
+}
+
+// rows of the settled deferred list (k_emit_cands writes them)
+__global__ void k_deferred_rowcnt(const Cand* __restrict__ cands, uint32_t n, uint32_t paired, uint8_t* __restrict__ rowcnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Cand c = cands[i];
+    rowcnt[i] = c.type ? (uint8_t)rows_of(c.type, c.a, c.b, paired) : (uint8_t)0;
 }
 
 // ----------------------------------------------------------------------------------------

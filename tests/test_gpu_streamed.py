@@ -1,0 +1,130 @@
+"""The streamed step of po_overlaps_to_host (reads uploaded piece by piece under the kernels, reversed strand-mirror
+order, deferred containments): the same rows as the goldens / the oracle for every cut of the read set into pieces."""
+import numpy as np
+import pytest
+
+import checker as ck
+import golden_utils as gu
+from oracle import overlap_oracle as oo   # row helpers only
+from phasm_amd.overlapper import ExactOverlapper
+
+pytestmark = pytest.mark.gpu
+
+CUTS = ["", "500", "250,500,750", "100,200,300,400,500,600,700,800,900", "30,60,90,120,150,180,210,240,270,300,900,950,990", "999"]
+
+
+def streamed_rows(seqs, m, calls=1):
+    ov = ExactOverlapper()
+    for i, s in enumerate(seqs):
+        ov.add_sequence("r%d" % i, s)
+    out = []
+    for _ in range(calls):
+        ov.invalidate()
+        res = ov.overlaps_to_host_result(m)
+        out.append((oo.sort_rows(oo.struct_to_rows(res.rows_view())), ov.stats()))
+        res.free()
+    ov.close()
+    return out
+
+
+@pytest.mark.parametrize("cuts", CUTS)
+def test_streamed_step_matches_the_goldens(cuts, monkeypatch):
+    monkeypatch.setenv("PHASM_STREAM", "1")
+    if cuts:
+        monkeypatch.setenv("PHASM_STREAM_CUTS", cuts)
+    n_streamed = 0
+    cases = [gu.ladder_case(name) for name in gu.LADDER_NAMES] + list(gu.repeats_cases()) + list(gu.all_small_cases())
+    for name, seqs, m, want in cases:
+        for got, st in streamed_rows(seqs, m, calls=2):
+            ck.assert_same_rows(got, want, seqs, m, "%s, cuts %r" % (name, cuts))
+            n_streamed += st["streamed"]
+            if st["streamed"]:
+                assert st["paired"] == 1 and st["n_rows"] == len(want)
+    assert n_streamed >= 2 * len(gu.LADDER_NAMES)   # every ladder case is a set of strand pairs of pure ACGT reads
+
+
+def _nested_reads(seed, n_reads, genome_len, lo, hi):
+    """reads of very different lengths from a short genome: many reads lie inside longer ones (containments), in
+    both index directions; every read is followed by its reverse complement"""
+    rng = np.random.default_rng(seed)
+    genome = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=genome_len))
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    seqs = []
+    for _ in range(n_reads):
+        ln = int(rng.integers(lo, hi))
+        s = int(rng.integers(0, genome_len - ln))
+        r = genome[s:s + ln]
+        seqs += [r, r.translate(comp)[::-1]]
+    return seqs
+
+
+@pytest.mark.parametrize("cuts", ["", "500", "200,400,600,800", "999"])
+def test_containments_of_reads_that_arrive_later_are_deferred(cuts, monkeypatch):
+    monkeypatch.setenv("PHASM_STREAM", "1")
+    if cuts:
+        monkeypatch.setenv("PHASM_STREAM_CUTS", cuts)
+    seqs = _nested_reads(20260, 150, 6000, 40, 1500)
+    m = 35
+    want = ck.oracle_overlaps(seqs, m)
+    (got, st), (got2, st2) = streamed_rows(seqs, m, calls=2)
+    assert st["streamed"] == 1 and st2["streamed"] == 1
+    if cuts != "999":
+        assert st["n_deferred"] > 0
+    ck.assert_same_rows(got, want, seqs, m, "nested reads, cuts %r" % cuts)
+    ck.assert_same_rows(got2, want, seqs, m, "nested reads, second call, cuts %r" % cuts)
+
+
+def test_deferred_list_overflow_falls_back_to_the_chunked_form(monkeypatch):
+    monkeypatch.setenv("PHASM_STREAM", "1")
+    monkeypatch.setenv("PHASM_STREAM_CUTS", "250,500,750")
+    monkeypatch.setenv("PHASM_DEFER_CAP", "3")
+    seqs = _nested_reads(77, 120, 5000, 40, 1200)
+    m = 35
+    want = ck.oracle_overlaps(seqs, m)
+    ov = ExactOverlapper()
+    for i, s in enumerate(seqs):
+        ov.add_sequence("r%d" % i, s)
+    res = ov.overlaps_to_host_result(m)
+    st = ov.stats()
+    assert st["streamed"] == 0          # the list overflowed: nothing of the streamed attempt was handed out
+    ck.assert_same_rows(oo.sort_rows(oo.struct_to_rows(res.rows_view())), want, seqs, m, "overflow fallback")
+    res.free()
+    monkeypatch.delenv("PHASM_DEFER_CAP")
+    ov.invalidate()
+    res = ov.overlaps_to_host_result(m)   # the next streamed call sizes the list by what the first one counted
+    st = ov.stats()
+    assert st["streamed"] == 1 and st["n_deferred"] > 3
+    ck.assert_same_rows(oo.sort_rows(oo.struct_to_rows(res.rows_view())), want, seqs, m, "after the overflow")
+    res.free()
+    ov.close()
+
+
+def test_streamed_fuzz_against_the_oracle(monkeypatch):
+    monkeypatch.setenv("PHASM_STREAM", "1")
+    rng = np.random.default_rng(4711)
+    for trial in range(12):
+        cuts = sorted(set(int(c) for c in rng.integers(1, 999, size=int(rng.integers(1, 9)))))
+        monkeypatch.setenv("PHASM_STREAM_CUTS", ",".join(str(c) for c in cuts))
+        n = int(rng.integers(4, 90))
+        glen = int(rng.integers(300, 4000))
+        seqs = _nested_reads(1000 + trial, n, glen, 20, max(40, glen // 3))
+        if trial % 3 == 0:   # a few exact duplicates and a period-3 repeat read
+            seqs += seqs[:4] + [b"ACG" * 60, b"CGT" * 60]
+        m = int(rng.integers(1, 60))
+        want = ck.oracle_overlaps(seqs, m)
+        (got, st), = streamed_rows(seqs, m)
+        assert st["streamed"] == 1
+        ck.assert_same_rows(got, want, seqs, m, "fuzz trial %d, cuts %s, m %d" % (trial, cuts, m))
+
+
+def test_streamed_step_is_not_taken_for_reads_it_cannot_serve(monkeypatch):
+    monkeypatch.setenv("PHASM_STREAM", "1")
+    rng = np.random.default_rng(5)
+    genome = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=3000))
+    plain = [genome[int(s):int(s) + 400] for s in rng.integers(0, 2600, size=20)]   # not strand pairs
+    withn = _nested_reads(9, 10, 2000, 100, 500)
+    withn[4] = withn[4][:50] + b"N" + withn[4][51:]                                  # exception record
+    for seqs in (plain, withn):
+        (got, st), = streamed_rows(seqs, 30)
+        assert st["streamed"] == 0
+        ck.assert_same_rows(got, ck.oracle_overlaps(seqs, 30), seqs, 30, "not streamed")
