@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <string>
 #include <system_error>
@@ -53,7 +54,7 @@ struct HostBuf {
     }
 };
 
-enum { EV_START = 0, EV_INDEX, EV_COUNT, EV_FILL, EV_VERIFY, EV_SELECT, EV_EMIT, EV_PROBE0, EV_PROBE1, EV_VER0, EV_VER1, EV_N };
+enum { EV_START = 0, EV_INDEX, EV_COUNT, EV_FILL, EV_VERIFY, EV_SELECT, EV_EMIT, EV_PROBE0, EV_PROBE1, EV_VER0, EV_VER1, EV_DONE, EV_N };
 
 }  // namespace
 
@@ -63,9 +64,11 @@ struct po_handle {
     int device = 0;
     bool dev_ready = false;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[EV_N] = {};
+    hipEvent_t ev_sets[2][EV_N] = {};   // (two sets: the pieces of a streamed step alternate, a piece's stage times are read one piece later)
+    hipEvent_t* ev = ev_sets[0];
     hipEvent_t ev_up0 = nullptr, ev_up1 = nullptr;
-    uint64_t* pinned = nullptr;  // host-pinned landing zone for device totals/counters (8 x u64)
+    uint64_t* pinned = nullptr;  // host-pinned landing zone for device totals/counters (64 x u64)
+    uint64_t* pinned_dev = nullptr;  // the same memory as the device sees it (kernels write totals there directly)
     int n_cu = 256;
     size_t lds_max = 64 * 1024;
     std::string err;
@@ -136,6 +139,16 @@ struct po_handle {
     uint32_t elig_m = 0;
     DevBuf d_first, d_defer;
     uint32_t defer_need = 0;       // deferred containment candidates the last streamed call produced
+    // a piece whose kernels are queued but whose row count has not been read yet (run_overlaps returned without the
+    // closing synchronisation: the next piece's first host wait covers it, st_harvest then sends its rows home)
+    struct Pending {
+        bool valid = false;
+        uint32_t k = 0;
+        po_stats S = {};
+        bool ver_timed = false;
+        hipEvent_t* ev = nullptr;
+    } st_pend;
+    std::function<po_status()> st_harvest;
     bool st_on = false;            // run_overlaps works on piece [st_r_begin, st_r_end) of a streamed step
     uint32_t st_r_begin = 0, st_r_end = 0, st_defer_cap = 0;
     uint64_t last_host_rows = 0;   // rows of the previous po_overlaps_to_host call (sizes the pinned buffer up front)
@@ -294,10 +307,11 @@ po_status init_device(po_handle* h) {
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->lds_max = prop.sharedMemPerBlock;
     HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    for (int i = 0; i < EV_N; ++i) HIP_TRY(h, hipEventCreate(&h->ev[i]));
+    for (int i = 0; i < 2 * EV_N; ++i) HIP_TRY(h, hipEventCreate(&h->ev_sets[i / EV_N][i % EV_N]));
     HIP_TRY(h, hipEventCreate(&h->ev_up0));
     HIP_TRY(h, hipEventCreate(&h->ev_up1));
     HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->pinned), 512, hipHostMallocDefault));
+    HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pinned_dev), h->pinned, 0));
     if (const char* e = getenv("PHASM_POISON")) h->poison = (int)(strtol(e, nullptr, 0) & 0xFF);
     h->dev_ready = true;
     return PO_OK;
@@ -687,19 +701,63 @@ void shard_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint32_t*
 // exclusive scan of n items (u8 or u32) -> u32 offsets; *total_host gets the grand total
 // (a pinned slot: valid after the next hipStreamSynchronize)
 template <typename T>
-po_status prefix_sum(po_handle* h, const T* in, uint64_t n, uint32_t* out, volatile uint64_t* total_host) {
+po_status prefix_sum(po_handle* h, const T* in, uint64_t n, uint32_t* out, volatile uint64_t* total_host,
+                     const uint64_t* also_src = nullptr, volatile uint64_t* also_host = nullptr) {
     *total_host = 0;
     if (n == 0) return PO_OK;
     const uint32_t nblocks = cdiv(n, po::PS_TILE);
     PO_TRY(ensure(h, h->d_ps_blocks, (size_t)nblocks * 8));
     uint64_t* blocks = h->d_ps_blocks.as<uint64_t>();
     uint64_t* total_dev = h->d_scalars.as<uint64_t>();
+    uint64_t* total_mapped = h->pinned_dev + (const_cast<uint64_t*>(total_host) - h->pinned);   // the slot as the device sees it
     hipLaunchKernelGGL(po::k_ps_reduce<T>, dim3(nblocks), dim3(po::PS_BLOCK), 0, h->stream, in, n, blocks);
-    hipLaunchKernelGGL(po::k_ps_spine, dim3(1), dim3(1024), 0, h->stream, blocks, nblocks, total_dev);
+    uint64_t* also_mapped = also_host ? h->pinned_dev + (const_cast<uint64_t*>(also_host) - h->pinned) : nullptr;
+    hipLaunchKernelGGL(po::k_ps_spine, dim3(1), dim3(1024), 0, h->stream, blocks, nblocks, total_dev, total_mapped, also_src, also_mapped);
     hipLaunchKernelGGL(po::k_ps_down<T>, dim3(nblocks), dim3(po::PS_BLOCK), 0, h->stream, in, n, blocks, out);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(const_cast<uint64_t*>(total_host), total_dev, 8, hipMemcpyDeviceToHost, h->stream));
     return PO_OK;
+}
+
+// one-workgroup form for short u32 inputs (kernels.hip.h, k_ps_small); `extra` is added into `in` first, `also_src`
+// (a device counter) lands in the pinned slot `also_host`
+po_status prefix_sum_small(po_handle* h, uint32_t* in, const uint32_t* extra, uint32_t n, uint32_t* out, volatile uint64_t* total_host,
+                           const uint64_t* also_src, volatile uint64_t* also_host) {
+    *total_host = 0;
+    if (n == 0) return PO_OK;
+    uint64_t* total_mapped = h->pinned_dev + (const_cast<uint64_t*>(total_host) - h->pinned);
+    uint64_t* also_mapped = also_host ? h->pinned_dev + (const_cast<uint64_t*>(also_host) - h->pinned) : nullptr;
+    hipLaunchKernelGGL(po::k_ps_small, dim3(1), dim3(1024), 0, h->stream, in, extra, n, out, h->d_scalars.as<uint64_t>(), total_mapped,
+                       also_src, also_mapped);
+    HIP_TRY(h, hipGetLastError());
+    return PO_OK;
+}
+
+void stage_times(po_stats& S, hipEvent_t* ev, bool ver_timed) {
+    (void)hipEventElapsedTime(&S.ms_index, ev[EV_START], ev[EV_INDEX]);
+    (void)hipEventElapsedTime(&S.ms_scan_count, ev[EV_INDEX], ev[EV_COUNT]);
+    (void)hipEventElapsedTime(&S.ms_scan_fill, ev[EV_COUNT], ev[EV_FILL]);
+    (void)hipEventElapsedTime(&S.ms_verify, ev[EV_FILL], ev[EV_VERIFY]);
+    (void)hipEventElapsedTime(&S.ms_select, ev[EV_VERIFY], ev[EV_SELECT]);
+    (void)hipEventElapsedTime(&S.ms_emit, ev[EV_SELECT], ev[EV_EMIT]);
+    (void)hipEventElapsedTime(&S.ms_total, ev[EV_START], ev[EV_EMIT]);
+    (void)hipEventElapsedTime(&S.ms_scan_probe, ev[EV_PROBE0], ev[EV_PROBE1]);
+    S.ms_verify_kernel = 0.f;
+    if (ver_timed) (void)hipEventElapsedTime(&S.ms_verify_kernel, ev[EV_VER0], ev[EV_VER1]);
+}
+
+// the closing part of run_overlaps for a pending piece of a streamed step; the handle's stream has been synchronised
+// since the piece was queued.  Returns the piece's row count.
+uint64_t finish_piece(po_handle* h) {
+    po_handle::Pending& P = h->st_pend;
+    const uint64_t n_rows = h->pinned[2];
+    P.S.n_rows = n_rows;
+    P.S.n_verified = h->pinned[4];
+    P.S.sum_overlap_bases = h->pinned[5];
+    P.S.verify_bytes_algo = h->pinned[6];
+    P.S.verify_bytes_exec = h->pinned[7];
+    stage_times(P.S, P.ev, P.ver_timed);
+    P.valid = false;
+    return n_rows;
 }
 
 template <int BITS>
@@ -851,8 +909,12 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                              !getenv("PHASM_NO_INDEX_REUSE");
     S.index_reused = reuse_index ? 1u : 0u;
     h->idx_valid = false;
-    if (reuse_index || ext_idx) {
-        hipLaunchKernelGGL(po::k_call_reset, dim3(cdiv(std::max(n, 8u), 256)), dim3(256), 0, st, selfrep, n, scalars);
+    // (narrow scan on a reused index: the reset kernel also clears the scan's two small per-call arrays, below)
+    const bool fold_clear = reuse_index && !wide;
+    if (fold_clear) {
+    } else if (reuse_index || ext_idx) {
+        hipLaunchKernelGGL(po::k_call_reset, dim3(cdiv(std::max(n, 8u), 256)), dim3(256), 0, st, selfrep, n, scalars,
+                           (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, 0u);
     } else {
         const uint32_t bloom_words = (uint32_t)(bloom_bytes / 4);
         const uint32_t init_n = std::max(std::max(nslots, n), std::max(bloom_words, 8u));
@@ -983,9 +1045,14 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         const uint32_t n_scan_waves = scan_grid * scan_waves;
         PO_TRY(ensure(h, h->d_left, (size_t)n_scan_waves * po::LEFT_CAP * sizeof(uint2)));
         PO_TRY(ensure(h, h->d_left_cnt, (size_t)n_scan_waves * 4));
-        HIP_TRY(h, hipMemsetAsync(h->d_left_cnt.p, 0, (size_t)n_scan_waves * 4, st));
         PO_TRY(ensure(h, h->d_tile_extra, ((size_t)h->n_tiles + 1) * 4));
-        HIP_TRY(h, hipMemsetAsync(h->d_tile_extra.as<uint32_t>() + tile_begin, 0, (size_t)ntiles * 4, st));
+        if (fold_clear) {
+            hipLaunchKernelGGL(po::k_call_reset, dim3(cdiv(std::max(std::max(n, 8u), std::max(n_scan_waves, ntiles)), 256)), dim3(256), 0, st,
+                               selfrep, n, scalars, h->d_left_cnt.as<uint32_t>(), n_scan_waves, h->d_tile_extra.as<uint32_t>() + tile_begin, ntiles);
+        } else {
+            HIP_TRY(h, hipMemsetAsync(h->d_left_cnt.p, 0, (size_t)n_scan_waves * 4, st));
+            HIP_TRY(h, hipMemsetAsync(h->d_tile_extra.as<uint32_t>() + tile_begin, 0, (size_t)ntiles * 4, st));
+        }
         A.left = h->d_left.as<uint2>();
         A.left_cnt = h->d_left_cnt.as<uint32_t>();
         A.tile_extra = h->d_tile_extra.as<uint32_t>();
@@ -994,8 +1061,9 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
         auto fixup = streamed ? po::k_scan_fixup<BITS, CAN_STREAM> : po::k_scan_fixup<BITS, false>;
         hipLaunchKernelGGL(fixup, dim3(n_scan_waves), dim3(256), 0, st, A, n_scan_waves);
-        hipLaunchKernelGGL(po::k_add_extra, dim3(cdiv(ntiles, 256)), dim3(256), 0, st, A.tile_count, A.tile_extra, tile_begin,
-                           tile_end);
+        if (ntiles > po::PS_SMALL_MAX)   // (short tile ranges: folded into the one-workgroup prefix sum below)
+            hipLaunchKernelGGL(po::k_add_extra, dim3(cdiv(ntiles, 256)), dim3(256), 0, st, A.tile_count, A.tile_extra, tile_begin,
+                               tile_end);
         if (getenv("PHASM_DEBUG_LEFT")) {  // how many positions did the scan waves defer to k_scan_fixup?
             PO_TRY(ensure_host(h, h->scratch_host, (size_t)n_scan_waves * 4));
             HIP_TRY(h, hipMemcpyAsync(h->scratch_host.p, h->d_left_cnt.p, (size_t)n_scan_waves * 4, hipMemcpyDeviceToHost, st));
@@ -1021,9 +1089,22 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                          sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5], sum[3] / sum[5], sum[4] / sum[5], sum[5]);
     }
 #endif
-    PO_TRY(prefix_sum<uint32_t>(h, A.tile_count + tile_begin, ntiles, h->d_tile_off.as<uint32_t>() + tile_begin, &h->pinned[1]));
-    HIP_TRY(h, hipMemcpyAsync(h->pinned + 8, scalars + 2, 8, hipMemcpyDeviceToHost, st));
+    if (ntiles <= po::PS_SMALL_MAX) {
+        PO_TRY(prefix_sum_small(h, A.tile_count + tile_begin, wide ? nullptr : A.tile_extra + tile_begin, ntiles,
+                                h->d_tile_off.as<uint32_t>() + tile_begin, &h->pinned[1],
+                                reinterpret_cast<const uint64_t*>(scalars + 2), &h->pinned[8]));
+    } else {
+        PO_TRY(prefix_sum<uint32_t>(h, A.tile_count + tile_begin, ntiles, h->d_tile_off.as<uint32_t>() + tile_begin, &h->pinned[1],
+                                    reinterpret_cast<const uint64_t*>(scalars + 2), &h->pinned[8]));
+    }
     HIP_TRY(h, hipEventRecord(h->ev[EV_COUNT], st));
+    if (h->st_pend.valid && h->st_harvest) {
+        // the previous piece of a streamed step returned with its kernels queued; this piece's counting pass is queued
+        // behind them now.  Wait for the previous piece alone, send its rows home, THEN wait for this piece's count:
+        // the device is never idle while the host does that, and the rows leave the moment they exist
+        HIP_TRY(h, hipEventSynchronize(h->st_pend.ev[EV_DONE]));
+        PO_TRY(h->st_harvest());
+    }
     HIP_TRY(h, hipStreamSynchronize(st));
     const uint64_t n_cand64 = h->pinned[1];
     uint32_t n_selfrep_reads = (uint32_t)h->pinned[8];
@@ -1313,10 +1394,22 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     HIP_TRY(h, hipEventRecord(h->ev[EV_EMIT], st));
     uint64_t* counters = h->pinned + 4;
     HIP_TRY(h, hipMemcpyAsync(counters, scalars + 4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    res->unique_twins = !want_cands && paired != 0 && !dpE;
+    HIP_TRY(h, hipEventRecord(h->ev[EV_DONE], st));
+    if (streamed && rows_late && h->st_harvest && !h->st_pend.valid) {
+        // a piece of a streamed step with its rows in a buffer known to be large enough: nothing here needs the host
+        // to wait -- the counts are read when the next piece waits for ITS candidate count (finish_piece)
+        h->st_pend.valid = true;
+        h->st_pend.k = shard;
+        h->st_pend.S = S;
+        h->st_pend.ver_timed = ver_timed;
+        h->st_pend.ev = h->ev;
+        res->count = 0;
+        return PO_OK;
+    }
     HIP_TRY(h, hipStreamSynchronize(st));
     if (rows_late) n_rows64 = h->pinned[2];  // (<= worst_rows < 2^32 by construction of the fast path)
     res->count = n_rows64;
-    res->unique_twins = !want_cands && paired != 0 && !dpE;
     S.n_rows = want_cands ? 0 : n_rows64;
     S.n_verified = want_cands ? n_rows64 : counters[0];
     S.sum_overlap_bases = counters[1];
@@ -1326,16 +1419,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         S.dp_steps = h->pinned[32];
         S.dp_stopped = h->pinned[33];
     }
-    (void)hipEventElapsedTime(&S.ms_index, h->ev[EV_START], h->ev[EV_INDEX]);
-    (void)hipEventElapsedTime(&S.ms_scan_count, h->ev[EV_INDEX], h->ev[EV_COUNT]);
-    (void)hipEventElapsedTime(&S.ms_scan_fill, h->ev[EV_COUNT], h->ev[EV_FILL]);
-    (void)hipEventElapsedTime(&S.ms_verify, h->ev[EV_FILL], h->ev[EV_VERIFY]);
-    (void)hipEventElapsedTime(&S.ms_select, h->ev[EV_VERIFY], h->ev[EV_SELECT]);
-    (void)hipEventElapsedTime(&S.ms_emit, h->ev[EV_SELECT], h->ev[EV_EMIT]);
-    (void)hipEventElapsedTime(&S.ms_total, h->ev[EV_START], h->ev[EV_EMIT]);
-    (void)hipEventElapsedTime(&S.ms_scan_probe, h->ev[EV_PROBE0], h->ev[EV_PROBE1]);
-    S.ms_verify_kernel = 0.f;
-    if (ver_timed) (void)hipEventElapsedTime(&S.ms_verify_kernel, h->ev[EV_VER0], h->ev[EV_VER1]);
+    stage_times(S, h->ev, ver_timed);
     return PO_OK;
 }
 
@@ -1859,7 +1943,7 @@ void po_destroy(po_handle* h) {
                           &h->d_vlabel, &h->d_vrank, &h->d_vperm, &h->d_end_a, &h->d_end_b, &h->d_dpcnt, &h->d_lay_len, &h->d_lay_cnt, &h->d_rflag, &h->d_removed, &h->d_ekey, &h->d_ecnt,
                           &h->d_ewin, &h->d_eoff};
         for (DevBuf* b : bufs) b->release();
-        for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(h->ev[i]);
+        for (int i = 0; i < 2 * EV_N; ++i) (void)hipEventDestroy(h->ev_sets[i / EV_N][i % EV_N]);
         for (hipEvent_t e : h->ev_lay)
             if (e) (void)hipEventDestroy(e);
         (void)hipEventDestroy(h->ev_up0);
@@ -2267,7 +2351,7 @@ bool stream_eligible(const po_handle* h, uint32_t min_length) {
     const uint32_t n = (uint32_t)h->len.size();
     if (!h->dirty || h->bits != 2 || n < 4 || (n % 2) != 0 || !h->all_pairs_rc || !h->exc_pos.empty()) return false;
     if (h->asm_pieces || h->ex_on || h->sl_build_n > 1 || h->ext_index) return false;
-    if (getenv("PHASM_FULL_UPLOAD") || getenv("PHASM_NO_MIRROR") || h->poison >= 0) return false;   // (poison mode rebuilds the index per call)
+    if (getenv("PHASM_FULL_UPLOAD") || getenv("PHASM_NO_MIRROR")) return false;
     bool want = n >= 8192 && h->total_bases >= (64ull << 20);
     if (const char* e = getenv("PHASM_STREAM")) want = atoi(e) != 0;
     if (!want) return false;
@@ -2287,7 +2371,7 @@ bool stream_eligible(const po_handle* h, uint32_t min_length) {
 // pieces are made small, their rows are what is left to send home after the upload has ended.
 std::vector<uint32_t> stream_bounds(const po_handle* h) {
     const uint32_t n = (uint32_t)h->len.size();
-    std::vector<uint32_t> cuts = {180, 340, 480, 600, 700, 790, 870, 940};
+    std::vector<uint32_t> cuts = {150, 300, 450, 600, 730, 850, 940};   // (config 2: 5.24 ms per step; 5 to 10 pieces measure within 3 % of it)
     if (const char* e = getenv("PHASM_STREAM_CUTS")) {
         cuts.clear();
         for (const char* q = e; *q;) {
@@ -2325,6 +2409,11 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
     for (uint32_t k = 0; k < P; ++k)
         if (!h->ev_piece[k]) HIP_TRY(h, hipEventCreate(&h->ev_piece[k]));
     uint64_t* dw = h->d_words.as<uint64_t>();
+    if (h->poison >= 0) {
+        // (PHASM_POISON fills a fresh device buffer on the handle's stream: the pieces must not land under that fill)
+        HIP_TRY(h, hipEventRecord(h->ev_up1, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->up_stream, h->ev_up1, 0));
+    }
     HIP_TRY(h, hipEventRecord(h->ev_up0, h->up_stream));
     for (uint32_t k = 0; k < P; ++k) {
         const uint64_t wb = bounds[k] < n ? h->woff[bounds[k]] : h->words[0].size();
@@ -2376,6 +2465,27 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
     if (trace) std::fprintf(stderr, "[stream] %u pieces queued at %.3f ms\n", P, since());
     uint64_t* dw = h->d_words.as<uint64_t>();
     po_status st = PO_OK;
+    // a finished piece: statistics, rows queued for home.  Called by run_overlaps at the next piece's first host wait
+    // (a piece that emitted into a buffer known to be large enough returns with its kernels still queued), or below.
+    auto completed = [&](uint32_t k, const po_stats& S, uint64_t nk) -> po_status {
+        add_stats(sum, S);
+        PO_TRY(append_rows(h, R, h->chunk_rows[k], nk, k, P));
+        if (trace) {
+            float up = 0;
+            (void)hipEventElapsedTime(&up, h->ev_up0, h->ev_piece[k]);
+            std::fprintf(stderr, "[stream] piece %u reads [%u, %u): landed %.3f ms after the first copy started, rows counted at %.3f ms (device %.3f ms: scan %.3f verify %.3f), %llu rows (%.1f MB) queued for home\n",
+                         k, bounds[k], bounds[k + 1], up, since(), S.ms_total, S.ms_scan_count + S.ms_scan_fill, S.ms_verify,
+                         (unsigned long long)nk, nk * 24e-6);
+        }
+        return PO_OK;
+    };
+    h->st_pend.valid = false;
+    h->st_harvest = [&]() -> po_status {
+        const uint32_t k = h->st_pend.k;
+        const uint64_t nk = finish_piece(h);
+        return completed(k, h->st_pend.S, nk);
+    };
+    if (getenv("PHASM_STREAM_SYNC")) h->st_harvest = nullptr;   // (developer switch: every piece waits for its own end)
     for (uint32_t k = 0; k < P && st == PO_OK; ++k) {
         // piece k has landed -> its odd reads (reverse complements) are written next to it
         if (hipStreamWaitEvent(h->stream, h->ev_piece[k], 0) != hipSuccess) { st = fail(h, PO_ERR_HIP, "hipStreamWaitEvent"); break; }
@@ -2385,20 +2495,27 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
         h->st_on = true;
         h->st_r_begin = bounds[k];
         h->st_r_end = bounds[k + 1];
+        h->ev = h->ev_sets[k & 1];
         uint64_t nk = 0;
         st = run_chunk(h, min_length, k, P, &nk);
         h->st_on = false;
         if (st != PO_OK) break;
-        add_stats(sum, h->stats);
-        st = append_rows(h, R, h->chunk_rows[k], nk, k, P);
-        if (trace) {
-            float up = 0;
-            (void)hipEventElapsedTime(&up, h->ev_up0, h->ev_piece[k]);
-            std::fprintf(stderr, "[stream] piece %u reads [%u, %u): landed %.3f ms after the first copy started, kernels done at %.3f ms (device %.3f ms: scan %.3f verify %.3f), %llu rows (%.1f MB) queued for home\n",
-                         k, bounds[k], bounds[k + 1], up, since(), h->stats.ms_total, h->stats.ms_scan_count + h->stats.ms_scan_fill,
-                         h->stats.ms_verify, (unsigned long long)nk, nk * 24e-6);
+        if (h->st_pend.valid && h->st_pend.k == k) continue;   // piece k is queued, its counts are read later (an older one was collected inside)
+        if (h->st_pend.valid) {
+            // (piece k never waited for the device -- it had nothing to scan: the older piece is still to be collected)
+            if (hipStreamSynchronize(h->stream) != hipSuccess) { st = fail(h, PO_ERR_HIP, "stream"); break; }
+            st = h->st_harvest();
+            if (st != PO_OK) break;
         }
+        st = completed(k, h->stats, nk);   // piece k waited for its own end
     }
+    if (st == PO_OK && h->st_pend.valid) {
+        if (hipStreamSynchronize(h->stream) != hipSuccess) st = fail(h, PO_ERR_HIP, "stream");
+        else st = h->st_harvest();
+    }
+    h->st_harvest = nullptr;
+    h->st_pend.valid = false;
+    h->ev = h->ev_sets[0];
     if (st != PO_OK) {
         (void)hipStreamSynchronize(h->up_stream);
         h->dirty = true;   // (a piece may be missing on the device)

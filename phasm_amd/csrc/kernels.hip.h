@@ -282,10 +282,14 @@ __global__ void k_call_init(Slot* tab, uint32_t nslots, uint32_t* slot_cnt, uint
 }
 
 // the per-call part of k_call_init, for a call that reuses the index of the previous one
-__global__ void k_call_reset(uint32_t* selfrep, uint32_t n_reads, unsigned long long* scalars) {
+__global__ void k_call_reset(uint32_t* selfrep, uint32_t n_reads, unsigned long long* scalars, uint32_t* clear_a, uint32_t n_a,
+                             uint32_t* clear_b, uint32_t n_b) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_reads) selfrep[i] = NO_SELFREP;
     if (i < 8) scalars[i] = 0;
+    // (two small per-call arrays of the narrow scan, cleared here instead of by two fill commands)
+    if (i < n_a) clear_a[i] = 0;
+    if (i < n_b) clear_b[i] = 0;
 }
 
 __global__ void k_fill_u32(uint32_t* p, uint64_t n, uint32_t v) {
@@ -2158,7 +2162,9 @@ __global__ __launch_bounds__(PS_BLOCK) void k_ps_reduce(const T* __restrict__ in
 // single workgroup: exclusive scan of the block sums in place, grand total to *total.  Each thread owns a
 // contiguous chunk; the 1024 chunk sums are scanned with wave scans (a serial loop in thread 0 took 13 us,
 // 3-4 times per step).
-__global__ __launch_bounds__(1024) void k_ps_spine(uint64_t* __restrict__ block_sums, uint32_t nblocks, uint64_t* __restrict__ total) {
+__global__ __launch_bounds__(1024) void k_ps_spine(uint64_t* __restrict__ block_sums, uint32_t nblocks, uint64_t* __restrict__ total,
+                                                  uint64_t* __restrict__ total_host, const uint64_t* __restrict__ also_src = nullptr,
+                                                  uint64_t* __restrict__ also_host = nullptr) {
     __shared__ uint64_t s_wave[1024 / WAVE];
     const uint32_t per = (nblocks + 1023) / 1024;
     const uint32_t lo = min(threadIdx.x * per, nblocks);
@@ -2176,11 +2182,59 @@ __global__ __launch_bounds__(1024) void k_ps_spine(uint64_t* __restrict__ block_
     __syncthreads();
     uint64_t run = incl - acc;
     for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) run += s_wave[w];
-    if (threadIdx.x == 1023) *total = run + acc;
+    if (threadIdx.x == 1023) {
+        *total = run + acc;
+        *total_host = run + acc;   // (page-locked host memory mapped into the device: no copy command behind the kernel)
+        if (also_src) *also_host = *also_src;   // (a device counter the host wants with the total)
+    }
     for (uint32_t i = lo; i < hi; ++i) {
         const uint64_t v = block_sums[i];
         block_sums[i] = run;
         run += v;
+    }
+}
+
+// The same scan for inputs of a few thousand items (the tile counts of one piece of a streamed step, of one shard)
+// in ONE workgroup: three dependent launches and a copy command cost more than the arithmetic there.  `extra`
+// (optional) is added to the input first and the sum written back (k_add_extra folded in); `also_src` (optional) is a
+// device counter the host wants next to the total.
+constexpr uint32_t PS_SMALL_MAX = 1u << 13;   // (8 items per thread; at 128 k items the one workgroup took 300 us)
+__global__ __launch_bounds__(1024) void k_ps_small(uint32_t* __restrict__ in, const uint32_t* __restrict__ extra, uint32_t n,
+                                                  uint32_t* __restrict__ out, uint64_t* __restrict__ total,
+                                                  uint64_t* __restrict__ total_host, const uint64_t* __restrict__ also_src,
+                                                  uint64_t* __restrict__ also_host) {
+    __shared__ uint64_t s_wave[1024 / WAVE];
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = min(threadIdx.x * per, n);
+    const uint32_t hi = min(lo + per, n);
+    uint64_t acc = 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        uint32_t v = in[i];
+        if (extra && extra[i]) {
+            v += extra[i];
+            in[i] = v;
+        }
+        acc += v;
+    }
+    uint64_t incl = acc;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint64_t up = __shfl_up(incl, d, WAVE);
+        if (lane_id() >= (uint32_t)d) incl += up;
+    }
+    if (lane_id() == WAVE - 1) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t run = incl - acc;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) run += s_wave[w];
+    if (threadIdx.x == 1023) {
+        *total = run + acc;
+        *total_host = run + acc;
+        out[n] = (uint32_t)(run + acc);   // closing sentinel, as k_ps_down writes it: out has n + 1 entries
+        if (also_src) *also_host = *also_src;
+    }
+    for (uint32_t i = lo; i < hi; ++i) {
+        out[i] = (uint32_t)run;
+        run += in[i];
     }
 }
 

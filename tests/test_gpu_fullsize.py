@@ -145,3 +145,32 @@ def test_full_size_cfg4_noise_emits_nothing_but_verifies_millions():
         assert len(arr) < 100
         for a, b, s, e, bs, be in rows.tolist():
             assert be >= M and oriented[a][1][s:e] == oriented[b][1][:be]
+
+
+@pytest.mark.parametrize("cfg_name", ["cfg2", "cfg4"])
+def test_full_size_streamed_step_equals_the_resident_call(cfg_name, monkeypatch):
+    """The bench's step at full size: po_overlaps_to_host on a changed read set takes the streamed form (reads
+    uploaded in pieces under the kernels, reversed strand-mirror order).  Its rows are the multiset of the resident
+    call -- whose rows pass the property checks above -- for the default cut and for a coarse and a fine one."""
+    cfg, oriented, ov = load(cfg_name)
+    res = ov.overlaps_result(M)
+    arr = res.rows()
+    st = ov.stats()
+    res.free()
+    if cfg_name == "cfg2":
+        sig = check_properties(oriented, ov, arr, st, 6_000_000)
+    else:
+        sig = signature(oo.struct_to_rows(arr))
+    del arr
+    for cuts in ("", "400,800", "50,100,150,200,300,400,500,600,700,800,900,950,980,995"):
+        if cuts:
+            monkeypatch.setenv("PHASM_STREAM_CUTS", cuts)
+        ov.invalidate()
+        res = ov.overlaps_to_host_result(M)
+        st2 = ov.stats()
+        got = signature(oo.struct_to_rows(res.rows_view()))
+        res.free()
+        assert st2["streamed"] == 1 and st2["paired"] == 1 and st2["n_rows"] == sig[0]
+        # (candidate counts differ a little: a K-mer hit that does not verify has no counterpart on the mirror side)
+        assert got == sig, "streamed step, cuts %r" % cuts
+    ov.close()
