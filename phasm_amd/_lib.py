@@ -132,6 +132,8 @@ def _preload_torch_hip_runtime() -> None:
     one finds no device.  Loading torch's copy first -- by path, without importing torch -- makes both bind
     to the same one, whatever the import order."""
     import importlib.util
+    if os.environ.get("PHASM_HIP_RUNTIME") == "system":
+        return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):

@@ -87,6 +87,18 @@ int main() {
         printf("rep %d: h2d %.3f ms (%.1f GB/s)  d2h %.3f ms (%.1f GB/s)  both %.3f ms\n", rep,
                t1 - t0, up / (t1 - t0) * 1e-6, t2 - t1, down / (t2 - t1) * 1e-6, t3 - t2);
     }
+    // the same device->host bytes in 8 pieces, queued back to back on one stream, from a buffer a kernel has just written
+    {
+        double t0 = now();
+        for (int k = 0; k < 8; k++) {
+            hipLaunchKernelGGL(k_tiny, dim3(1), dim3(64), 0, ks, (uint32_t*)d_down);
+            CK(hipStreamSynchronize(ks));
+            CK(hipMemcpyAsync((char*)h_down + down / 8 * k, (char*)d_down + down / 8 * k, down / 8, hipMemcpyDeviceToHost, s2));
+        }
+        CK(hipStreamSynchronize(s2));
+        double t1 = now();
+        printf("d2h in 8 pieces of %.1f MB: %.3f ms (%.1f GB/s)\n", down / 8 * 1e-6, t1 - t0, down / (t1 - t0) * 1e-6);
+    }
     // an HBM-bound kernel (64 MB in, 64 MB out) next to the copies
     const size_t n16 = (64u << 20) / 16;
     uint4 *a, *b;
