@@ -331,6 +331,7 @@ def main() -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     incl_acc = dict(acc)
+    incl_last = dict(last)   # (statistics of the last host-to-host step, before the resident loop overwrites them)
     # the kernel pipeline alone (reads resident in HBM, rows left in HBM): an extra, never `value`
     for k in acc:
         acc[k] = 0.0
@@ -398,8 +399,10 @@ def main() -> int:
         scan_bytes = last["shard_bases"] * bits // 8
         exec_bytes = last["verify_bytes_exec"]          # both sides of every VERIFIED CANDIDATE, once
         sharded = "true" if world > 1 else "false"
-        scan_name = ("k_wide_scan<%d, false>" % bits) if last["wide_index"] else ("k_scan_probe<%d, true>" % bits)
-        ver_name = "k_verify_a<%d, %s, true>" % (bits, sharded)
+        # (kernel names as rocprofv3 prints them; the trailing `false` = not the streamed step's instantiation: the resident
+        # loop and the --pmc passes run whole-set launches)
+        scan_name = ("k_wide_scan<%d, false>" % bits) if last["wide_index"] else ("k_scan_probe<%d, true, false>" % bits)
+        ver_name = "k_verify_a<%d, %s, true, false>" % (bits, sharded)
         peaks = measured_peaks() if world == 1 else {}
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
@@ -479,7 +482,7 @@ def main() -> int:
                            "pcie_floor_ms": (h2d_bytes + d2h_bytes) / 64e9 * 1e3,
                            "pcie_floor_duplex_ms": max(h2d_bytes, d2h_bytes) / 64e9 * 1e3,
                            "streamed": bool(pcie.get("streamed_steps")),
-                           "deferred_containments": int(last.get("n_deferred", 0)),
+                           "deferred_containments": int(incl_last.get("n_deferred", 0)),
                            "note": ("streamed step: the packed reads go up piece by piece (h2d_ms = first copy starts -> last piece landed, device events) "
                                     "while the pieces that have arrived are scanned, verified and emitted and their rows travel home -- PCIe carries both "
                                     "directions at once, so kernels_plus_d2h_ms overlaps h2d_ms and the two do not add up to ms_per_step. "

@@ -137,7 +137,7 @@ po_status po_upload_assemble(po_handle* h, const void* pieces_device, uint64_t s
 /* Forget the device copy of the read set: the next po_upload / po_overlaps* copies the packed reads host->device
  * again, as the first call of a fresh process does.  The reference's overlaps() starts from the host-side string
  * set on every call (index built from `readset`, src/overlapper.cpp:33-36), so ONE reference call corresponds to
- * po_invalidate + po_upload + po_overlaps + po_result_rows: the region bench.py times. */
+ * po_invalidate + po_overlaps_to_host + po_result_rows: the region bench.py times. */
 po_status po_invalidate(po_handle* h);
 
 /* overlaps(min_length)  -- src/overlapper.cpp:28-150.  Rows stay on the device until
@@ -149,7 +149,15 @@ po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out);
  * (src/overlapper.cpp:149) -- as ONE pipelined call: po_overlaps + po_result_rows, with the rows of one chunk of a-side
  * reads travelling device->host (second stream, one page-locked array) while the next chunk is in the kernels.  The
  * result holds the host array only (po_result_rows returns it at once; po_result_device_rows is NULL; po_layout_edges
- * would copy the rows back).  Same multiset of rows as po_overlaps, a-major chunk by chunk. */
+ * would copy the rows back).  Same multiset of rows as po_overlaps, a-major chunk by chunk.
+ * When the read set changed since the last upload -- what the reference faces on every call, its reads are host memory
+ * (:22-36) -- the call also does the upload, STREAMED: the packed reads cross PCIe in pieces on a third stream, a piece
+ * that has landed is scanned against the whole index (built from every read's first word, sent ahead), its candidates
+ * whose b-side read has arrived are verified and emitted (every suffix-prefix candidate, by the choice of which member
+ * of a strand-mirror pair is computed; containments of a read still on its way wait on a list), and its rows travel
+ * home while the next piece is still coming in.  Needs reads added as (x, reverse complement of x) pairs of pure
+ * upper-case ACGT and the narrow index; otherwise the call uploads first (po_upload) and runs the chunked form.
+ * po_stats.streamed tells which form ran. */
 po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out);
 
 /* Banded seed-extension mode -- an EXTENSION BEYOND THE REFERENCE, which is exact (src/overlapper.cpp:28-150; CLI help
