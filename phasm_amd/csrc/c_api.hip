@@ -128,6 +128,7 @@ struct po_handle {
     // up_stream while the pieces that have arrived go through the kernels and their rows travel back
     hipStream_t up_stream = nullptr;
     hipEvent_t ev_piece[PO_MAX_PIECES] = {};
+    hipEvent_t ev_first = nullptr;   // the first words of the later pieces are in place
     HostBuf first_host;            // first packed word of every read (pinned), valid for first_n reads
     uint32_t first_n = 0;
     // per-read metadata of the upload, kept page-locked while the read set is unchanged (reads are only ever appended):
@@ -1962,6 +1963,7 @@ void po_destroy(po_handle* h) {
         }
         for (hipEvent_t e : h->ev_piece)
             if (e) (void)hipEventDestroy(e);
+        if (h->ev_first) (void)hipEventDestroy(h->ev_first);
         if (h->copy_stream) {
             (void)hipStreamSynchronize(h->copy_stream);
             (void)hipStreamDestroy(h->copy_stream);
@@ -2415,7 +2417,7 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
         HIP_TRY(h, hipStreamWaitEvent(h->up_stream, h->ev_up1, 0));
     }
     HIP_TRY(h, hipEventRecord(h->ev_up0, h->up_stream));
-    for (uint32_t k = 0; k < P; ++k) {
+    auto queue_piece = [&](uint32_t k) -> po_status {
         const uint64_t wb = bounds[k] < n ? h->woff[bounds[k]] : h->words[0].size();
         const uint64_t we = bounds[k + 1] < n ? h->woff[bounds[k + 1]] : h->words[0].size();
         if (we > wb) {
@@ -2423,21 +2425,33 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
             h->upload_bytes += (we - wb) * 8;
         }
         HIP_TRY(h, hipEventRecord(h->ev_piece[k], h->up_stream));
+        return PO_OK;
+    };
+    PO_TRY(queue_piece(0));
+    if (P > 1) {
+        // first words of the reads of the later pieces (both strands: the host packed the odd store too, it just does
+        // not travel), put in place on the handle's stream while piece 0 is crossing; the later pieces' copies are
+        // ordered behind that kernel -- they bring the same values, but two writers of one word want an order
+        if (h->first_n != n || !h->first_host.p) {
+            PO_TRY(ensure_host(h, h->first_host, (size_t)n * 8));
+            uint64_t* f = static_cast<uint64_t*>(h->first_host.p);
+            for (uint32_t r = 0; r < n; ++r) f[r] = h->words[r & 1][h->woff[r]];   // (an empty read: its guard word, zero)
+            h->first_n = n;
+        }
+        const uint32_t r0 = bounds[1];
+        PO_TRY(ensure(h, h->d_first, (size_t)n * 8));
+        HIP_TRY(h, hipMemcpyAsync(h->d_first.as<uint64_t>() + r0, static_cast<uint64_t*>(h->first_host.p) + r0, (size_t)(n - r0) * 8,
+                                  hipMemcpyHostToDevice, h->stream));
+        h->upload_bytes += (size_t)(n - r0) * 8;
+        hipLaunchKernelGGL(po::k_scatter_first, dim3(cdiv(n - r0, 256)), dim3(256), 0, h->stream, dw, h->d_woff.as<uint64_t>(),
+                           h->d_first.as<uint64_t>(), r0, n);
+        HIP_TRY(h, hipGetLastError());
+        if (!h->ev_first) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_first, hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(h->ev_first, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->up_stream, h->ev_first, 0));
     }
+    for (uint32_t k = 1; k < P; ++k) PO_TRY(queue_piece(k));
     HIP_TRY(h, hipEventRecord(h->ev_up1, h->up_stream));
-    // first words (both strands: the host packed store 1 too, it just does not travel)
-    if (h->first_n != n || !h->first_host.p) {
-        PO_TRY(ensure_host(h, h->first_host, (size_t)n * 8));
-        uint64_t* f = static_cast<uint64_t*>(h->first_host.p);
-        for (uint32_t r = 0; r < n; ++r) f[r] = h->words[r & 1][h->woff[r]];   // (an empty read: its guard word, zero)
-        h->first_n = n;
-    }
-    PO_TRY(ensure(h, h->d_first, (size_t)n * 8));
-    HIP_TRY(h, hipMemcpyAsync(h->d_first.p, h->first_host.p, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
-    h->upload_bytes += (size_t)n * 8;
-    hipLaunchKernelGGL(po::k_scatter_first, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, dw, h->d_woff.as<uint64_t>(),
-                       h->d_first.as<uint64_t>(), n);
-    HIP_TRY(h, hipGetLastError());
     // deferred containment list: [Cand x cap | counter]
     h->st_defer_cap = std::max<uint32_t>(1u << 16, h->defer_need + h->defer_need / 2);
     if (const char* e = getenv("PHASM_DEFER_CAP")) h->st_defer_cap = (uint32_t)std::max(1, atoi(e));   // (tests: force the overflow path)

@@ -2064,10 +2064,12 @@ __global__ __launch_bounds__(256) void k_revcomp_store(uint64_t* __restrict__ wo
 
 // ---- streamed step (po_overlaps_to_host while the reads are still crossing PCIe piece by piece) ----------------
 // The index only needs every read's first word (its prefix K-mer, K <= 32 bases of a word-aligned read): those
-// travel first, 8 bytes per read, and are put where the reads will land.  The pieces later bring the same values.
+// travel first, 8 bytes per read, and are put where the reads of the LATER pieces will land (reads [r0, n): the first
+// piece has landed before the index is built).  The pieces later bring the same values; their copies are ordered
+// behind this kernel.
 __global__ void k_scatter_first(uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
-                                const uint64_t* __restrict__ first, uint32_t n) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+                                const uint64_t* __restrict__ first, uint32_t r0, uint32_t n) {
+    const uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n) words[woff[r]] = first[r];
 }
 
