@@ -152,11 +152,11 @@ po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out);
  * would copy the rows back).  Same multiset of rows as po_overlaps, a-major chunk by chunk.
  * When the read set changed since the last upload -- what the reference faces on every call, its reads are host memory
  * (:22-36) -- the call also does the upload, STREAMED: the packed reads cross PCIe in pieces on a third stream, a piece
- * that has landed is scanned against the whole index (built from every read's first word, sent ahead), its candidates
+ * that has landed is scanned against the whole index (built from every read's first two words, sent ahead), its candidates
  * whose b-side read has arrived are verified and emitted (every suffix-prefix candidate, by the choice of which member
  * of a strand-mirror pair is computed; containments of a read still on its way wait on a list), and its rows travel
  * home while the next piece is still coming in.  Needs reads added as (x, reverse complement of x) pairs of pure
- * upper-case ACGT and the narrow index; otherwise the call uploads first (po_upload) and runs the chunked form.
+ * upper-case ACGT; otherwise the call uploads first (po_upload) and runs the chunked form.
  * po_stats.streamed tells which form ran. */
 po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out);
 

@@ -824,7 +824,6 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         if (!strcmp(e, "wide")) wide = m >= 2 * W - 1;
         if (!strcmp(e, "narrow")) wide = false;
     }
-    if (streamed && wide) return fail(h, PO_ERR_INVALID, "streamed step with the wide index");
     S.wide_index = wide ? 1u : 0u;
     bool WA_ext = false;
     const bool slice_build = h->sl_build_n > 1;     // build one sub-table of the sliced wide index, then stop
@@ -1032,7 +1031,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     WA.tile_off = A.tile_off;
     if (wide) {
         HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE0], st));
-        hipLaunchKernelGGL((po::k_wide_scan<BITS, false>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA);
+        auto wscan = streamed ? po::k_wide_scan<BITS, false, BITS == 2> : po::k_wide_scan<BITS, false, false>;
+        hipLaunchKernelGGL(wscan, dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA);
         HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
     } else {
         const size_t scan_lds = (size_t)scan_waves * po::SCAN_LDS_PER_WAVE + bloom_bytes;
@@ -1131,7 +1131,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             WA.cand_a = A.cand_a;
             WA.cand_p = A.cand_p;
             WA.cand_b = A.cand_b;
-            hipLaunchKernelGGL((po::k_wide_scan<BITS, true>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA);
+            auto wfill = streamed ? po::k_wide_scan<BITS, true, BITS == 2> : po::k_wide_scan<BITS, true, false>;
+            hipLaunchKernelGGL(wfill, dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA);
         } else {
             auto fill = streamed ? po::k_scan_fill<BITS, BITS == 2> : po::k_scan_fill<BITS, false>;
             hipLaunchKernelGGL(fill, dim3(cdiv(ntiles, 4 * po::FILL_TILES)), dim3(256), 0, st, A);
@@ -2360,12 +2361,7 @@ bool stream_eligible(const po_handle* h, uint32_t min_length) {
     const uint32_t m = min_length ? min_length : 1;
     const uint64_t n_elig = count_eligible(const_cast<po_handle*>(h), m);
     if (n_elig == 0) return false;
-    bool wide = n_elig > 160000 && m >= 2 * 32 - 1;
-    if (const char* e = getenv("PHASM_INDEX")) {
-        if (!strcmp(e, "wide")) wide = m >= 2 * 32 - 1;
-        if (!strcmp(e, "narrow")) wide = false;
-    }
-    return !wide;
+    return true;   // (either index flavour: the narrow one needs every read's first word ahead of the pieces, the wide one two)
 }
 
 // piece boundaries (even read indices, first 0, last n): cut points in thousandths of the packed store.  Pair (a, b)
@@ -2433,18 +2429,22 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
         // not travel), put in place on the handle's stream while piece 0 is crossing; the later pieces' copies are
         // ordered behind that kernel -- they bring the same values, but two writers of one word want an order
         if (h->first_n != n || !h->first_host.p) {
-            PO_TRY(ensure_host(h, h->first_host, (size_t)n * 8));
+            PO_TRY(ensure_host(h, h->first_host, (size_t)n * 16));
             uint64_t* f = static_cast<uint64_t*>(h->first_host.p);
-            for (uint32_t r = 0; r < n; ++r) f[r] = h->words[r & 1][h->woff[r]];   // (an empty read: its guard word, zero)
+            for (uint32_t r = 0; r < n; ++r) {   // (every read owns two words or more: data, guard, alignment padding)
+                const uint64_t* w = h->words[r & 1].data() + h->woff[r];
+                f[2 * (size_t)r] = w[0];
+                f[2 * (size_t)r + 1] = w[1];
+            }
             h->first_n = n;
         }
         const uint32_t r0 = bounds[1];
-        PO_TRY(ensure(h, h->d_first, (size_t)n * 8));
-        HIP_TRY(h, hipMemcpyAsync(h->d_first.as<uint64_t>() + r0, static_cast<uint64_t*>(h->first_host.p) + r0, (size_t)(n - r0) * 8,
-                                  hipMemcpyHostToDevice, h->stream));
-        h->upload_bytes += (size_t)(n - r0) * 8;
+        PO_TRY(ensure(h, h->d_first, (size_t)n * 16));
+        HIP_TRY(h, hipMemcpyAsync(h->d_first.as<uint64_t>() + 2 * (size_t)r0, static_cast<uint64_t*>(h->first_host.p) + 2 * (size_t)r0,
+                                  (size_t)(n - r0) * 16, hipMemcpyHostToDevice, h->stream));
+        h->upload_bytes += (size_t)(n - r0) * 16;
         hipLaunchKernelGGL(po::k_scatter_first, dim3(cdiv(n - r0, 256)), dim3(256), 0, h->stream, dw, h->d_woff.as<uint64_t>(),
-                           h->d_first.as<uint64_t>(), r0, n);
+                           h->d_first.as<ulonglong2>(), r0, n);
         HIP_TRY(h, hipGetLastError());
         if (!h->ev_first) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_first, hipEventDisableTiming));
         HIP_TRY(h, hipEventRecord(h->ev_first, h->stream));

@@ -515,7 +515,7 @@ __global__ void k_wide_finalize(Slot* tab, uint32_t nslots, const uint32_t* __re
 }
 
 // candidates of the word-aligned K-mer at base offset pw of read a, given the slot it found
-template <int BITS, typename F>
+template <int BITS, bool STREAM = false, typename F>
 __device__ inline void for_each_candidate_wide(const uint64_t* __restrict__ chain, const uint32_t* __restrict__ len,
                                                uint32_t paired, uint32_t z, uint32_t w, uint32_t a, uint32_t la,
                                                uint32_t pw, uint32_t m, F&& f) {
@@ -524,7 +524,7 @@ __device__ inline void for_each_candidate_wide(const uint64_t* __restrict__ chai
         if (j > pw) return;            // p = pw - j would be negative
         const uint32_t p = pw - j;
         if (p + m > la) return;        // too close to the end of a to reach min_length
-        const uint32_t k = keep_bits(a, b, la - p, lb, paired);
+        const uint32_t k = keep_bits<STREAM>(a, b, la - p, lb, paired);
         if (k) f(b, p, k);
     };
     if (w & SLOT_SINGLE) {
@@ -561,7 +561,7 @@ struct WideArgs {
 
 // One wave per tile, one word per lane: probe the table with the word itself.  FILL = false: count
 // candidates per tile and remember the slot per lane; FILL = true: write the candidates.
-template <int BITS, bool FILL>
+template <int BITS, bool FILL, bool STREAM = false>
 __global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A) {
     constexpr uint32_t W = 64 / BITS;
     const uint32_t lane = lane_id();
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A) {
                 }
             }
             if (w) {
-                for_each_candidate_wide<BITS>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
+                for_each_candidate_wide<BITS, STREAM>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
                                               [&](uint32_t, uint32_t, uint32_t) { ++n; });
                 if (n) slot1 = base + i + 1u;
             }
@@ -621,13 +621,13 @@ __global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A) {
             w = s.w;
             if (A.n_slices > 1u)
                 chain = reinterpret_cast<const uint64_t*>(A.table + ((slot1 - 1u) / A.chunk_slots) * A.chunk_slots + A.chain_off_slots);
-            for_each_candidate_wide<BITS>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
+            for_each_candidate_wide<BITS, STREAM>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
                                           [&](uint32_t, uint32_t, uint32_t) { ++n; });
         }
         const uint32_t inc = wave_incl_scan(n);
         uint32_t off = A.tile_off[t] + inc - n;
         if (n) {
-            for_each_candidate_wide<BITS>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
+            for_each_candidate_wide<BITS, STREAM>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
                                           [&](uint32_t b, uint32_t p, uint32_t) {
                                               A.cand_a[off] = a;
                                               A.cand_p[off] = p;
@@ -2063,14 +2063,18 @@ __global__ __launch_bounds__(256) void k_revcomp_store(uint64_t* __restrict__ wo
 }
 
 // ---- streamed step (po_overlaps_to_host while the reads are still crossing PCIe piece by piece) ----------------
-// The index only needs every read's first word (its prefix K-mer, K <= 32 bases of a word-aligned read): those
-// travel first, 8 bytes per read, and are put where the reads of the LATER pieces will land (reads [r0, n): the first
+// The index only needs every read's first word (its prefix K-mer, K <= 32 bases of a word-aligned read; the wide index:
+// the first two): those travel first, 16 bytes per read, and are put where the reads of the LATER pieces will land (reads [r0, n): the first
 // piece has landed before the index is built).  The pieces later bring the same values; their copies are ordered
 // behind this kernel.
 __global__ void k_scatter_first(uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
-                                const uint64_t* __restrict__ first, uint32_t r0, uint32_t n) {
+                                const ulonglong2* __restrict__ first, uint32_t r0, uint32_t n) {
     const uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) words[woff[r]] = first[r];
+    if (r >= n) return;
+    // two words (the wide index reads the K-mers at the first W offsets: bases 0 .. 2W-2); a read starts on a 16-byte
+    // boundary, so both words are its own -- data, guard or padding
+    const ulonglong2 f = first[r];
+    *reinterpret_cast<ulonglong2*>(words + woff[r]) = f;
 }
 
 // Containment candidates (B) whose b-side read has not arrived yet: the verify kernel leaves them alone

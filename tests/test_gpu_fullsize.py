@@ -125,6 +125,13 @@ def test_full_size_large_configs(cfg_name, expect_rows):
         n, h1, h2 = n + pn, (h1 + p1) % (1 << 64), (h2 + p2) % (1 << 64)
         del part
     assert (n, h1, h2) == sig
+    # the host-to-host call on a changed read set: streamed (wide index: the first TWO words of every read go ahead)
+    ov.invalidate()
+    res = ov.overlaps_to_host_result(M)
+    st2 = ov.stats()
+    got = signature(oo.struct_to_rows(res.rows_view()))
+    res.free()
+    assert st2["streamed"] == 1 and st2["wide_index"] == 1 and got == sig
     ov.close()
 
 

@@ -27,20 +27,25 @@ def streamed_rows(seqs, m, calls=1):
     return out
 
 
+@pytest.mark.parametrize("index", ["narrow", "wide"])
 @pytest.mark.parametrize("cuts", CUTS)
-def test_streamed_step_matches_the_goldens(cuts, monkeypatch):
+def test_streamed_step_matches_the_goldens(cuts, index, monkeypatch):
     monkeypatch.setenv("PHASM_STREAM", "1")
+    monkeypatch.setenv("PHASM_INDEX", index)   # (wide needs min_length >= 63: the other cases stay narrow)
     if cuts:
         monkeypatch.setenv("PHASM_STREAM_CUTS", cuts)
     n_streamed = 0
+    n_wide = 0
     cases = [gu.ladder_case(name) for name in gu.LADDER_NAMES] + list(gu.repeats_cases()) + list(gu.all_small_cases())
     for name, seqs, m, want in cases:
         for got, st in streamed_rows(seqs, m, calls=2):
             ck.assert_same_rows(got, want, seqs, m, "%s, cuts %r" % (name, cuts))
             n_streamed += st["streamed"]
+            n_wide += st["streamed"] and st["wide_index"]
             if st["streamed"]:
                 assert st["paired"] == 1 and st["n_rows"] == len(want)
     assert n_streamed >= 2 * len(gu.LADDER_NAMES)   # every ladder case is a set of strand pairs of pure ACGT reads
+    assert (n_wide >= 6) == (index == "wide")
 
 
 def _nested_reads(seed, n_reads, genome_len, lo, hi):
@@ -58,16 +63,17 @@ def _nested_reads(seed, n_reads, genome_len, lo, hi):
     return seqs
 
 
+@pytest.mark.parametrize("index,m", [("narrow", 35), ("wide", 70)])
 @pytest.mark.parametrize("cuts", ["", "500", "200,400,600,800", "999"])
-def test_containments_of_reads_that_arrive_later_are_deferred(cuts, monkeypatch):
+def test_containments_of_reads_that_arrive_later_are_deferred(cuts, index, m, monkeypatch):
     monkeypatch.setenv("PHASM_STREAM", "1")
+    monkeypatch.setenv("PHASM_INDEX", index)
     if cuts:
         monkeypatch.setenv("PHASM_STREAM_CUTS", cuts)
     seqs = _nested_reads(20260, 150, 6000, 40, 1500)
-    m = 35
     want = ck.oracle_overlaps(seqs, m)
     (got, st), (got2, st2) = streamed_rows(seqs, m, calls=2)
-    assert st["streamed"] == 1 and st2["streamed"] == 1
+    assert st["streamed"] == 1 and st2["streamed"] == 1 and st["wide_index"] == (index == "wide")
     if cuts != "999":
         assert st["n_deferred"] > 0
     ck.assert_same_rows(got, want, seqs, m, "nested reads, cuts %r" % cuts)
@@ -110,10 +116,11 @@ def test_streamed_fuzz_against_the_oracle(monkeypatch):
         seqs = _nested_reads(1000 + trial, n, glen, 20, max(40, glen // 3))
         if trial % 3 == 0:   # a few exact duplicates and a period-3 repeat read
             seqs += seqs[:4] + [b"ACG" * 60, b"CGT" * 60]
-        m = int(rng.integers(1, 60))
+        m = int(rng.integers(1, 60)) if trial % 2 else int(rng.integers(63, 120))
+        monkeypatch.setenv("PHASM_INDEX", "narrow" if trial % 2 else "wide")
         want = ck.oracle_overlaps(seqs, m)
         (got, st), = streamed_rows(seqs, m)
-        assert st["streamed"] == 1
+        assert st["streamed"] == 1 or not any(len(x) >= m for x in seqs)
         ck.assert_same_rows(got, want, seqs, m, "fuzz trial %d, cuts %s, m %d" % (trial, cuts, m))
 
 
