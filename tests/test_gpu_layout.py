@@ -207,12 +207,17 @@ def test_layout_without_the_table_equals_layout_with_it(name, monkeypatch):
         ov.add_sequence("read%d+" % i, seqs[2 * i])
         ov.add_sequence("read%d-" % i, seqs[2 * i + 1])
     outs = []
-    for mode in ("fast", "table", "host"):
+    for mode in ("fast", "table", "host", "streamed"):
         if mode == "table":
             monkeypatch.setenv("PHASM_LAYOUT_TABLE", "1")
         else:
             monkeypatch.delenv("PHASM_LAYOUT_TABLE", raising=False)
-        res = ov.overlaps_to_host_result(m) if mode == "host" else ov.overlaps_result(m)
+        if mode == "streamed":   # rows of the streamed step: another member of each mirror pair computed, deferred rows last
+            monkeypatch.setenv("PHASM_STREAM", "1")
+            monkeypatch.setenv("PHASM_STREAM_CUTS", "300,600,900")
+            ov.invalidate()
+        res = ov.overlaps_to_host_result(m) if mode in ("host", "streamed") else ov.overlaps_result(m)
+        assert ov.stats()["streamed"] == (mode == "streamed")
         g = layout.build_assembly_graph(ov, res, min_overlap_length=m + 50)
         rows = res.rows()
         res.free()
@@ -223,3 +228,31 @@ def test_layout_without_the_table_equals_layout_with_it(name, monkeypatch):
     for e, c in outs:
         assert np.array_equal(e, want["edges"]) and c == want["contained"].tolist()
     assert len(want["edges"]) > 100
+
+
+def test_layout_on_streamed_rows_of_nested_reads(monkeypatch):
+    """Reads of very different lengths: many containments, part of them settled from the streamed step's deferred list
+    (their rows come last in the array).  Stage 1 on those rows -- table-free -- equals the oracle's."""
+    rng = np.random.default_rng(99)
+    genome = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=7000))
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    ov = ExactOverlapper()
+    for i in range(160):
+        ln = int(rng.integers(60, 1800))
+        st = int(rng.integers(0, 7000 - ln))
+        r = genome[st:st + ln]
+        ov.add_sequence("read%d+" % i, r)
+        ov.add_sequence("read%d-" % i, r.translate(comp)[::-1])
+    monkeypatch.setenv("PHASM_STREAM", "1")
+    monkeypatch.setenv("PHASM_STREAM_CUTS", "200,400,600,800")
+    m = 40
+    res = ov.overlaps_to_host_result(m)
+    assert ov.stats()["streamed"] == 1 and ov.stats()["n_deferred"] > 0
+    g = layout.build_assembly_graph(ov, res, min_overlap_length=m + 20)
+    rows = res.rows()
+    res.free()
+    r6 = np.stack([rows[k] for k in rows.dtype.names], 1).astype(np.int64)
+    want = ck.layout_vectorised(r6, ov.lengths(), min_overlap_length=m + 20)
+    ov.close()
+    assert np.array_equal(edge_array(g.edges), want["edges"]) and g.contained.tolist() == want["contained"].tolist()
+    assert len(want["contained"]) > 20
