@@ -2643,6 +2643,9 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
         st = fail(h, PO_ERR_NOMEM, "out of host memory in po_overlaps_to_host");
     }
     h->st_on = false;
+    h->st_harvest = nullptr;   // (an exception may have left the streamed step half way: its callback captures dead locals)
+    h->st_pend.valid = false;
+    h->ev = h->ev_sets[0];
     if (h->dev_ready) (void)hipStreamSynchronize(h->stream);
     if (h->up_stream) (void)hipStreamSynchronize(h->up_stream);
     if (h->copy_stream && hipStreamSynchronize(h->copy_stream) != hipSuccess && st == PO_OK) st = fail(h, PO_ERR_HIP, "row copy device->host");
