@@ -2536,7 +2536,8 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
         return st;
     }
     float ms = 0;
-    (void)hipEventElapsedTime(&ms, h->ev_up0, h->ev_up1);   // (every piece was waited for: both events have happened)
+    (void)hipEventSynchronize(h->ev_up1);   // (recorded right behind the last piece's event, which the kernels waited for)
+    (void)hipEventElapsedTime(&ms, h->ev_up0, h->ev_up1);
     h->stats.ms_upload = ms;
     // ---- the deferred containments: every read is there now
     HIP_TRY(h, hipMemcpyAsync(h->pinned + 40, h->d_defer.as<char>() + (size_t)h->st_defer_cap * sizeof(po::Cand), 8,

@@ -135,3 +135,32 @@ def test_streamed_step_is_not_taken_for_reads_it_cannot_serve(monkeypatch):
         (got, st), = streamed_rows(seqs, 30)
         assert st["streamed"] == 0
         ck.assert_same_rows(got, ck.oracle_overlaps(seqs, 30), seqs, 30, "not streamed")
+
+
+def test_other_entry_points_after_a_streamed_step(monkeypatch):
+    """The streamed step leaves the handle as po_upload would: the resident call, the chunked host call, the sharded
+    calls and the extension mode on the same handle afterwards give the same rows (index built by piece 0 reused)."""
+    monkeypatch.setenv("PHASM_STREAM", "1")
+    monkeypatch.setenv("PHASM_STREAM_CUTS", "200,500,800")
+    for name in ("ladder_varlen", "cfg2_1k"):
+        _, seqs, m, want = gu.ladder_case(name)
+        ov = ExactOverlapper()
+        for i, s in enumerate(seqs):
+            ov.add_sequence("r%d" % i, s)
+        res = ov.overlaps_to_host_result(m)
+        assert ov.stats()["streamed"] == 1
+        ck.assert_same_rows(oo.sort_rows(oo.struct_to_rows(res.rows_view())), want, seqs, m, "%s streamed" % name)
+        res.free()
+        res = ov.overlaps_result(m)
+        st = ov.stats()
+        ck.assert_same_rows(oo.sort_rows(oo.struct_to_rows(res.rows())), want, seqs, m, "%s resident after streamed" % name)
+        assert st["streamed"] == 0 and st["index_reused"] == 1
+        res.free()
+        res = ov.overlaps_to_host_result(m)      # not invalidated: the chunked form
+        assert ov.stats()["streamed"] == 0
+        ck.assert_same_rows(oo.sort_rows(oo.struct_to_rows(res.rows_view())), want, seqs, m, "%s chunked after streamed" % name)
+        res.free()
+        parts = np.concatenate([ov.overlaps_shard_array(m, k, 3) for k in range(3)])
+        ck.assert_same_rows(oo.sort_rows(oo.struct_to_rows(parts)), want, seqs, m, "%s shards after streamed" % name)
+        ck.assert_same_rows(oo.sort_rows(oo.struct_to_rows(ov.overlaps_ex_array(m, 0, 0))), want, seqs, m, "%s DP after streamed" % name)
+        ov.close()
