@@ -2281,6 +2281,7 @@ po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out) {
 //
 // Same rows as po_overlaps as a multiset (which member of a strand-mirror pair is computed differs, the emitted
 // pair of rows does not), a-major chunk by chunk.  The result holds the host array only.
+extern "C++" {
 namespace {
 
 struct HostRows {
@@ -2595,6 +2596,7 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
 }
 
 }  // namespace
+}  // extern "C++"
 
 po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out) {
     if (!h || !out) return PO_ERR_INVALID;
