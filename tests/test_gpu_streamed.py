@@ -1,5 +1,7 @@
 """The streamed step of po_overlaps_to_host (reads uploaded piece by piece under the kernels, reversed strand-mirror
 order, deferred containments): the same rows as the goldens / the oracle for every cut of the read set into pieces."""
+import os
+
 import numpy as np
 import pytest
 
@@ -154,7 +156,8 @@ def test_other_entry_points_after_a_streamed_step(monkeypatch):
         res = ov.overlaps_result(m)
         st = ov.stats()
         ck.assert_same_rows(oo.sort_rows(oo.struct_to_rows(res.rows())), want, seqs, m, "%s resident after streamed" % name)
-        assert st["streamed"] == 0 and st["index_reused"] == 1
+        assert st["streamed"] == 0
+        assert st["index_reused"] == (0 if os.environ.get("PHASM_POISON") else 1)   # (the poison mode rebuilds per call)
         res.free()
         res = ov.overlaps_to_host_result(m)      # not invalidated: the chunked form
         assert ov.stats()["streamed"] == 0
