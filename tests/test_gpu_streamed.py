@@ -12,7 +12,8 @@ from phasm_amd.overlapper import ExactOverlapper
 
 pytestmark = pytest.mark.gpu
 
-CUTS = ["", "500", "250,500,750", "100,200,300,400,500,600,700,800,900", "30,60,90,120,150,180,210,240,270,300,900,950,990", "999"]
+CUTS = ["", "500", "250,500,750", "100,200,300,400,500,600,700,800,900", "30,60,90,120,150,180,210,240,270,300,900,950,990", "999",
+        ",".join(str(c) for c in range(40, 1000, 40))]   # (24 cuts: the library keeps the first 15 = 16 pieces)
 
 
 def streamed_rows(seqs, m, calls=1):
