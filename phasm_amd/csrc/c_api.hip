@@ -2432,10 +2432,13 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
         if (h->first_n != n || !h->first_host.p) {
             PO_TRY(ensure_host(h, h->first_host, (size_t)n * 16));
             uint64_t* f = static_cast<uint64_t*>(h->first_host.p);
-            for (uint32_t r = 0; r < n; ++r) {   // (every read owns two words or more: data, guard, alignment padding)
-                const uint64_t* w = h->words[r & 1].data() + h->woff[r];
-                f[2 * (size_t)r] = w[0];
-                f[2 * (size_t)r + 1] = w[1];
+            for (uint32_t r = 0; r < n; ++r) {
+                // (a read owns its data words and a zero guard word; the word behind an EMPTY read is alignment padding,
+                // or -- for the last read of a store -- not part of the host store at all: zero on the device either way)
+                const std::vector<uint64_t>& store = h->words[r & 1];
+                const uint64_t o = h->woff[r];
+                f[2 * (size_t)r] = store[o];
+                f[2 * (size_t)r + 1] = o + 1 < store.size() ? store[o + 1] : 0;
             }
             h->first_n = n;
         }

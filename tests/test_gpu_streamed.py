@@ -168,3 +168,20 @@ def test_other_entry_points_after_a_streamed_step(monkeypatch):
         ck.assert_same_rows(oo.sort_rows(oo.struct_to_rows(parts)), want, seqs, m, "%s shards after streamed" % name)
         ck.assert_same_rows(oo.sort_rows(oo.struct_to_rows(ov.overlaps_ex_array(m, 0, 0))), want, seqs, m, "%s DP after streamed" % name)
         ov.close()
+
+
+def test_streamed_step_with_empty_and_tiny_reads(monkeypatch):
+    """Empty reads and reads shorter than a packed word, in the middle of the set and as its last pair: their footprint
+    in the packed store is one or two words, which is what the first-words pass writes ahead of the pieces."""
+    monkeypatch.setenv("PHASM_STREAM", "1")
+    monkeypatch.setenv("PHASM_STREAM_CUTS", "300,600,900")
+    base = _nested_reads(3, 30, 1500, 40, 400)
+    tiny = [b"", b"", b"ACG", b"CGT", b"A", b"T"]
+    for index, m in (("narrow", 1), ("narrow", 30), ("wide", 64)):
+        monkeypatch.setenv("PHASM_INDEX", index)
+        for seqs in (base[:20] + tiny + base[20:], base + tiny, tiny[:2] + base + tiny[:2]):
+            want = ck.oracle_overlaps(seqs, m)
+            (got, st), (got2, _) = streamed_rows(seqs, m, calls=2)
+            assert st["streamed"] == 1
+            ck.assert_same_rows(got, want, seqs, m, "tiny reads, %s index, m %d" % (index, m))
+            ck.assert_same_rows(got2, want, seqs, m, "tiny reads, second call")
