@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -2356,7 +2357,9 @@ bool stream_eligible(const po_handle* h, uint32_t min_length) {
     if (!h->dirty || h->bits != 2 || n < 4 || (n % 2) != 0 || !h->all_pairs_rc || !h->exc_pos.empty()) return false;
     if (h->asm_pieces || h->ex_on || h->sl_build_n > 1 || h->ext_index) return false;
     if (getenv("PHASM_FULL_UPLOAD") || getenv("PHASM_NO_MIRROR")) return false;
-    bool want = n >= 8192 && h->total_bases >= (64ull << 20);
+    // (worth it from ~16 MB of packed even reads on: below that a piece's fixed cost, ~0.2 ms of small launches, is more
+    // than the transfer time it hides)
+    bool want = n >= 4096 && h->words[0].size() * 8 >= (16ull << 20);
     if (const char* e = getenv("PHASM_STREAM")) want = atoi(e) != 0;
     if (!want) return false;
     const uint32_t m = min_length ? min_length : 1;
@@ -2370,7 +2373,13 @@ bool stream_eligible(const po_handle* h, uint32_t min_length) {
 // pieces are made small, their rows are what is left to send home after the upload has ended.
 std::vector<uint32_t> stream_bounds(const po_handle* h) {
     const uint32_t n = (uint32_t)h->len.size();
-    std::vector<uint32_t> cuts = {150, 300, 450, 600, 730, 850, 940};   // (config 2: 5.24 ms per step; 5 to 10 pieces measure within 3 % of it)
+    // one piece per ~16 MB, 2 to 8 of them, cut at 1 - (1 - i/P)^1.25: 154/302/444/580/707/823/926 thousandths at P = 8
+    // (config 2, 190 MB: 5.3 ms per step; 5 to 10 pieces measure within 3 % of it.  Config 2 scaled to 12 k reads, 45 MB:
+    // 8 pieces 2.24 ms, 3 pieces 1.83, none 2.38; to 6 k reads, 22 MB: 8 pieces 1.74, 2 pieces 1.15, none 1.52)
+    const uint64_t bytes0 = (uint64_t)h->words[0].size() * 8;
+    const uint32_t n_pieces = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(2, (bytes0 + (8ull << 20)) / (16ull << 20)));
+    std::vector<uint32_t> cuts;
+    for (uint32_t i = 1; i < n_pieces; ++i) cuts.push_back((uint32_t)(1000.0 * (1.0 - std::pow(1.0 - (double)i / n_pieces, 1.25))));
     if (const char* e = getenv("PHASM_STREAM_CUTS")) {
         cuts.clear();
         for (const char* q = e; *q;) {
