@@ -93,6 +93,7 @@ typedef struct {
                                  /* odd read is the reverse complement of its even partner: the device rebuilds them) */
     uint32_t streamed;           /* po_overlaps_to_host: 1 = streamed step (reads uploaded piece by piece under the      */
     uint32_t n_deferred;         /*    kernels); n_deferred = containment candidates that waited for a later piece       */
+                                 /*    (streamed == 0 with n_deferred > 0: their list overflowed, the chunked form ran)  */
 } po_stats;
 
 /* ExactOverlapper()  -- src/overlapper.cpp:19, py::init at src/phasm.cpp:13. */

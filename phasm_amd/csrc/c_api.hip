@@ -2623,7 +2623,7 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
     po_status st = PO_OK;
     HostRows R;
     po_stats sum = {};
-    bool streamed = false;
+    bool streamed = false, overflowed = false;
     float ms_upload = 0;
     try {
         st = init_device(h);
@@ -2641,6 +2641,7 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
                 streamed = true;
             } else if (st == PO_OK) {
                 // (rare: more containments of later reads than the list holds -- the reads are resident now)
+                overflowed = true;
                 if (hipStreamSynchronize(h->copy_stream) != hipSuccess) st = fail(h, PO_ERR_HIP, "copy stream");
                 R.total = 0;
                 sum = po_stats();
@@ -2689,7 +2690,7 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
     S.ms_scan_probe = sum.ms_scan_probe;
     S.ms_verify_kernel = sum.ms_verify_kernel;
     S.streamed = streamed ? 1u : 0u;
-    S.n_deferred = streamed ? h->defer_need : 0u;
+    S.n_deferred = (streamed || overflowed) ? h->defer_need : 0u;   // (streamed == 0 with n_deferred > 0: the list overflowed, chunked form taken)
     if (streamed) {
         S.ms_upload = ms_upload;
         S.upload_bytes = h->upload_bytes;

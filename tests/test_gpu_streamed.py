@@ -95,7 +95,7 @@ def test_deferred_list_overflow_falls_back_to_the_chunked_form(monkeypatch):
         ov.add_sequence("r%d" % i, s)
     res = ov.overlaps_to_host_result(m)
     st = ov.stats()
-    assert st["streamed"] == 0          # the list overflowed: nothing of the streamed attempt was handed out
+    assert st["streamed"] == 0 and st["n_deferred"] > 3   # the list overflowed: nothing of the streamed attempt was handed out
     ck.assert_same_rows(oo.sort_rows(oo.struct_to_rows(res.rows_view())), want, seqs, m, "overflow fallback")
     res.free()
     monkeypatch.delenv("PHASM_DEFER_CAP")
@@ -111,7 +111,7 @@ def test_deferred_list_overflow_falls_back_to_the_chunked_form(monkeypatch):
 def test_streamed_fuzz_against_the_oracle(monkeypatch):
     monkeypatch.setenv("PHASM_STREAM", "1")
     rng = np.random.default_rng(4711)
-    for trial in range(12):
+    for trial in range(int(os.environ.get("PHASM_SOAK_TRIALS", "12"))):   # (a soak run sets a few hundred)
         cuts = sorted(set(int(c) for c in rng.integers(1, 999, size=int(rng.integers(1, 9)))))
         monkeypatch.setenv("PHASM_STREAM_CUTS", ",".join(str(c) for c in cuts))
         n = int(rng.integers(4, 90))
@@ -123,7 +123,8 @@ def test_streamed_fuzz_against_the_oracle(monkeypatch):
         monkeypatch.setenv("PHASM_INDEX", "narrow" if trial % 2 else "wide")
         want = ck.oracle_overlaps(seqs, m)
         (got, st), = streamed_rows(seqs, m)
-        assert st["streamed"] == 1 or not any(len(x) >= m for x in seqs)
+        # (tiny min_length: more containment candidates of later reads than the deferred list holds -> the chunked form)
+        assert st["streamed"] == 1 or st["n_deferred"] > 65536 or not any(len(x) >= m for x in seqs)
         ck.assert_same_rows(got, want, seqs, m, "fuzz trial %d, cuts %s, m %d" % (trial, cuts, m))
 
 
