@@ -117,3 +117,32 @@ int oracle_overlaps_ex(const uint8_t* cat, const uint64_t* offs, const uint32_t*
 }
 
 void oracle_ex_free(void* p) { free(p); }
+
+/* ---- pair-level entry points for the FULL-SIZE tests (tests/test_gpu_fullsize.py): the candidates of a 100 k-read set
+ * are known from the generator's truth, so the checker does not search anchors, it evaluates listed pairs.
+ * cat = all reads back to back; candidate k compares x = cat[ax[k] .. ax[k]+rem[k]) with y = cat[ay[k] .. ay[k]+lb[k]). */
+
+/* Hamming distance of the first n[k] bytes of both sides (substitution-only noise: an upper bound of the DP's cost on
+ * the main diagonal, and equal to it unless two indels beat the substitutions between them). */
+void oracle_pair_hamming(const uint8_t* cat, uint64_t npairs, const uint64_t* ax, const uint64_t* ay, const uint32_t* n, uint32_t* out) {
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t k = 0; k < (int64_t)npairs; ++k) {
+        const uint8_t* x = cat + ax[k];
+        const uint8_t* y = cat + ay[k];
+        uint32_t h = 0;
+        for (uint32_t i = 0; i < n[k]; ++i) h += x[i] != y[i];
+        out[k] = h;
+    }
+}
+
+/* extend_one on listed pairs: out[4k..4k+4) = {okA, jA, okB, iB}. */
+void oracle_extend_pairs(const uint8_t* cat, uint64_t npairs, const uint64_t* ax, const uint32_t* rem, const uint64_t* ay,
+                         const uint32_t* lb, uint32_t max_diff, uint32_t band, uint32_t* out) {
+    const uint32_t W = max_diff ? band : 0;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t k = 0; k < (int64_t)npairs; ++k) {
+        int okA, okB; uint32_t jA = 0, iB = 0;
+        extend_one(cat + ax[k], rem[k], cat + ay[k], lb[k], max_diff, W, &okA, &jA, &okB, &iB);
+        out[4 * k] = (uint32_t)okA; out[4 * k + 1] = jA; out[4 * k + 2] = (uint32_t)okB; out[4 * k + 3] = iB;
+    }
+}

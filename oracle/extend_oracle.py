@@ -29,6 +29,10 @@ def _load():
                                            ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
         lib.oracle_ex_free.argtypes = [ctypes.c_void_p]
+        lib.oracle_pair_hamming.restype = None
+        lib.oracle_pair_hamming.argtypes = [ctypes.c_void_p, ctypes.c_uint64] + [ctypes.c_void_p] * 4
+        lib.oracle_extend_pairs.restype = None
+        lib.oracle_extend_pairs.argtypes = [ctypes.c_void_p, ctypes.c_uint64] + [ctypes.c_void_p] * 4 + [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
         _lib = lib
     return _lib
 
@@ -56,3 +60,34 @@ def oracle_overlaps_ex(seqs: Sequence, min_length: int, max_diff: int, band: int
         arr = np.empty(0, dtype=ROW_DTYPE)
     lib.oracle_ex_free(rows_p)
     return sort_rows(struct_to_rows(arr))
+
+
+def pair_hamming(cat: np.ndarray, ax: np.ndarray, ay: np.ndarray, n: np.ndarray) -> np.ndarray:
+    """Hamming distance of ``cat[ax[k]:ax[k]+n[k]]`` and ``cat[ay[k]:ay[k]+n[k]]`` for every listed pair (all host cores)."""
+    lib = _load()
+    cat = np.ascontiguousarray(cat, dtype=np.uint8)
+    ax = np.ascontiguousarray(ax, dtype=np.uint64)
+    ay = np.ascontiguousarray(ay, dtype=np.uint64)
+    n = np.ascontiguousarray(n, dtype=np.uint32)
+    assert len(ax) == len(ay) == len(n)
+    assert not len(n) or (int((ax + n).max()) <= len(cat) and int((ay + n).max()) <= len(cat))
+    out = np.zeros(len(n), dtype=np.uint32)
+    lib.oracle_pair_hamming(cat.ctypes.data, len(n), ax.ctypes.data, ay.ctypes.data, n.ctypes.data, out.ctypes.data)
+    return out
+
+
+def extend_pairs(cat: np.ndarray, ax: np.ndarray, rem: np.ndarray, ay: np.ndarray, lb: np.ndarray, max_diff: int, band: int) -> np.ndarray:
+    """The restatement's DP (``extend_one``) on listed candidates: (n, 4) uint32 ``okA, jA, okB, iB`` -- x = ``cat[ax:ax+rem]``
+    (a from the anchor position to its end), y = ``cat[ay:ay+lb]`` (all of b)."""
+    lib = _load()
+    cat = np.ascontiguousarray(cat, dtype=np.uint8)
+    ax = np.ascontiguousarray(ax, dtype=np.uint64)
+    ay = np.ascontiguousarray(ay, dtype=np.uint64)
+    rem = np.ascontiguousarray(rem, dtype=np.uint32)
+    lb = np.ascontiguousarray(lb, dtype=np.uint32)
+    assert len(ax) == len(ay) == len(rem) == len(lb)
+    assert not len(ax) or (int((ax + rem).max()) <= len(cat) and int((ay + lb).max()) <= len(cat))
+    out = np.zeros((len(ax), 4), dtype=np.uint32)
+    lib.oracle_extend_pairs(cat.ctypes.data, len(ax), ax.ctypes.data, rem.ctypes.data, ay.ctypes.data, lb.ctypes.data,
+                            int(max_diff), int(band), out.ctypes.data)
+    return out

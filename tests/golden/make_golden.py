@@ -159,6 +159,9 @@ LADDER = {
                                            ploidy=2, snp=0.005, seed=2), 1000),
     "ladder_cfg4_noise": (synth.SynthConfig(n_reads=120, read_len=15_000, genome_len=40_000,
                                             ploidy=2, snp=0.005, seed=4, noise=0.01), 1000),
+    # low noise: some overlaps survive it, so the noise branch of synth.expected_rows is pinned by non-empty output
+    "ladder_lownoise": (synth.SynthConfig(n_reads=200, read_len=3000, genome_len=20_000, ploidy=2,
+                                          snp=0.004, seed=14, noise=0.0004), 300),
     # BASELINE.json configs[0] at FULL size: 1k reads (~10 kb), min-overlap 1000 -- the reference's own
     # CPU-runnable case (about 40 s of reference time)
     "cfg1_full": (synth.CONFIGS["cfg1"], 1000),

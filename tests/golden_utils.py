@@ -43,7 +43,7 @@ def repeats_cases():
 
 
 LADDER_NAMES = ["ladder_small", "ladder_varlen", "ladder_cfg1_mini", "ladder_cfg2_mini",
-                "ladder_cfg4_noise", "cfg1_full", "cfg2_1k", "cfg3_1k", "cfg5_1k"]
+                "ladder_cfg4_noise", "ladder_lownoise", "cfg1_full", "cfg2_1k", "cfg3_1k", "cfg5_1k"]
 
 
 def ladder_case(name):

@@ -130,7 +130,8 @@ def test_rccl_collectives_one_rank_group():
 
 @pytest.mark.skipif(os.environ.get("PHASM_SKIP_FULL") == "1", reason="full-size run disabled")
 def test_full_size_cfg2_properties():
-    """50k x 15 kb (100k oriented reads): too big for the CPU oracle in seconds, so check what must
+    """50k x 15 kb (100k oriented reads): too big for the CPU oracle in seconds -- the rows are compared with the
+    generator-derived expected multiset (exact), and on top with what must
     hold at any size: every row is a true match on the original strings (sampled), A rows are unique
     per (a,b) and reach the end of a, B rows cover the whole of b, the multiset is closed under the
     strand mirror, and a sampled set of reads agrees with the CPU oracle run on
@@ -160,6 +161,13 @@ def test_full_size_cfg2_properties():
     assert np.array_equal(oo.sort_rows(oo.struct_to_rows(sharded)), oo.sort_rows(oo.struct_to_rows(arr)))
     del sharded
     ov.close()
+    # THE WHOLE MULTISET, exactly: what the generator's truth says the reference must return for these reads
+    # (synth.expected_rows, pinned to the reference on all ladder goldens by tests/test_synth_truth.py)
+    import rowsig
+    want_all = synth.expected_rows(cfg, 1000)
+    rowsig.assert_same_multiset(oo.struct_to_rows(arr), want_all, "cfg2 at full size")
+    assert np.array_equal(oo.sort_rows(oo.struct_to_rows(arr)), oo.sort_rows(want_all))
+    del want_all
     lens = np.array([len(s) for _, s in oriented], dtype=np.int64)
     a, b = arr["a_idx"].astype(np.int64), arr["b_idx"].astype(np.int64)
     s, e, bs, be = (arr[k].astype(np.int64) for k in ("astart", "aend", "bstart", "bend"))
