@@ -187,6 +187,38 @@ def layout_leg(ov: ExactOverlapper, m: int, with_cpu: bool) -> dict:
     return out
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU, RCCL) as CHILD processes and pass rank 0's
+    JSON line on.  The parent never initialises the GPU (a process that has must not exec or fork GPU work), it only counts
+    devices; with --dist-backend gloo the ranks share whatever GPUs there are (a rehearsal, merged on the host)."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()      # (does not initialise the runtime)
+    if args.dist_backend == "nccl" and n_dev < args.gpus:
+        print("bench.py --gpus %d: only %d GPU(s) visible (RCCL needs one device per rank; --dist-backend gloo rehearses "
+              "the N-rank step on fewer)" % (args.gpus, n_dev), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's peer mappings need it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if p.returncode != 0 or line is None:
+        print("bench.py: the %d-rank run failed (exit code %d)" % (args.gpus, p.returncode), file=sys.stderr)
+        return p.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +237,11 @@ def main() -> int:
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearse the N>1 path with several ranks on one GPU (rows merged on the host)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: this process never touches the GPU, it starts the N ranks as a child
+        # (torch.distributed.run) and relays rank 0's JSON line
+        return launch_ranks(args)
 
     # stdout carries exactly ONE line, the JSON: RCCL prints a version banner on stdout when its first
     # communicator comes up, and libraries may print what they like -- everything written to descriptor 1 from
@@ -235,6 +272,13 @@ def main() -> int:
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group("gloo")
+        # how many ranks really take part in a collective (goes into the line as `rccl_ranks`)
+        ones = torch.ones(1, dtype=torch.int64, device=merge_device)
+        dist.all_reduce(ones)
+        ranks_in_collective = int(ones.item())
+        assert ranks_in_collective == dist.get_world_size() == world
+    else:
+        ranks_in_collective = 1
 
     cfg = synth.CONFIGS[args.config]
     if args.reads:
@@ -378,6 +422,9 @@ def main() -> int:
                        "parallelism": "each rank uploads 1/N of the packed reads, one RCCL all-gather over xGMI completes every rank's copy; a-side read shards x%d + one RCCL all-gather of verified candidates (16 B, fixed slots) per step + local row expansion on every rank; each rank copies 1/%d of the merged rows to its host" % (world, world) if world > 1
                                       else "single GPU"},
             "rows_per_step": int(n_rows),
+            "rccl_ranks": ranks_in_collective if args.dist_backend == "nccl" else 0,
+            "dist_backend": (args.dist_backend if (world > 1 or args.dist_path) else None),
+            "ranks": ranks_in_collective,
             "read_pairs_per_sec": n_oriented * (n_oriented - 1) / (dt / K),
             "resident": {"overlaps_per_sec": n_rows / (dt_res / K), "ms_per_step": dt_res / K * 1e3,
                          "stage_ms": {k: round(v, 4) for k, v in avg_res.items()},

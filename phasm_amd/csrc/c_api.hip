@@ -222,8 +222,26 @@ po_status fail(po_handle* h, po_status st, const std::string& msg) {
         }                                                                                       \
     } while (0)
 
+// PHASM_ALLOC_TRACE=1: every allocation / registration a call makes, with its wall time, on stderr (developer aid:
+// what a COLD call -- the first one on a handle -- pays that the steady state does not)
+struct AllocTrace {
+    const char* what;
+    size_t bytes;
+    std::chrono::steady_clock::time_point t0;
+    bool on;
+    AllocTrace(const char* w, size_t b) : what(w), bytes(b), on(getenv("PHASM_ALLOC_TRACE") != nullptr) {
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    ~AllocTrace() {
+        if (on)
+            std::fprintf(stderr, "[alloc] %-16s %10.3f MB  %8.3f ms\n", what, bytes / 1e6,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
 po_status ensure(po_handle* h, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return PO_OK;
+    AllocTrace tr("hipMalloc", bytes);
     b.release();
     size_t want = bytes + bytes / 8 + 256;
     hipError_t e = hipMalloc(&b.p, want);
@@ -241,6 +259,7 @@ po_status ensure(po_handle* h, DevBuf& b, size_t bytes) {
 
 po_status ensure_host(po_handle* h, HostBuf& b, size_t bytes) {
     if (bytes <= b.cap) return PO_OK;
+    AllocTrace tr("hipHostMalloc", bytes);
     b.release();
     const size_t want = bytes + bytes / 16 + 4096;
     hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
@@ -273,6 +292,7 @@ void pin_words(po_handle* h, int k) {
     const size_t bytes = h->words[k].size() * 8;
     if (bytes < (1u << 20) || getenv("PHASM_NO_PIN")) return;
     if (h->reg_ptr[k] == (void*)h->words[k].data() && h->reg_bytes[k] == bytes) return;
+    AllocTrace tr("hipHostRegister", bytes);
     if (h->reg_ptr[k]) {
         (void)hipStreamSynchronize(h->stream);
         (void)hipHostUnregister(h->reg_ptr[k]);
@@ -298,6 +318,7 @@ po_status init_device(po_handle* h) {
         HIP_TRY(h, hipSetDevice(h->device));
         return PO_OK;
     }
+    AllocTrace tr("init_device", 0);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0)

@@ -213,7 +213,9 @@ def test_full_size_cfg4_banded_dp_equals_truth_and_the_cpu_dp(monkeypatch):
     assert (pos < len(ckey)).all() and (ckey[order][np.minimum(pos, len(ckey) - 1)] == key(rows[:, 0], rows[:, 1], rows[:, 2])).all(), "a row without a true anchor"
     cand_of_row = order[pos]
     is_a_row = rows[:, 3] == la[cand_of_row]
-    assert (np.bincount(cand_of_row[is_a_row], minlength=len(a)) <= 1).all()
+    # (a candidate with p <= band may also have a B row, and one that ends where a ends looks like an A row here;
+    # which rows exactly is settled against the CPU DP below)
+    assert (np.bincount(cand_of_row[is_a_row], minlength=len(a)) <= 1 + (p <= DP_W)).all()
     has_a = np.zeros(len(a), dtype=bool)
     has_a[cand_of_row[is_a_row]] = True
     assert has_a[H <= DP_E].all(), "a candidate within max_diff substitutions has no A row"
