@@ -187,6 +187,59 @@ def layout_leg(ov: ExactOverlapper, m: int, with_cpu: bool) -> dict:
     return out
 
 
+def cli_overlap_leg(reads, m: int) -> dict:
+    """`python -m phasm_amd.cli overlap reads.fasta -l m -o out.gfa` in a fresh process: interpreter start, GPU runtime
+    start, FASTA ingest, the ONE cold overlap call, GFA2 written -- the wall time of the whole command."""
+    import shutil
+    import subprocess
+    import tempfile
+    d = tempfile.mkdtemp(prefix="phasm_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        fa, out = os.path.join(d, "reads.fasta"), os.path.join(d, "overlaps.gfa")
+        synth.write_fasta(fa, reads)
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        t0 = time.perf_counter()
+        p = subprocess.run([sys.executable, "-m", "phasm_amd.cli", "overlap", fa, "-l", str(m), "-o", out],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, text=True)
+        dt = time.perf_counter() - t0
+        if p.returncode != 0:
+            return {"error": p.stderr[-500:]}
+        n_e = 0
+        with open(out, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 24), b""):
+                n_e += chunk.count(b"\nE\t")
+        return {"cli_overlap_seconds": dt, "fasta_bytes": os.path.getsize(fa), "gfa_bytes": os.path.getsize(out), "e_lines": n_e,
+                "note": "wall time of the child process `python -m phasm_amd.cli overlap` (files in /dev/shm): interpreter + GPU runtime start, "
+                        "FASTA ingest, one cold po_overlaps call, S and E lines written"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def cold_call_leg(dev_idx: int, oriented, m: int, n_handles: int = 3) -> dict:
+    """The first call on a FRESH handle -- what the reference's one-shot caller sees (the index is built inside the one call,
+    overlapper.cpp:33-36; `phasm overlap` makes exactly one, assembler.py:42): po_create ... reads added (untimed, like
+    addSequence) ... then po_overlaps_to_host + po_result_rows timed, next to the second call on the same handle."""
+    cold, second = [], []
+    rows = 0
+    for _ in range(n_handles):
+        ov = ExactOverlapper(device=dev_idx)
+        for name, seq in oriented:
+            ov.add_sequence(name, seq)
+        torch.cuda.synchronize()
+        for dst in (cold, second):
+            if dst is second:
+                ov.invalidate()
+            t0 = time.perf_counter()
+            res = ov.overlaps_to_host_result(m)
+            rows = len(res.rows_view())
+            dst.append((time.perf_counter() - t0) * 1e3)
+            res.free()
+        ov.close()
+    return {"cold_call_ms": min(cold), "cold_call_ms_all": [round(x, 3) for x in cold], "second_call_ms": [round(x, 3) for x in second],
+            "rows": rows, "note": "fresh handle each time (this process has run the step before): po_create, reads added untimed, "
+                                  "then ONE po_overlaps_to_host + po_result_rows timed"}
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU, RCCL) as CHILD processes and pass rank 0's
     JSON line on.  The parent never initialises the GPU (a process that has must not exec or fork GPU work), it only counts
@@ -232,6 +285,8 @@ def main() -> int:
     ap.add_argument("--no-tuples", action="store_true", help="skip the Python tuple materialisation leg")
     ap.add_argument("--no-stream", action="store_true", help="N=1: upload the whole read set first (po_upload), then call po_overlaps_to_host (the unstreamed form of the step)")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the config-4 leg (exact path + banded DP)")
+    ap.add_argument("--no-cli", action="store_true", help="skip the `overlap` command leg (a child process: FASTA file in, GFA2 file out)")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-call leg (first call on fresh handles)")
     ap.add_argument("--dist-path", action="store_true",
                     help="dev: run the N>1 code path (shard + RCCL all-gather + expansion) even with one rank")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -255,6 +310,15 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    cfg = synth.CONFIGS[args.config]
+    if args.reads:
+        cfg = synth.scaled(cfg, args.reads)
+    reads_once = synth.generate_reads(cfg)
+    # the `overlap` COMMAND as a user runs it -- one process, one call (assembler.py:42): FASTA file in, GFA2 file out.
+    # Run as a child BEFORE this process touches the GPU (a process that has initialised the GPU starts no children).
+    cli_leg = None
+    if world == 1 and not args.dist_path and not args.no_cli:
+        cli_leg = cli_overlap_leg(reads_once, args.min_length)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the overlap path has no CPU fallback)")
     n_dev = torch.cuda.device_count()
@@ -280,12 +344,11 @@ def main() -> int:
     else:
         ranks_in_collective = 1
 
-    cfg = synth.CONFIGS[args.config]
-    if args.reads:
-        cfg = synth.scaled(cfg, args.reads)
     t_load = time.time()
+    oriented_once = synth.oriented(reads_once)
+    del reads_once
     ov = ExactOverlapper(device=dev_idx)
-    for name, seq in synth.oriented(synth.generate_reads(cfg)):
+    for name, seq in oriented_once:
         ov.add_sequence(name, seq)
     ov.upload()  # packed reads resident in HBM before anything is timed
     n_oriented = len(ov)
@@ -550,6 +613,14 @@ def main() -> int:
                 del tup
             out["roofline"]["hbm_copy_measured"] = measured_hbm_gbs(device)   # GB/s of a d2d copy on this box
             out["layout_stage1"] = layout_leg(ov, m, not args.no_cpu_baseline)
+            if not args.no_cold:
+                cc = cold_call_leg(dev_idx, oriented_once, m)
+                out["cold_call_ms"] = cc["cold_call_ms"]
+                out["cold_call"] = cc
+                out["cold_over_steady"] = cc["cold_call_ms"] / ms_step
+            if cli_leg is not None:
+                out["cli_overlap_seconds"] = cli_leg.get("cli_overlap_seconds")
+                out["cli_overlap"] = cli_leg
             if not args.no_cfg4 and not args.reads:
                 out["cfg4_extension"] = cfg4_leg(dev_idx, m, 400, 8)
             if not args.no_cpu_baseline:

@@ -34,11 +34,13 @@ namespace {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool arena = false;   // carved out of the handle's arena (po_handle::arena_*): lives until the handle dies
     template <typename T> T* as() const { return static_cast<T*>(p); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !arena) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        arena = false;
     }
 };
 
@@ -60,6 +62,46 @@ enum { EV_START = 0, EV_INDEX, EV_COUNT, EV_FILL, EV_VERIFY, EV_SELECT, EV_EMIT,
 }  // namespace
 
 constexpr int PO_MAX_PIECES = 16;
+
+// The packed host stores live in memory that is REGISTERED with the HIP runtime from the moment it is allocated
+// (page-aligned malloc + hipHostRegister, portable across devices): po_add_sequence grows the stores, so the cost of
+// pinning is paid there, piece by piece as the vector doubles -- not inside the first po_overlaps call, whose H2D then
+// runs at the DMA rate straight away (a cold call used to start with 2-4 ms of hipHostRegister).  Without a GPU (or
+// with PHASM_NO_PIN) the registration fails or is skipped and the memory is plain heap: the copy works either way.
+struct RegHeader {
+    size_t bytes;
+    int registered;
+};
+constexpr size_t REG_PAGE = 4096;
+template <class T>
+struct RegAlloc {
+    using value_type = T;
+    RegAlloc() = default;
+    template <class U> RegAlloc(const RegAlloc<U>&) {}
+    T* allocate(size_t n) {
+        const size_t bytes = ((n * sizeof(T) + REG_PAGE - 1) / REG_PAGE) * REG_PAGE;
+        void* base = nullptr;
+        if (posix_memalign(&base, REG_PAGE, bytes + REG_PAGE) != 0 || !base) throw std::bad_alloc();
+        RegHeader* hd = static_cast<RegHeader*>(base);
+        hd->bytes = bytes;
+        hd->registered = 0;
+        char* data = static_cast<char*>(base) + REG_PAGE;
+        if (bytes >= (1u << 20) && !getenv("PHASM_NO_PIN")) {
+            if (hipHostRegister(data, bytes, hipHostRegisterPortable) == hipSuccess) hd->registered = 1;
+            else (void)hipGetLastError();
+        }
+        return reinterpret_cast<T*>(data);
+    }
+    void deallocate(T* p, size_t) {
+        char* base = reinterpret_cast<char*>(p) - REG_PAGE;
+        RegHeader* hd = reinterpret_cast<RegHeader*>(base);
+        if (hd->registered) (void)hipHostUnregister(p);
+        free(base);
+    }
+    template <class U> bool operator==(const RegAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const RegAlloc<U>&) const { return false; }
+};
+using WordStore = std::vector<uint64_t, RegAlloc<uint64_t>>;
 
 struct po_handle {
     int device = 0;
@@ -84,7 +126,7 @@ struct po_handle {
     // as the reads arrive) only store 0 crosses PCIe and store 1 is rebuilt on the device -- half the H2D bytes.
     // On the device the two stores are one buffer [store 0 | store 1 | padding]; d_woff holds absolute offsets.
     std::vector<uint64_t> woff;
-    std::vector<uint64_t> words[2];
+    WordStore words[2];
     bool all_pairs_rc = true;   // every complete (even, odd) pair so far: same length, odd == revcomp(even), no exception records
     uint64_t base1 = 0;         // first word of store 1 in the device buffer (set at upload)
     uint64_t dev_words = 0;     // words in the device buffer, padding included
@@ -116,10 +158,17 @@ struct po_handle {
     DevBuf spare_edges;
     HostBuf spare_host;    // pinned row buffer of a freed result, kept for the next po_result_rows
     HostBuf scratch_host;  // pinned landing zone for small device->host copies into caller memory
-    // the packed host store registered with the HIP runtime (hipHostRegister) while it is unchanged: the H2D of
-    // po_upload then runs at the DMA rate instead of through the runtime's staging buffers
-    void* reg_ptr[2] = {nullptr, nullptr};
-    size_t reg_bytes[2] = {0, 0};
+    // pinned result pool sized while the reads are added (result_pool_grow): bytes of total_bases it was sized for
+    uint64_t pool_bases = 0;
+    // streamed step: per-piece workspaces are sized for the LARGEST piece when the first one asks (ws_scale > 1), so
+    // that no later piece has to free and re-allocate (hipFree synchronises the device)
+    double ws_scale = 1.0;
+    // small device workspaces (<= 8 MB each, some forty of them) are carved out of 64 MB chunks instead of being
+    // allocated one by one: on a process whose allocator has handed memory back, every small hipMalloc is a trip to
+    // the kernel driver (0.2 ms each, 4 ms per first call of a handle)
+    std::vector<void*> arena_chunks;
+    char* arena_cur = nullptr;
+    size_t arena_left = 0;
     int poison = -1;       // PHASM_POISON=<byte>: per-call workspaces are filled with it before every call
     // po_overlaps_ex: the verify step is the banded DP of extend.hip.h (set around the call by po_overlaps_ex)
     // po_overlaps_to_host: a second stream copies chunk k's rows to the host while chunk k + 1 is computed
@@ -239,11 +288,37 @@ struct AllocTrace {
     }
 };
 
-po_status ensure(po_handle* h, DevBuf& b, size_t bytes) {
+po_status ensure(po_handle* h, DevBuf& b, size_t bytes, double scale = 1.0) {
     if (bytes <= b.cap) return PO_OK;
     AllocTrace tr("hipMalloc", bytes);
+    const bool first = b.p == nullptr;
     b.release();
     size_t want = bytes + bytes / 8 + 256;
+    if (scale > 1.0) want = (size_t)((double)bytes * scale) + 256;   // (a streamed piece: room for the largest piece)
+    constexpr size_t ARENA_CHUNK = 64u << 20, ARENA_MAX = 8u << 20;
+    if (h && first && want <= ARENA_MAX && !getenv("PHASM_NO_ARENA")) {
+        // (only a buffer's FIRST allocation: one that has to grow moves out, so a chunk never fills up with dead pieces)
+        want = (want + 255) & ~size_t(255);
+        if (h->arena_left < want) {
+            void* c = nullptr;
+            if (hipMalloc(&c, ARENA_CHUNK) == hipSuccess) {
+                h->arena_chunks.push_back(c);
+                h->arena_cur = static_cast<char*>(c);
+                h->arena_left = ARENA_CHUNK;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (h->arena_left >= want) {
+            b.p = h->arena_cur;
+            b.cap = want;
+            b.arena = true;
+            h->arena_cur += want;
+            h->arena_left -= want;
+            if (h->poison >= 0 && h->stream) (void)hipMemsetAsync(b.p, h->poison, want, h->stream);
+            return PO_OK;
+        }
+    }
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) {
         b.p = nullptr;
@@ -256,6 +331,9 @@ po_status ensure(po_handle* h, DevBuf& b, size_t bytes) {
     if (h && h->poison >= 0 && h->stream) (void)hipMemsetAsync(b.p, h->poison, want, h->stream);
     return PO_OK;
 }
+
+// a workspace whose size follows the candidate count of the a-side range at hand
+po_status ensure_piece(po_handle* h, DevBuf& b, size_t bytes) { return ensure(h, b, bytes, h->ws_scale); }
 
 po_status ensure_host(po_handle* h, HostBuf& b, size_t bytes) {
     if (bytes <= b.cap) return PO_OK;
@@ -271,39 +349,45 @@ po_status ensure_host(po_handle* h, HostBuf& b, size_t bytes) {
     return PO_OK;
 }
 
-// the packed host store is about to change (or go away): the runtime must let go of it first
-void unpin_words(po_handle* h) {
-    if (!h->reg_ptr[0] && !h->reg_ptr[1]) return;
-    if (h->dev_ready) {
-        (void)hipSetDevice(h->device);
-        (void)hipStreamSynchronize(h->stream);
-    }
-    for (int k = 0; k < 2; ++k) {
-        if (h->reg_ptr[k]) (void)hipHostUnregister(h->reg_ptr[k]);
-        h->reg_ptr[k] = nullptr;
-        h->reg_bytes[k] = 0;
-    }
+// the packed host store is about to change (it may move, and the old block is unregistered and freed): no copy out of
+// it may be in flight
+void quiesce_store(po_handle* h) {
+    if (!h->dev_ready) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->up_stream) (void)hipStreamSynchronize(h->up_stream);
 }
 
-// Pin host store k in place (once per state of the store; po_add_* unpins before it changes it): a pageable
-// source goes through the runtime's staging buffers at a fraction of the PCIe rate.  Failure to register is not
-// an error -- the copy works either way.
-void pin_words(po_handle* h, int k) {
-    const size_t bytes = h->words[k].size() * 8;
-    if (bytes < (1u << 20) || getenv("PHASM_NO_PIN")) return;
-    if (h->reg_ptr[k] == (void*)h->words[k].data() && h->reg_bytes[k] == bytes) return;
-    AllocTrace tr("hipHostRegister", bytes);
-    if (h->reg_ptr[k]) {
-        (void)hipStreamSynchronize(h->stream);
-        (void)hipHostUnregister(h->reg_ptr[k]);
-        h->reg_ptr[k] = nullptr;
-        h->reg_bytes[k] = 0;
+// Pinned result pool, sized WHILE THE READS ARE ADDED.  A fresh 170 MB page-locked array costs 8 ms (hipHostMalloc maps
+// and pins every page), more than the whole steady-state call: a cold call that allocates it -- let alone grows it
+// twice, as the first call on a handle used to -- pays several times the step.  How many rows a call will return is
+// not known before the scan, so the pool is a guess made from what IS known, the bases added so far: one row per
+// 160 oriented bases (BASELINE config 2 gives one per 214, config 3 one per 320, config 5 one per 436), re-made
+// whenever the read set has grown by half, capped at 4 GB.  A call that needs more grows the array as before.
+po_status init_device(po_handle* h);
+
+void result_pool_grow(po_handle* h) {
+    h->pool_bases = h->total_bases + h->total_bases / 2;   // next look when the set has grown by half
+    if (getenv("PHASM_NO_POOL")) return;
+    // a read set this size is headed for the GPU: bring the device up now (runtime start, stream, events: 130 ms in a
+    // fresh process) rather than inside the first call.  No GPU: the call itself will say so.
+    if (!h->dev_ready && init_device(h) != PO_OK) h->err.clear();
+    const uint64_t want = std::min<uint64_t>(h->pool_bases / 160 * sizeof(po_row), 4ull << 30);
+    if (h->spare_host.cap >= want || h->live_results) return;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        h->pool_bases = ~0ull;   // no GPU here: never ask again
+        return;
     }
-    if (hipHostRegister(h->words[k].data(), bytes, hipHostRegisterDefault) == hipSuccess) {
-        h->reg_ptr[k] = h->words[k].data();
-        h->reg_bytes[k] = bytes;
+    AllocTrace tr("result pool", want);
+    h->spare_host.release();
+    if (hipHostMalloc(&h->spare_host.p, want, hipHostMallocPortable) == hipSuccess) {
+        h->spare_host.cap = want;
     } else {
         (void)hipGetLastError();
+        h->spare_host.p = nullptr;
+        h->pool_bases = ~0ull;
     }
 }
 
@@ -336,6 +420,9 @@ po_status init_device(po_handle* h) {
     HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->pinned), 512, hipHostMallocDefault));
     HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pinned_dev), h->pinned, 0));
     if (const char* e = getenv("PHASM_POISON")) h->poison = (int)(strtol(e, nullptr, 0) & 0xFF);
+    // the library's code object is loaded by the first launch out of it (15 ms in a fresh process): here, not in a call
+    hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->stream, reinterpret_cast<uint32_t*>(h->pinned_dev + 63), (uint64_t)1, 0u);
+    (void)hipGetLastError();
     h->dev_ready = true;
     return PO_OK;
 }
@@ -360,7 +447,7 @@ const BaseLut g_lut;
 // which case the caller moves the whole handle to 8 bits per base.
 bool append_packed(po_handle* h, const unsigned char* s, size_t n, int bits) {
     const size_t per = 64 / bits;
-    std::vector<uint64_t>& store = h->words[h->woff.size() & 1];  // (woff has one entry per read appended so far)
+    WordStore& store = h->words[h->woff.size() & 1];  // (woff has one entry per read appended so far)
     const size_t old_size = store.size();
     const size_t off = (old_size + 1) & ~size_t(1);
     const size_t nw = (n + per - 1) / per;
@@ -412,7 +499,7 @@ bool append_packed(po_handle* h, const unsigned char* s, size_t n, int bits) {
 }
 
 // The bytes of read r as they were added (2-bit mode: codes + exception records).
-void materialize(const po_handle* h, size_t r, const std::vector<uint64_t>* stores, const uint64_t* woff, std::vector<unsigned char>& out) {
+void materialize(const po_handle* h, size_t r, const WordStore* stores, const uint64_t* woff, std::vector<unsigned char>& out) {
     const uint32_t n = h->len[r];
     out.resize(n);
     const uint64_t* w = stores[r & 1].data() + woff[r];
@@ -423,7 +510,7 @@ void materialize(const po_handle* h, size_t r, const std::vector<uint64_t>* stor
 // Non-ACGT bytes too dense for exception records: re-encode everything held so far at 8 bits per
 // base (lossless).
 void widen_to_bytes(po_handle* h) {
-    std::vector<uint64_t> old_words[2];
+    WordStore old_words[2];
     std::vector<uint64_t> old_off;
     old_words[0].swap(h->words[0]);
     old_words[1].swap(h->words[1]);
@@ -584,8 +671,6 @@ po_status upload_meta(po_handle* h, bool* generate_out) {
     *generate_out = generate;
     h->base1 = base1;
     h->dev_words = nwords;
-    pin_words(h, 0);
-    if (!generate) pin_words(h, 1);
     PO_TRY(ensure(h, h->d_words, nwords * 8));
     PO_TRY(ensure(h, h->d_woff, ((size_t)n + 1) * 8));
     PO_TRY(ensure(h, h->d_len, ((size_t)n + 1) * 4));
@@ -729,7 +814,7 @@ po_status prefix_sum(po_handle* h, const T* in, uint64_t n, uint32_t* out, volat
     *total_host = 0;
     if (n == 0) return PO_OK;
     const uint32_t nblocks = cdiv(n, po::PS_TILE);
-    PO_TRY(ensure(h, h->d_ps_blocks, (size_t)nblocks * 8));
+    PO_TRY(ensure_piece(h, h->d_ps_blocks, (size_t)nblocks * 8));
     uint64_t* blocks = h->d_ps_blocks.as<uint64_t>();
     uint64_t* total_dev = h->d_scalars.as<uint64_t>();
     uint64_t* total_mapped = h->pinned_dev + (const_cast<uint64_t*>(total_host) - h->pinned);   // the slot as the device sees it
@@ -1139,12 +1224,12 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
 
     uint64_t n_rows64 = 0;
     if (n_cand) {
-        PO_TRY(ensure(h, h->d_cand_a, (size_t)n_cand * 4));
-        PO_TRY(ensure(h, h->d_cand_p, (size_t)n_cand * 4));
-        PO_TRY(ensure(h, h->d_cand_b, (size_t)n_cand * 4));
-        PO_TRY(ensure(h, h->d_type, (size_t)n_cand));
-        PO_TRY(ensure(h, h->d_rowcnt, (size_t)n_cand));
-        PO_TRY(ensure(h, h->d_row_off, ((size_t)n_cand + 1) * 4));
+        PO_TRY(ensure_piece(h, h->d_cand_a, (size_t)n_cand * 4));
+        PO_TRY(ensure_piece(h, h->d_cand_p, (size_t)n_cand * 4));
+        PO_TRY(ensure_piece(h, h->d_cand_b, (size_t)n_cand * 4));
+        PO_TRY(ensure_piece(h, h->d_type, (size_t)n_cand));
+        PO_TRY(ensure_piece(h, h->d_rowcnt, (size_t)n_cand));
+        PO_TRY(ensure_piece(h, h->d_row_off, ((size_t)n_cand + 1) * 4));
         A.cand_a = h->d_cand_a.as<uint32_t>();
         A.cand_p = h->d_cand_p.as<uint32_t>();
         A.cand_b = h->d_cand_b.as<uint32_t>();
@@ -1335,7 +1420,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             if (n_sus) {
                 pbits = 4;
                 while ((1ull << pbits) < 2ull * n_sus) ++pbits;
-                PO_TRY(ensure(h, h->d_pair_key, ((size_t)1 << pbits) * sizeof(po::PairSlot)));
+                PO_TRY(ensure_piece(h, h->d_pair_key, ((size_t)1 << pbits) * sizeof(po::PairSlot)));
                 hipLaunchKernelGGL(po::k_fill_gated, dim3((uint32_t)h->n_cu * 8), dim3(256), 0, st, h->d_pair_key.as<uint4>(),
                                    (uint64_t)((size_t)1 << pbits) * sizeof(po::PairSlot) / 16, 0xFFFFFFFFu, gate);
                 ptab = h->d_pair_key.as<po::PairSlot>();
@@ -1980,6 +2065,8 @@ void po_destroy(po_handle* h) {
         h->d_defer.release();
         h->first_host.release();
         h->meta_host.release();
+        for (void* c : h->arena_chunks) (void)hipFree(c);
+        h->arena_chunks.clear();
         if (h->up_stream) {
             (void)hipStreamSynchronize(h->up_stream);
             (void)hipStreamDestroy(h->up_stream);
@@ -1991,9 +2078,9 @@ void po_destroy(po_handle* h) {
             (void)hipStreamSynchronize(h->copy_stream);
             (void)hipStreamDestroy(h->copy_stream);
         }
-        unpin_words(h);
         (void)hipStreamDestroy(h->stream);
     }
+    h->spare_host.release();   // (the result pool may exist without the handle ever having made a call)
     delete h;
 }
 
@@ -2009,7 +2096,7 @@ po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const cha
     if (h->segments_only) return fail(h, PO_ERR_INVALID, "this handle holds GFA segments (no sequences); use a new handle");
     if (seq_len > 0x7FFFFFF0ull) return fail(h, PO_ERR_CAPACITY, "read longer than 2^31 bases");
     if (h->len.size() >= 0xFFFFFFF0ull) return fail(h, PO_ERR_CAPACITY, "too many reads");
-    unpin_words(h);  // (the store may move)
+    quiesce_store(h);  // (the store may move)
     try {
         const unsigned char* s = reinterpret_cast<const unsigned char*>(seq);
         if (h->bits != 2 || !append_packed(h, s, seq_len, 2)) {
@@ -2021,6 +2108,7 @@ po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const cha
         h->total_bases += seq_len;
         h->dirty = true;
         h->ids_paired = -1;
+        if (h->total_bases >= h->pool_bases && h->total_bases >= (64ull << 20)) result_pool_grow(h);
         if (h->bits == 2 && (h->len.size() & 1) == 0) {
             if (!h->exc_pos.empty()) host_pair_check(h, h->len.size() - 1, s);
             if (h->all_pairs_rc) h->all_pairs_rc = packed_is_revcomp(h, h->len.size() - 1);
@@ -2038,7 +2126,7 @@ po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const cha
 po_status po_add_fasta(po_handle* h, const char* path, int both_strands, uint64_t* n_records) {
     if (!h || !path) return PO_ERR_INVALID;
     if (n_records) *n_records = 0;
-    unpin_words(h);  // (the store may move)
+    quiesce_store(h);  // (the store may move)
     if (both_strands && !h->segments_only && !getenv("PHASM_FASTA_SEQUENTIAL")) {
         // fast path: map the file, pack with a few threads (pure upper-case ACGT only; see add_fasta_parallel)
         const int fd = ::open(path, O_RDONLY);
@@ -2061,7 +2149,10 @@ po_status po_add_fasta(po_handle* h, const char* path, int both_strands, uint64_
             }
         }
         ::close(fd);
-        if (done) return PO_OK;
+        if (done) {
+            if (h->total_bases >= h->pool_bases && h->total_bases >= (64ull << 20)) result_pool_grow(h);
+            return PO_OK;
+        }
     }
     FILE* f = std::fopen(path, "rb");
     if (!f) return fail(h, PO_ERR_INVALID, std::string("cannot open ") + path);
@@ -2176,7 +2267,6 @@ po_status po_upload_piece(po_handle* h, uint32_t shard, uint32_t nshards, void* 
     *ok = 1;
     if (!dst_device) return PO_OK;   // (a query: how many words is this shard's piece?)
     if (wc > capacity_words) return fail(h, PO_ERR_INVALID, "po_upload_piece: the piece does not fit the destination");
-    pin_words(h, 0);
     if (wc) HIP_TRY(h, hipMemcpyAsync(dst_device, h->words[0].data() + wb, wc * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->upload_bytes = wc * 8;
@@ -2313,12 +2403,15 @@ struct HostRows {
 
 // rows of one chunk: room in the page-locked array, then the copy on the copy stream (dev must stay untouched
 // until that stream has been synchronised)
-po_status append_rows(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t nk, uint32_t k, uint32_t n_chunks) {
+po_status append_rows(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t nk, uint32_t k, uint32_t n_chunks, double seen_share = 0.0) {
     if (nk == 0) return PO_OK;
     const size_t need = (size_t)(R.total + nk) * sizeof(po_row);
     if (need > R.hb.cap) {
-        // first call, or more rows than last time: guess the whole from what has been seen, move what is there
-        const uint64_t guess = std::max<uint64_t>(h->last_host_rows, (R.total + nk) * n_chunks / (k + 1));
+        // first call, or more rows than last time: guess the whole from what has been seen, move what is there.
+        // seen_share (streamed step): the share of all (a, b) index pairs the pieces so far cover -- rows grow with the
+        // SQUARE of the reads that have arrived, a linear guess from the first piece is 6 x short
+        uint64_t guess = std::max<uint64_t>(h->last_host_rows, (R.total + nk) * n_chunks / (k + 1));
+        if (seen_share > 0.0) guess = std::max<uint64_t>(guess, (uint64_t)((double)(R.total + nk) / seen_share * 1.05));
         HostBuf bigger;
         PO_TRY(ensure_host(h, bigger, std::max<size_t>(need, (size_t)(guess + guess / 8) * sizeof(po_row))));
         if (hipStreamSynchronize(h->copy_stream) != hipSuccess) {
@@ -2465,7 +2558,7 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
             for (uint32_t r = 0; r < n; ++r) {
                 // (a read owns its data words and a zero guard word; the word behind an EMPTY read is alignment padding,
                 // or -- for the last read of a store -- not part of the host store at all: zero on the device either way)
-                const std::vector<uint64_t>& store = h->words[r & 1];
+                const WordStore& store = h->words[r & 1];
                 const uint64_t o = h->woff[r];
                 f[2 * (size_t)r] = store[o];
                 f[2 * (size_t)r + 1] = o + 1 < store.size() ? store[o + 1] : 0;
@@ -2517,7 +2610,8 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
     // (a piece that emitted into a buffer known to be large enough returns with its kernels still queued), or below.
     auto completed = [&](uint32_t k, const po_stats& S, uint64_t nk) -> po_status {
         add_stats(sum, S);
-        PO_TRY(append_rows(h, R, h->chunk_rows[k], nk, k, P));
+        const double seen = (double)bounds[k + 1] / (double)n;
+        PO_TRY(append_rows(h, R, h->chunk_rows[k], nk, k, P, seen * seen));
         if (trace) {
             float up = 0;
             (void)hipEventElapsedTime(&up, h->ev_up0, h->ev_piece[k]);
@@ -2543,10 +2637,19 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
         h->st_on = true;
         h->st_r_begin = bounds[k];
         h->st_r_end = bounds[k + 1];
+        // per-piece workspaces: sized for the largest piece when they are first needed.  A piece keeps the candidates
+        // whose b lies below its a, so piece j has about (b[j+1]^2 - b[j]^2) / (b[k+1]^2 - b[k]^2) times piece k's
+        h->ws_scale = 1.0;
+        {
+            const double mine = (double)bounds[k + 1] * bounds[k + 1] - (double)bounds[k] * bounds[k];
+            for (uint32_t j = k + 1; j < P; ++j)
+                h->ws_scale = std::max(h->ws_scale, ((double)bounds[j + 1] * bounds[j + 1] - (double)bounds[j] * bounds[j]) / mine * 1.1);
+        }
         h->ev = h->ev_sets[k & 1];
         uint64_t nk = 0;
         st = run_chunk(h, min_length, k, P, &nk);
         h->st_on = false;
+        h->ws_scale = 1.0;
         if (st != PO_OK) break;
         if (h->st_pend.valid && h->st_pend.k == k) continue;   // piece k is queued, its counts are read later (an older one was collected inside)
         if (h->st_pend.valid) {
