@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PO_ABI_VERSION 2
+#define PO_ABI_VERSION 3
 
 typedef enum {
     PO_OK = 0,
@@ -94,6 +94,9 @@ typedef struct {
     uint32_t streamed;           /* po_overlaps_to_host: 1 = streamed step (reads uploaded piece by piece under the      */
     uint32_t n_deferred;         /*    kernels); n_deferred = containment candidates that waited for a later piece       */
                                  /*    (streamed == 0 with n_deferred > 0: their list overflowed, the chunked form ran)  */
+    uint32_t fused_tail;         /* chunks / pieces of the call whose select + row offsets + emission ran as ONE kernel   */
+    uint32_t tail_fallback;      /*    (k_tail: needs a kept row buffer that holds the worst case); tail_fallback = how   */
+                                 /*    often that kernel met tandem-repeat reads and the classic kernels ran instead      */
 } po_stats;
 
 /* ExactOverlapper()  -- src/overlapper.cpp:19, py::init at src/phasm.cpp:13. */

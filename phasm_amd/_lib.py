@@ -63,6 +63,7 @@ class PoStats(ctypes.Structure):
         ("max_diff", ctypes.c_uint32), ("band", ctypes.c_uint32), ("index_reused", ctypes.c_uint32),
         ("dp_lanes", ctypes.c_uint32), ("upload_bytes", ctypes.c_uint64),
         ("streamed", ctypes.c_uint32), ("n_deferred", ctypes.c_uint32),
+        ("fused_tail", ctypes.c_uint32), ("tail_fallback", ctypes.c_uint32),
     ]
 
     def as_dict(self) -> dict:

@@ -153,6 +153,8 @@ struct po_handle {
     DevBuf d_bloom, d_selfrep, d_tile_count, d_tile_off, d_truemask, d_ps_blocks, d_scalars, d_left, d_left_cnt, d_tile_extra;
     DevBuf d_cand_a, d_cand_p, d_cand_b, d_type, d_rowcnt, d_row_off, d_flag, d_pair_key, d_pair_min;
     DevBuf d_vlabel, d_vrank, d_vperm;  // verify order (k_read_label, k_read_sort, k_read_invert)
+    DevBuf d_chain_state;               // ticket / done / status words of the single-pass scans (all-zero between launches)
+    DevBuf d_tail_state;                // k_tile_rows / k_tail: row sums per tile of candidates + the done counter
     DevBuf spare_rows;   // device buffers of freed results, kept for the next call (hipFree / hipMalloc of a
     DevBuf spare_cands;  // 50-170 MB buffer costs ~0.2 ms each and synchronises the device)
     DevBuf spare_edges;
@@ -197,9 +199,11 @@ struct po_handle {
         uint32_t k = 0;
         po_stats S = {};
         bool ver_timed = false;
+        bool tail = false;         // the piece's tail ran as k_tail: counts in pinned[48..], fallback flag in pinned[55]
         hipEvent_t* ev = nullptr;
     } st_pend;
     std::function<po_status()> st_harvest;
+    bool st_tail_gave_up = false;  // the last streamed step was abandoned because of tandem-repeat reads (statistics / tests)
     bool st_on = false;            // run_overlaps works on piece [st_r_begin, st_r_end) of a streamed step
     uint32_t st_r_begin = 0, st_r_end = 0, st_defer_cap = 0;
     uint64_t last_host_rows = 0;   // rows of the previous po_overlaps_to_host call (sizes the pinned buffer up front)
@@ -808,18 +812,45 @@ void shard_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint32_t*
 
 // exclusive scan of n items (u8 or u32) -> u32 offsets; *total_host gets the grand total
 // (a pinned slot: valid after the next hipStreamSynchronize)
+// the state of the single-pass scans (kernels.hip.h, ChainState): zero when allocated, left zero by every launch
+po_status chain_state(po_handle* h, uint32_t n_tiles, po::ChainState** out) {
+    const size_t need = po::chain_state_bytes(n_tiles);
+    if (need > h->d_chain_state.cap) {
+        PO_TRY(ensure(h, h->d_chain_state, std::max<size_t>(need * 2, 1u << 16)));
+        HIP_TRY(h, hipMemsetAsync(h->d_chain_state.p, 0, h->d_chain_state.cap, h->stream));
+    }
+    *out = h->d_chain_state.as<po::ChainState>();
+    return PO_OK;
+}
+
 template <typename T>
 po_status prefix_sum(po_handle* h, const T* in, uint64_t n, uint32_t* out, volatile uint64_t* total_host,
-                     const uint64_t* also_src = nullptr, volatile uint64_t* also_host = nullptr) {
+                     const uint64_t* also_src = nullptr, volatile uint64_t* also_host = nullptr, const uint32_t* extra = nullptr) {
     *total_host = 0;
     if (n == 0) return PO_OK;
     const uint32_t nblocks = cdiv(n, po::PS_TILE);
-    PO_TRY(ensure_piece(h, h->d_ps_blocks, (size_t)nblocks * 8));
-    uint64_t* blocks = h->d_ps_blocks.as<uint64_t>();
     uint64_t* total_dev = h->d_scalars.as<uint64_t>();
     uint64_t* total_mapped = h->pinned_dev + (const_cast<uint64_t*>(total_host) - h->pinned);   // the slot as the device sees it
-    hipLaunchKernelGGL(po::k_ps_reduce<T>, dim3(nblocks), dim3(po::PS_BLOCK), 0, h->stream, in, n, blocks);
     uint64_t* also_mapped = also_host ? h->pinned_dev + (const_cast<uint64_t*>(also_host) - h->pinned) : nullptr;
+    if (nblocks <= 64 && !getenv("PHASM_PS_CLASSIC")) {
+        // ONE launch: decoupled look-back (k_ps_chain); `extra` is added to the input on the way (u32 inputs).  Short
+        // inputs only -- the tile counts of a piece or a shard: hundreds of tiles spinning on status words across the
+        // XCDs are slower than three launches
+
+        po::ChainState* cs = nullptr;
+        PO_TRY(chain_state(h, nblocks, &cs));
+        hipLaunchKernelGGL(po::k_ps_chain<T>, dim3(nblocks), dim3(po::PS_BLOCK), 0, h->stream, const_cast<T*>(in), extra, n, out, cs,
+                           nblocks, total_dev, total_mapped, also_src, also_mapped);
+        HIP_TRY(h, hipGetLastError());
+        return PO_OK;
+    }
+    if (extra) {   // (u32 inputs: add in place first, as a launch of its own)
+        hipLaunchKernelGGL(po::k_add_extra, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(in)),
+                           extra, 0u, (uint32_t)n);
+    }
+    PO_TRY(ensure_piece(h, h->d_ps_blocks, (size_t)nblocks * 8));
+    uint64_t* blocks = h->d_ps_blocks.as<uint64_t>();
+    hipLaunchKernelGGL(po::k_ps_reduce<T>, dim3(nblocks), dim3(po::PS_BLOCK), 0, h->stream, in, n, blocks);
     hipLaunchKernelGGL(po::k_ps_spine, dim3(1), dim3(1024), 0, h->stream, blocks, nblocks, total_dev, total_mapped, also_src, also_mapped);
     hipLaunchKernelGGL(po::k_ps_down<T>, dim3(nblocks), dim3(po::PS_BLOCK), 0, h->stream, in, n, blocks, out);
     HIP_TRY(h, hipGetLastError());
@@ -855,14 +886,18 @@ void stage_times(po_stats& S, hipEvent_t* ev, bool ver_timed) {
 
 // the closing part of run_overlaps for a pending piece of a streamed step; the handle's stream has been synchronised
 // since the piece was queued.  Returns the piece's row count.
-uint64_t finish_piece(po_handle* h) {
+// *needs_classic: k_tail found reads handed to the global (a, b) table and wrote nothing (the piece's workspaces have
+// been reused by now: the streamed step gives up and the call takes the chunked form).
+uint64_t finish_piece(po_handle* h, bool* needs_classic) {
     po_handle::Pending& P = h->st_pend;
-    const uint64_t n_rows = h->pinned[2];
+    const int o = P.tail ? 48 : 2, c = P.tail ? 49 : 4;
+    *needs_classic = P.tail && h->pinned[55] != 0;
+    const uint64_t n_rows = h->pinned[o];
     P.S.n_rows = n_rows;
-    P.S.n_verified = h->pinned[4];
-    P.S.sum_overlap_bases = h->pinned[5];
-    P.S.verify_bytes_algo = h->pinned[6];
-    P.S.verify_bytes_exec = h->pinned[7];
+    P.S.n_verified = h->pinned[c];
+    P.S.sum_overlap_bases = h->pinned[c + 1];
+    P.S.verify_bytes_algo = h->pinned[c + 2];
+    P.S.verify_bytes_exec = h->pinned[c + 3];
     stage_times(P.S, P.ev, P.ver_timed);
     P.valid = false;
     return n_rows;
@@ -941,6 +976,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     }
     if (ext_idx && !wide) return fail(h, PO_ERR_INVALID, "a sliced index was supplied, but this call uses the narrow index");
     bool rows_late = false;  // rows emitted into a kept buffer before their number reached the host
+    bool used_tail = false;  // the call's tail ran as k_tail (counts in pinned[48..], fallback flag in pinned[55])
+    std::function<po_status()> tail_fallback;
     bool ver_timed = false;  // the verify kernel ran (there were candidates): its own events are valid
     uint64_t n_keys = wide ? n_elig * W : n_elig;
     if (slice_build) n_keys = n_keys / h->sl_build_n + n_keys / (16ull * h->sl_build_n) + 4096;  // (a slice's share + slack)
@@ -1169,9 +1206,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
         auto fixup = streamed ? po::k_scan_fixup<BITS, CAN_STREAM> : po::k_scan_fixup<BITS, false>;
         hipLaunchKernelGGL(fixup, dim3(n_scan_waves), dim3(256), 0, st, A, n_scan_waves);
-        if (ntiles > po::PS_SMALL_MAX)   // (short tile ranges: folded into the one-workgroup prefix sum below)
-            hipLaunchKernelGGL(po::k_add_extra, dim3(cdiv(ntiles, 256)), dim3(256), 0, st, A.tile_count, A.tile_extra, tile_begin,
-                               tile_end);
+        // (the leftover counts, tile_extra, are added to the tile counts by the prefix sum below)
         if (getenv("PHASM_DEBUG_LEFT")) {  // how many positions did the scan waves defer to k_scan_fixup?
             PO_TRY(ensure_host(h, h->scratch_host, (size_t)n_scan_waves * 4));
             HIP_TRY(h, hipMemcpyAsync(h->scratch_host.p, h->d_left_cnt.p, (size_t)n_scan_waves * 4, hipMemcpyDeviceToHost, st));
@@ -1203,7 +1238,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                                 reinterpret_cast<const uint64_t*>(scalars + 2), &h->pinned[8]));
     } else {
         PO_TRY(prefix_sum<uint32_t>(h, A.tile_count + tile_begin, ntiles, h->d_tile_off.as<uint32_t>() + tile_begin, &h->pinned[1],
-                                    reinterpret_cast<const uint64_t*>(scalars + 2), &h->pinned[8]));
+                                    reinterpret_cast<const uint64_t*>(scalars + 2), &h->pinned[8],
+                                    wide ? nullptr : A.tile_extra + tile_begin));
     }
     HIP_TRY(h, hipEventRecord(h->ev[EV_COUNT], st));
     if (h->st_pend.valid && h->st_harvest) {
@@ -1223,6 +1259,13 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     const uint32_t n_cand = (uint32_t)n_cand64;
 
     uint64_t n_rows64 = 0;
+    // (the tail's variables live at function scope: classic_tail may run after the block below, as k_tail's fallback)
+    po::PairSlot* ptab = nullptr;
+    uint32_t pbits = 0;
+    uint32_t* n_deferred = reinterpret_cast<uint32_t*>(scalars + 1) + 1;  // reads k_select_local hands to the global table
+    const uint32_t* gate = nullptr;
+    const uint64_t worst_rows = (uint64_t)n_cand * (paired ? 4u : 2u);
+    std::function<po_status()> classic_tail;
     if (n_cand) {
         PO_TRY(ensure_piece(h, h->d_cand_a, (size_t)n_cand * 4));
         PO_TRY(ensure_piece(h, h->d_cand_p, (size_t)n_cand * 4));
@@ -1244,8 +1287,16 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             auto fill = streamed ? po::k_scan_fill<BITS, BITS == 2> : po::k_scan_fill<BITS, false>;
             hipLaunchKernelGGL(fill, dim3(cdiv(ntiles, 4 * po::FILL_TILES)), dim3(256), 0, st, A);
         }
-        if (streamed && r_end < n) {
-            // containment candidates whose b has not arrived: onto the deferred list (the verify kernel skips them)
+        // locality order of the a-side reads (k_read_label): worth its ~50 us only when the verify is long
+        const bool use_order_early = [&]() {
+            bool u = n_cand >= 400000 && (r_end - r_begin) >= 4096;
+            if (const char* e = getenv("PHASM_VERIFY_ORDER")) u = atoi(e) != 0;
+            return u && !dp;
+        }();
+        const bool defer_needed = streamed && r_end < n;
+        if (defer_needed && !use_order_early) {
+            // containment candidates whose b has not arrived: onto the deferred list (the verify kernel skips them);
+            // when the locality order is computed, k_read_label's walk over the candidates does this on the way
             hipLaunchKernelGGL(po::k_defer_split, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_p, A.cand_b, n_cand,
                                r_end, h->d_defer.as<po::Cand>(), h->st_defer_cap, h->d_defer.as<uint32_t>() + (size_t)h->st_defer_cap * 4);
         }
@@ -1326,13 +1377,11 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             // a's words live in LDS (read length + 3 guard words); reads too long for 64 KB use the global path
             const uint64_t need_words = ((uint64_t)h->max_len + W - 1) / W + 3;
             const uint32_t lds_words_raw = (uint32_t)std::min<uint64_t>(need_words, 8192 - 1100);  // (room for the records in 64 KB)
-            // locality order of the a-side reads (k_read_label): worth its ~50 us only when the verify is long
             const uint32_t n_a = r_end - r_begin;
             const uint32_t* perm = nullptr;
             // (sharded calls too: 0.65 -> 0.51 ms at 2 shards, 0.19 -> 0.17 at 8 -- once the label of a read ranked by
             // the scrambled order was turned back into a read index, see k_read_label)
-            bool use_order = n_cand >= 400000 && n_a >= 4096;
-            if (const char* e = getenv("PHASM_VERIFY_ORDER")) use_order = atoi(e) != 0;
+            const bool use_order = use_order_early;
             if (use_order) {
                 // bins of label >> shift, as many as fit into one workgroup's LDS.  Labels are read indices
                 // (whole-set calls) or 32-bit scrambled ranks (sharded calls)
@@ -1343,9 +1392,17 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                 const size_t sort_lds = ((size_t)n_bins + po::SORT_BLOCK / 64) * 4;
                 PO_TRY(ensure(h, h->d_vlabel, (size_t)n_a * 4));
                 PO_TRY(ensure(h, h->d_vperm, (size_t)n_a * 4));
+                po::DeferOut dfo = {};
+                if (defer_needed) {
+                    dfo.cand_p = A.cand_p;
+                    dfo.b_limit = r_end;
+                    dfo.list = h->d_defer.as<uint4>();
+                    dfo.cap = h->st_defer_cap;
+                    dfo.counter = h->d_defer.as<uint32_t>() + (size_t)h->st_defer_cap * 4;
+                }
                 hipLaunchKernelGGL(po::k_read_label, dim3(cdiv((uint64_t)n_a * 16, 256)), dim3(256), 0, st,
                                    h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_b, r_begin, n_a, paired,
-                                   h->d_vlabel.as<uint32_t>());
+                                   h->d_vlabel.as<uint32_t>(), dfo);
                 if (sort_lds > 48 * 1024)
                     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_read_sort),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
@@ -1392,16 +1449,21 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
 #endif
         HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
         // ---- select + row offsets
-        po::PairSlot* ptab = nullptr;
-        uint32_t pbits = 0;
-        uint32_t* n_deferred = reinterpret_cast<uint32_t*>(scalars + 1) + 1;  // reads k_select_local hands to the global table
-        const uint32_t* gate = nullptr;
         if (nshards > 1 || streamed || wide || dpE) {
             static_assert(po::SEL_CAP == 512, "k_select_local hashes to 9 bits");
             hipLaunchKernelGGL(po::k_select_local, dim3(cdiv(r_end - r_begin, 256 / po::WAVE)), dim3(256), 0, st,
                                h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_b, h->d_type.as<uint8_t>(),
                                r_begin, r_end - r_begin, selfrep, n_deferred);
         }
+        // A candidate gives at most 2 rows (4 with their mirrors: worst_rows).  When the row buffer kept from an earlier
+        // call holds that many, the rows are written without asking the host for their number first.
+        // ---- the tail in ONE launch (k_tail: rows per candidate, their prefix sum, the rows, the counters) when the kept
+        // row buffer holds the worst case and no global (a, b) table is needed -- or only a gated one: if k_select_local
+        // hands a read over after all, k_tail writes nothing but a flag and the classic tail below runs instead
+        const bool can_tail = !want_cands && !dpE && h->spare_rows.p && h->spare_rows.cap >= worst_rows * sizeof(po_row) &&
+                              (!n_selfrep_reads || ((nshards > 1 || streamed || wide) && n_cand < (4u << 20))) &&
+                              cdiv(n_cand, po::TAIL_TILE) <= po::TAIL_MAX_TILES && !getenv("PHASM_TAIL_CLASSIC");
+        classic_tail = [&]() -> po_status {
         if (n_selfrep_reads) {
             // some read's prefix recurs inside it (or a read was too repetitive for k_select_local): A candidates
             // of such b may be non-longest duplicates
@@ -1436,7 +1498,6 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         // A candidate gives at most 2 rows (4 with their mirrors).  When the row buffer kept from an earlier call
         // holds that many, the rows are emitted without asking the host for their number first (one host round
         // trip less per step); the number arrives with the counters at the end.
-        const uint64_t worst_rows = (uint64_t)n_cand * (paired ? 4u : 2u);
         if (!want_cands) {
             PO_TRY(prefix_sum<uint8_t>(h, h->d_rowcnt.as<uint8_t>(), n_cand, h->d_row_off.as<uint32_t>(), &h->pinned[2]));
             HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
@@ -1495,6 +1556,46 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                                n_cand, len, res->d_rows.as<po::Row>(), (uint32_t)BITS, paired, scalars + 4);
             HIP_TRY(h, hipGetLastError());
         }
+        return PO_OK;
+        };
+        if (can_tail) {
+            const uint32_t n_tt = cdiv(n_cand, po::TAIL_TILE);
+            // [tile row sums x n_tt | done counter]; the counter is zero between launches (allocated zero, reset by k_tail)
+            if (((size_t)po::TAIL_MAX_TILES + 4) * 4 > h->d_tail_state.cap) {
+                PO_TRY(ensure(h, h->d_tail_state, ((size_t)po::TAIL_MAX_TILES + 4) * 4));
+                HIP_TRY(h, hipMemsetAsync(h->d_tail_state.p, 0, h->d_tail_state.cap, st));
+            }
+            uint32_t* tile_rows = h->d_tail_state.as<uint32_t>();
+            uint32_t* tail_done = tile_rows + po::TAIL_MAX_TILES;
+            const uint32_t* tgate = n_selfrep_reads ? n_deferred : nullptr;
+            hipLaunchKernelGGL(po::k_tile_rows, dim3(n_tt), dim3(po::TAIL_BLOCK), 0, st, A.cand_a, A.cand_b, h->d_type.as<uint8_t>(), n_cand,
+                               paired, tgate, tile_rows);
+            HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
+            rows_late = true;
+            used_tail = true;
+            S.fused_tail = 1;
+            res->d_rows = h->spare_rows;
+            h->spare_rows = DevBuf();
+            h->pinned[48] = 0;
+            h->pinned[55] = 0;
+            hipLaunchKernelGGL(po::k_tail, dim3(n_tt), dim3(po::TAIL_BLOCK), 0, st, A.cand_a, A.cand_p, A.cand_b, h->d_type.as<uint8_t>(),
+                               n_cand, len, res->d_rows.as<po::Row>(), (uint32_t)BITS, paired, tgate, tile_rows, n_tt, tail_done,
+                               scalars + 4, h->pinned_dev + 48);
+            HIP_TRY(h, hipGetLastError());
+        } else {
+            PO_TRY(classic_tail());
+        }
+        tail_fallback = [&]() -> po_status {
+            // k_tail found reads handed to the global table: nothing was written -- the classic tail, now
+            h->spare_rows = res->d_rows;
+            res->d_rows = DevBuf();
+            rows_late = false;
+            used_tail = false;
+            S.fused_tail = 0;
+            S.tail_fallback = 1;
+            PO_TRY(classic_tail());
+            return PO_OK;
+        };
     } else {
         HIP_TRY(h, hipEventRecord(h->ev[EV_FILL], st));
         HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
@@ -1502,10 +1603,11 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     }
     HIP_TRY(h, hipEventRecord(h->ev[EV_EMIT], st));
     uint64_t* counters = h->pinned + 4;
-    HIP_TRY(h, hipMemcpyAsync(counters, scalars + 4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    if (!used_tail) HIP_TRY(h, hipMemcpyAsync(counters, scalars + 4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     res->unique_twins = !want_cands && paired != 0 && !dpE;
     HIP_TRY(h, hipEventRecord(h->ev[EV_DONE], st));
     if (streamed && rows_late && h->st_harvest && !h->st_pend.valid) {
+        h->st_pend.tail = used_tail;
         // a piece of a streamed step with its rows in a buffer known to be large enough: nothing here needs the host
         // to wait -- the counts are read when the next piece waits for ITS candidate count (finish_piece)
         h->st_pend.valid = true;
@@ -1517,7 +1619,19 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         return PO_OK;
     }
     HIP_TRY(h, hipStreamSynchronize(st));
-    if (rows_late) n_rows64 = h->pinned[2];  // (<= worst_rows < 2^32 by construction of the fast path)
+    if (used_tail && h->pinned[55]) {
+        PO_TRY(tail_fallback());
+        HIP_TRY(h, hipEventRecord(h->ev[EV_EMIT], st));
+        HIP_TRY(h, hipMemcpyAsync(counters, scalars + 4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipEventRecord(h->ev[EV_DONE], st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+    }
+    if (used_tail) {
+        n_rows64 = h->pinned[48];
+        for (int k = 0; k < 4; ++k) counters[k] = h->pinned[49 + k];
+    } else if (rows_late) {
+        n_rows64 = h->pinned[2];  // (<= worst_rows < 2^32 by construction of the fast path)
+    }
     res->count = n_rows64;
     S.n_rows = want_cands ? 0 : n_rows64;
     S.n_verified = want_cands ? n_rows64 : counters[0];
@@ -2050,7 +2164,7 @@ void po_destroy(po_handle* h) {
                           &h->d_ps_blocks, &h->d_scalars, &h->d_cand_a, &h->d_cand_p, &h->d_cand_b, &h->d_type,
                           &h->d_rowcnt, &h->d_row_off, &h->d_flag, &h->d_pair_key, &h->d_pair_min, &h->spare_rows, &h->spare_cands, &h->spare_edges,
                           &h->d_vlabel, &h->d_vrank, &h->d_vperm, &h->d_end_a, &h->d_end_b, &h->d_dpcnt, &h->d_lay_len, &h->d_lay_cnt, &h->d_rflag, &h->d_removed, &h->d_ekey, &h->d_ecnt,
-                          &h->d_ewin, &h->d_eoff};
+                          &h->d_ewin, &h->d_eoff, &h->d_chain_state, &h->d_tail_state};
         for (DevBuf* b : bufs) b->release();
         for (int i = 0; i < 2 * EV_N; ++i) (void)hipEventDestroy(h->ev_sets[i / EV_N][i % EV_N]);
         for (hipEvent_t e : h->ev_lay)
@@ -2437,6 +2551,8 @@ void add_stats(po_stats& sum, const po_stats& S) {
     sum.verify_bytes_exec += S.verify_bytes_exec;
     sum.n_tiles += S.n_tiles;
     sum.shard_bases += S.shard_bases;
+    sum.fused_tail += S.fused_tail;
+    sum.tail_fallback += S.tail_fallback;
     sum.ms_index += S.ms_index;
     sum.ms_scan_count += S.ms_scan_count;
     sum.ms_scan_fill += S.ms_scan_fill;
@@ -2622,9 +2738,15 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
         return PO_OK;
     };
     h->st_pend.valid = false;
+    bool tail_gave_up = false;   // a piece's k_tail met reads handed to the global (a, b) table (tandem repeats): chunked form
     h->st_harvest = [&]() -> po_status {
         const uint32_t k = h->st_pend.k;
-        const uint64_t nk = finish_piece(h);
+        bool needs_classic = false;
+        const uint64_t nk = finish_piece(h, &needs_classic);
+        if (needs_classic) {
+            tail_gave_up = true;
+            return PO_OK;
+        }
         return completed(k, h->st_pend.S, nk);
     };
     if (getenv("PHASM_STREAM_SYNC")) h->st_harvest = nullptr;   // (developer switch: every piece waits for its own end)
@@ -2650,7 +2772,7 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
         st = run_chunk(h, min_length, k, P, &nk);
         h->st_on = false;
         h->ws_scale = 1.0;
-        if (st != PO_OK) break;
+        if (st != PO_OK || tail_gave_up) break;
         if (h->st_pend.valid && h->st_pend.k == k) continue;   // piece k is queued, its counts are read later (an older one was collected inside)
         if (h->st_pend.valid) {
             // (piece k never waited for the device -- it had nothing to scan: the older piece is still to be collected)
@@ -2660,13 +2782,23 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
         }
         st = completed(k, h->stats, nk);   // piece k waited for its own end
     }
-    if (st == PO_OK && h->st_pend.valid) {
+    if (st == PO_OK && h->st_pend.valid && !tail_gave_up) {
         if (hipStreamSynchronize(h->stream) != hipSuccess) st = fail(h, PO_ERR_HIP, "stream");
         else st = h->st_harvest();
     }
     h->st_harvest = nullptr;
     h->st_pend.valid = false;
     h->ev = h->ev_sets[0];
+    if (st == PO_OK && tail_gave_up) {
+        // (rare: a read with hundreds of verified suffix-prefix hits.  Pieces may still be in flight and their odd reads
+        // unwritten: everything is uploaded again by the chunked form)
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->up_stream);
+        h->dirty = true;
+        h->st_tail_gave_up = true;
+        *overflow = true;
+        return PO_OK;
+    }
     if (st != PO_OK) {
         (void)hipStreamSynchronize(h->up_stream);
         h->dirty = true;   // (a piece may be missing on the device)
@@ -2813,6 +2945,9 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
     S.ms_total = sum.ms_total;
     S.ms_scan_probe = sum.ms_scan_probe;
     S.ms_verify_kernel = sum.ms_verify_kernel;
+    S.fused_tail = sum.fused_tail;
+    S.tail_fallback = sum.tail_fallback + (h->st_tail_gave_up ? 1u : 0u);
+    h->st_tail_gave_up = false;
     S.streamed = streamed ? 1u : 0u;
     S.n_deferred = (streamed || overflowed) ? h->defer_need : 0u;   // (streamed == 0 with n_deferred > 0: the list overflowed, chunked form taken)
     if (streamed) {

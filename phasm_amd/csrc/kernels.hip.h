@@ -1231,9 +1231,18 @@ __global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
 // in the order that picked the canonical candidates (mirror_rank: the index for whole-set calls, the scrambled
 // rank for sharded calls).  A read keeps exactly the candidates that rank above it, so the top-ranked read of a
 // neighbourhood is on the list of every one of its neighbours: they all get the same label.
+// The walk over every candidate's b also does k_defer_split's job in a streamed step (defer != nullptr): a candidate
+// whose b has not arrived (b >= b_limit: a containment, the only kind the scan keeps of those) goes on the deferred list.
+struct DeferOut {
+    const uint32_t* cand_p;
+    uint32_t b_limit;
+    uint4* list;          // Cand entries
+    uint32_t cap;
+    uint32_t* counter;
+};
 __global__ __launch_bounds__(256) void k_read_label(const uint32_t* __restrict__ read_tile0, const uint32_t* __restrict__ tile_off,
                                                     const uint32_t* __restrict__ cand_b, uint32_t r_begin, uint32_t n_reads,
-                                                    uint32_t paired, uint32_t* __restrict__ label) {
+                                                    uint32_t paired, uint32_t* __restrict__ label, const DeferOut defer) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = t >> 4, sub = t & 15u;
     if (i >= n_reads) return;  // (whole 16-lane groups leave together)
@@ -1242,7 +1251,14 @@ __global__ __launch_bounds__(256) void k_read_label(const uint32_t* __restrict__
     const bool reversed = (paired & 3u) == 3u;   // (a streamed step's order: ~index)
     auto rank = [&](uint32_t x) { return reversed ? ~x : mirror_rank(x, paired); };
     uint32_t best = rank(a);
-    for (uint32_t c = seg0 + sub; c < seg1; c += 16) best = max(best, rank(cand_b[c] ^ 1u));
+    for (uint32_t c = seg0 + sub; c < seg1; c += 16) {
+        const uint32_t b = cand_b[c];
+        best = max(best, rank(b ^ 1u));
+        if (defer.list && b >= defer.b_limit) {
+            const uint32_t k = atomicAdd(defer.counter, 1u);
+            if (k < defer.cap) defer.list[k] = uint4{a, defer.cand_p[c], b, 0u};
+        }
+    }
 #pragma unroll
     for (int o = 8; o >= 1; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o, 16));
     // the label is the top-ranked READ, whatever order ranked it: a scrambled rank (sharded calls) is turned back
@@ -1894,7 +1910,7 @@ __device__ inline void write_rows(Row* __restrict__ rows, uint32_t off, uint32_t
 // [3]=the same over the verified candidates (what the verify kernel compared)
 __device__ inline void flush_counters(uint64_t nver, uint64_t suml, uint64_t sumb, uint64_t sume,
                                       unsigned long long* __restrict__ counters) {
-    __shared__ uint64_t s_red[4][256 / WAVE];
+    __shared__ uint64_t s_red[4][1024 / WAVE];   // (workgroups of up to 1024 threads)
     nver = wave_sum64(nver);
     suml = wave_sum64(suml);
     sumb = wave_sum64(sumb);
@@ -1908,7 +1924,7 @@ __device__ inline void flush_counters(uint64_t nver, uint64_t suml, uint64_t sum
     __syncthreads();
     if (threadIdx.x < 4) {
         uint64_t v = 0;
-        for (int w = 0; w < 256 / WAVE; ++w) v += s_red[threadIdx.x][w];
+        for (uint32_t w = 0; w < blockDim.x / WAVE; ++w) v += s_red[threadIdx.x][w];
         if (v) atomicAdd(&counters[threadIdx.x], (unsigned long long)v);
     }
 }
@@ -2309,6 +2325,337 @@ __global__ __launch_bounds__(PS_BLOCK) void k_ps_down(const T* __restrict__ in, 
             if (base + k < n) out[base + k] = o[k];
     }
     if (base < n && n <= base + PS_ITEMS) out[n] = run;  // closing sentinel (this thread holds item n-1): out has n+1 entries
+}
+
+
+// ----------------------------------------------------------------------------------------
+// Single-pass ("chained") scan: ONE launch instead of reduce + spine + down-sweep.
+//
+// A streamed piece is ~24 dependent launches of which most are a few microseconds of work; every dependent launch
+// costs ~4.5 us on this chip whatever it does (profiles/r03_piece_timeline.txt), so the three-kernel scans (run twice
+// per piece) and the select -> scan -> emit chain are folded into single kernels here.
+//
+// Decoupled look-back: tiles are handed out in ticket order (a tile's predecessors have all started), a tile
+// publishes its aggregate, then looks back over its predecessors' status words -- flag and value packed into one
+// 64-bit word, so a relaxed load sees them together -- until it meets an inclusive prefix.  The state (ticket, done
+// counter, status words) is all-zero between launches: the last tile to finish clears it.
+// ----------------------------------------------------------------------------------------
+constexpr unsigned long long CHAIN_AGG = 1ull << 62, CHAIN_PFX = 2ull << 62, CHAIN_VAL = (1ull << 62) - 1ull;
+struct ChainState {
+    uint32_t ticket, done, pad0, pad1;
+    unsigned long long status[1];   // [n_tiles]
+};
+__host__ __device__ inline size_t chain_state_bytes(uint32_t n_tiles) { return 16 + (size_t)n_tiles * 8; }
+
+__device__ __forceinline__ unsigned long long chain_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the tile this workgroup works on (ticket order); call with all threads, one __syncthreads inside
+__device__ __forceinline__ uint32_t chain_take_tile(ChainState* st, uint32_t* s_tile) {
+    if (threadIdx.x == 0) *s_tile = atomicAdd(&st->ticket, 1u);
+    __syncthreads();
+    return *s_tile;
+}
+
+// exclusive prefix of tile `tile` given its aggregate; executed by ONE whole wave (all 64 lanes call it, same arguments)
+__device__ __forceinline__ unsigned long long chain_lookback(ChainState* st, uint32_t tile, unsigned long long aggregate) {
+    const uint32_t lane = lane_id();
+    if (lane == 0) chain_store(&st->status[tile], (tile == 0 ? CHAIN_PFX : CHAIN_AGG) | aggregate);
+    unsigned long long prefix = 0;
+    if (tile == 0) return 0;
+    int64_t j = (int64_t)tile - 1;
+    for (;;) {
+        const int64_t idx = j - (int64_t)lane;
+        unsigned long long v;
+        for (;;) {   // every predecessor holds an earlier ticket: it is running or done, its word will come
+            v = idx >= 0 ? chain_load(&st->status[idx]) : CHAIN_PFX;
+            if (!__any((v >> 62) == 0)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const uint64_t pm = __ballot((v >> 62) == 2);
+        const uint32_t first = pm ? (uint32_t)__builtin_ctzll(pm) : 64u;
+        unsigned long long part = lane <= first ? (v & CHAIN_VAL) : 0ull;
+        part = wave_sum64(part);
+        prefix += part;
+        if (pm) break;
+        j -= 64;
+    }
+    if (lane == 0) chain_store(&st->status[tile], CHAIN_PFX | (prefix + aggregate));
+    return prefix;
+}
+
+// a tile is finished with the state; the last one of the launch clears it for the next launch.  All threads call it.
+__device__ __forceinline__ bool chain_finish(ChainState* st, uint32_t n_tiles, uint32_t* s_last) {
+    // (no __threadfence: on this chip a device-scope release writes back the whole L2 of the XCD.  What must be ordered
+    // before the done count are this workgroup's READS of status words, and those have returned)
+    __syncthreads();
+    if (threadIdx.x == 0) *s_last = atomicAdd(&st->done, 1u) == n_tiles - 1u ? 1u : 0u;
+    __syncthreads();
+    const bool last = *s_last != 0u;
+    if (last) {
+        for (uint32_t i = threadIdx.x; i < n_tiles; i += blockDim.x) st->status[i] = 0;
+        if (threadIdx.x == 0) {
+            st->ticket = 0;
+            st->done = 0;
+        }
+    }
+    return last;
+}
+
+// exclusive scan of n items (u8 / u32) -> u32 offsets (+ closing sentinel out[n]), total to *total and the pinned
+// *total_host; `extra` (u32 inputs only) is added to the input first and the sum written back (k_add_extra folded in)
+template <typename T>
+__global__ __launch_bounds__(PS_BLOCK) void k_ps_chain(T* __restrict__ in, const uint32_t* __restrict__ extra, uint64_t n,
+                                                       uint32_t* __restrict__ out, ChainState* __restrict__ st, uint32_t n_tiles,
+                                                       uint64_t* __restrict__ total, uint64_t* __restrict__ total_host,
+                                                       const uint64_t* __restrict__ also_src, uint64_t* __restrict__ also_host) {
+    static_assert(PS_ITEMS == 16, "vector paths assume 16 items per thread");
+    __shared__ uint32_t s_wave[PS_BLOCK / WAVE];
+    __shared__ uint32_t s_tile, s_last;
+    __shared__ unsigned long long s_prefix;
+    const uint32_t tile = chain_take_tile(st, &s_tile);
+    const uint64_t base = (uint64_t)tile * PS_TILE + (uint64_t)threadIdx.x * PS_ITEMS;
+    const bool full = base + PS_ITEMS <= n;
+    uint32_t v[PS_ITEMS];
+    if (full && (reinterpret_cast<uintptr_t>(in + base) & 15u) == 0) {
+        if constexpr (sizeof(T) == 1) {
+            const u32x4 q = *reinterpret_cast<const u32x4*>(in + base);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < PS_ITEMS; ++k) v[k] = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const u32x4 q = *reinterpret_cast<const u32x4*>(in + base + 4 * g);
+                v[4 * g] = q.x;
+                v[4 * g + 1] = q.y;
+                v[4 * g + 2] = q.z;
+                v[4 * g + 3] = q.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < PS_ITEMS; ++k) {
+            const uint64_t i = base + k;
+            v[k] = i < n ? (uint32_t)in[i] : 0u;
+        }
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (extra) {
+#pragma unroll
+            for (int k = 0; k < PS_ITEMS; ++k) {
+                const uint64_t i = base + k;
+                const uint32_t e = i < n ? extra[i] : 0u;
+                if (e) {
+                    v[k] += e;
+                    in[i] = v[k];
+                }
+            }
+        }
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < PS_ITEMS; ++k) acc += v[k];
+    const uint32_t incl = wave_incl_scan(acc);
+    if (lane_id() == WAVE - 1) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0, block_total = 0;
+    for (uint32_t w = 0; w < PS_BLOCK / WAVE; ++w) {
+        if (w < (threadIdx.x >> 6)) wave_base += s_wave[w];
+        block_total += s_wave[w];
+    }
+    if (threadIdx.x < WAVE) {
+        const unsigned long long pfx = chain_lookback(st, tile, block_total);
+        if (threadIdx.x == 0) s_prefix = pfx;
+    }
+    __syncthreads();
+    uint32_t run = (uint32_t)s_prefix + wave_base + incl - acc;
+    uint32_t o[PS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PS_ITEMS; ++k) {
+        o[k] = run;
+        run += v[k];
+    }
+    if (full && (reinterpret_cast<uintptr_t>(out + base) & 15u) == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x4 q;
+            q.x = o[4 * g];
+            q.y = o[4 * g + 1];
+            q.z = o[4 * g + 2];
+            q.w = o[4 * g + 3];
+            *reinterpret_cast<u32x4*>(out + base + 4 * g) = q;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < PS_ITEMS; ++k)
+            if (base + k < n) out[base + k] = o[k];
+    }
+    if (base < n && n <= base + PS_ITEMS) {   // this thread holds item n-1: closing sentinel and the grand total
+        const unsigned long long tot = s_prefix + wave_base + incl;
+        out[n] = (uint32_t)tot;
+        *total = tot;
+        *total_host = tot;   // (page-locked host memory mapped into the device)
+        if (also_src) *also_host = *also_src;
+    }
+    chain_finish(st, n_tiles, &s_last);
+}
+
+// ----------------------------------------------------------------------------------------
+// The tail of a call in TWO launches: rows per tile of candidates (k_tile_rows), then -- every workgroup adds up the
+// tiles before its own, a few KB from L2 -- offsets, the rows themselves and the counters, written straight into the
+// pinned landing zone (k_tail).  Instead of k_select, three scan kernels, k_emit and a copy command; for calls whose
+// row buffer is known to hold the worst case (the steady state).  No workgroup waits for another: a first version
+// chained the tiles with a decoupled look-back inside ONE kernel, and 600 spinning waves reading status words across
+// the eight XCDs took 130-340 us for what these two kernels do in 60.
+// `gate` (may be null): reads k_select_local handed to the global (a, b) table; if there are any, the two kernels write
+// nothing but host_out[7] = 1 and the host takes the classic path.
+// Thread t of a tile takes candidates t, t + 256, ...: neighbours write neighbouring rows.
+// host_out: [0] rows, [1] verified candidates, [2] sum l, [3] algorithmic bytes, [4] compared bytes, [7] fallback flag
+// ----------------------------------------------------------------------------------------
+constexpr int TAIL_BLOCK = 256;
+constexpr int TAIL_ITEMS = 2;
+constexpr int TAIL_TILE = TAIL_BLOCK * TAIL_ITEMS;
+constexpr uint32_t TAIL_MAX_TILES = 1u << 12;   // (a workgroup sums the tiles before its own: 2 M candidates at most -- a piece
+                                                //  of a streamed step, a shard; a whole-set call of 6.5 M candidates is faster classic)
+
+__global__ __launch_bounds__(TAIL_BLOCK) void k_tile_rows(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_b,
+                                                          const uint8_t* __restrict__ type, uint32_t n_cand, uint32_t paired,
+                                                          const uint32_t* __restrict__ gate, uint32_t* __restrict__ tile_rows) {
+    __shared__ uint32_t s_part[TAIL_BLOCK / WAVE];
+    if (gate && *gate != 0u) return;
+    const uint32_t base = blockIdx.x * TAIL_TILE;
+    uint32_t n = 0;
+#pragma unroll
+    for (int r = 0; r < TAIL_ITEMS; ++r) {
+        const uint32_t i = base + r * TAIL_BLOCK + threadIdx.x;
+        const uint32_t t = i < n_cand ? type[i] : 0u;
+        if (t) n += rows_of(t, cand_a[i], cand_b[i], paired);
+    }
+    n = wave_sum(n);
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int w = 0; w < TAIL_BLOCK / WAVE; ++w) s += s_part[w];
+        tile_rows[blockIdx.x] = s;
+    }
+}
+
+// done: a device counter, zero between launches (the last workgroup resets it)
+__global__ __launch_bounds__(TAIL_BLOCK) void k_tail(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
+                                                     const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,
+                                                     uint32_t n_cand, const uint32_t* __restrict__ len, Row* __restrict__ rows,
+                                                     uint32_t bits, uint32_t paired, const uint32_t* __restrict__ gate,
+                                                     const uint32_t* __restrict__ tile_rows, uint32_t n_tiles, uint32_t* __restrict__ done,
+                                                     unsigned long long* __restrict__ counters, uint64_t* __restrict__ host_out) {
+    __shared__ uint32_t s_cnt[TAIL_ITEMS][TAIL_BLOCK / WAVE];
+    __shared__ uint32_t s_pre[TAIL_BLOCK / WAVE];
+    __shared__ uint32_t s_last;
+    if (gate && *gate != 0u) {   // (grid-uniform)
+        if (blockIdx.x == 0 && threadIdx.x == 0) host_out[7] = 1;
+        return;
+    }
+    const uint32_t tile = blockIdx.x;
+    const uint32_t base = tile * TAIL_TILE;
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    // rows of the tiles before this one (a few KB, L2-resident: every workgroup reads the same array)
+    uint32_t pre = 0;
+    {
+        uint32_t k = threadIdx.x;
+        for (; k + 3 * TAIL_BLOCK < tile; k += 4 * TAIL_BLOCK)   // (four loads in flight)
+            pre += tile_rows[k] + tile_rows[k + TAIL_BLOCK] + tile_rows[k + 2 * TAIL_BLOCK] + tile_rows[k + 3 * TAIL_BLOCK];
+        for (; k < tile; k += TAIL_BLOCK) pre += tile_rows[k];
+    }
+    uint32_t t[TAIL_ITEMS], a[TAIL_ITEMS], b[TAIL_ITEMS], cnt[TAIL_ITEMS], excl[TAIL_ITEMS];
+    uint32_t pp[TAIL_ITEMS], la[TAIL_ITEMS], lb[TAIL_ITEMS];
+#pragma unroll
+    for (int r = 0; r < TAIL_ITEMS; ++r) {
+        const uint32_t i = base + r * TAIL_BLOCK + threadIdx.x;
+        t[r] = i < n_cand ? type[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < TAIL_ITEMS; ++r) {   // (all loads before the first row store)
+        const uint32_t i = base + r * TAIL_BLOCK + threadIdx.x;
+        a[r] = b[r] = pp[r] = la[r] = lb[r] = 0;
+        if (t[r]) {
+            a[r] = cand_a[i];
+            b[r] = cand_b[i];
+            pp[r] = cand_p[i];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < TAIL_ITEMS; ++r) {
+        if (t[r]) {
+            la[r] = len[a[r]];
+            lb[r] = len[b[r]];
+        }
+        cnt[r] = t[r] ? rows_of(t[r], a[r], b[r], paired) : 0u;
+        const uint32_t inc = wave_incl_scan(cnt[r]);
+        excl[r] = inc - cnt[r];
+        if (lane == WAVE - 1) s_cnt[r][wave] = inc;
+    }
+    pre = wave_sum(pre);
+    if (lane == 0) s_pre[wave] = pre;
+    __syncthreads();
+    uint32_t pfx = 0, block_total = 0;
+#pragma unroll
+    for (int w = 0; w < TAIL_BLOCK / WAVE; ++w) pfx += s_pre[w];
+#pragma unroll
+    for (int r = 0; r < TAIL_ITEMS; ++r) {
+        uint32_t before = block_total;   // rows of the earlier rounds
+#pragma unroll
+        for (int w = 0; w < TAIL_BLOCK / WAVE; ++w) {
+            if ((uint32_t)w < wave) before += s_cnt[r][w];
+            block_total += s_cnt[r][w];
+        }
+        excl[r] += before;
+    }
+    uint64_t nver = 0, suml = 0, sumb = 0, sume = 0;
+#pragma unroll
+    for (int r = 0; r < TAIL_ITEMS; ++r) {
+        if (!t[r]) continue;
+        nver += 1;
+        write_rows(rows, pfx + excl[r], t[r], a[r], pp[r], b[r], la[r], lb[r], bits, paired, suml, sumb, sume);
+    }
+    // counters: one RETURNING atomic per counter per workgroup -- the value coming back means the add has been performed
+    // at the coherence point, so the done count below is ordered behind it without a fence (a device-scope release
+    // fence writes back the XCD's whole L2, rows and all: 2.3 ms per call with one per workgroup)
+    {
+        __shared__ uint64_t s_red[4][TAIL_BLOCK / WAVE];
+        nver = wave_sum64(nver);
+        suml = wave_sum64(suml);
+        sumb = wave_sum64(sumb);
+        sume = wave_sum64(sume);
+        if (lane == 0) {
+            s_red[0][wave] = nver;
+            s_red[1][wave] = suml;
+            s_red[2][wave] = sumb;
+            s_red[3][wave] = sume;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            uint64_t v = 0;
+            for (int w = 0; w < TAIL_BLOCK / WAVE; ++w) v += s_red[threadIdx.x][w];
+            unsigned long long old = 0;
+            if (v) old = atomicAdd(&counters[threadIdx.x], (unsigned long long)v);
+            asm volatile("" :: "v"((uint32_t)old));   // (keeps the return value, hence the wait for it)
+        }
+    }
+    if (tile == n_tiles - 1u && threadIdx.x == 0) host_out[0] = (uint64_t)pfx + block_total;   // (the last tile: all rows)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_last = atomicAdd(done, 1u) == n_tiles - 1u ? 1u : 0u;
+        if (s_last) {
+            *done = 0;
+            for (int k = 0; k < 4; ++k) host_out[1 + k] = __hip_atomic_load(&counters[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_out[7] = 0;
+        }
+    }
 }
 
 }  // namespace po

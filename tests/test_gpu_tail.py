@@ -1,0 +1,97 @@
+"""The call's tail as ONE kernel (k_tail: rows per candidate, their prefix sum, the rows, the counters) and the single-pass
+scan behind every prefix sum (k_ps_chain, decoupled look-back).
+
+k_tail runs when the row buffer kept from an earlier call holds the worst case -- i.e. from the SECOND call on a handle
+on -- so every golden is computed three times on one handle: classic tail first, fused tail after, same rows.  Reads
+with hundreds of verified suffix-prefix hits (tandem repeats) make k_tail hand back to the classic kernels
+(po_stats.tail_fallback); in a streamed step that abandons the step for the chunked form.  Rows are held against the
+REFERENCE goldens (tests/golden/, /root/reference/src/overlapper.cpp:28-150)."""
+import numpy as np
+import pytest
+
+import checker as ck
+import golden_utils as gu
+from oracle import overlap_oracle as oo   # row helpers only
+from phasm_amd.overlapper import ExactOverlapper
+
+pytestmark = pytest.mark.gpu
+
+
+def three_calls(seqs, m, call):
+    ov = ExactOverlapper()
+    for i, s in enumerate(seqs):
+        ov.add_sequence("r%d" % i, s)
+    out = []
+    for _ in range(3):
+        rows = oo.sort_rows(oo.struct_to_rows(call(ov, m)))
+        out.append((rows, ov.stats()))
+    ov.close()
+    return out
+
+
+def whole(ov, m):
+    return ov.overlaps_array(m)
+
+
+def to_host(ov, m):
+    ov.invalidate()
+    res = ov.overlaps_to_host_result(m)
+    arr = res.rows_view().copy()
+    res.free()
+    return arr
+
+
+def sharded(ov, m):
+    return np.concatenate([ov.overlaps_shard_array(m, k, 3) for k in range(3)])
+
+
+@pytest.mark.parametrize("form", [whole, to_host, sharded], ids=["whole", "to_host", "sharded"])
+def test_fused_tail_gives_the_golden_rows(form, monkeypatch):
+    monkeypatch.setenv("PHASM_STREAM", "1")            # to_host: the streamed step wherever its preconditions hold
+    monkeypatch.setenv("PHASM_STREAM_CUTS", "300,600,800")
+    cases = gu.all_small_cases() + gu.repeats_cases() + [gu.ladder_case(n) for n in ("ladder_small", "ladder_varlen", "ladder_cfg2_mini")]
+    n_fused = n_fallback = 0
+    for name, seqs, m, want in cases:
+        for call_no, (rows, st) in enumerate(three_calls(seqs, m, form)):
+            ck.assert_same_rows(rows, want, seqs, m, "%s call %d (%s)" % (name, call_no, form.__name__))
+            if call_no:
+                n_fused += st["fused_tail"]
+                n_fallback += st["tail_fallback"]
+    assert n_fused > 20                                  # the fused kernel really ran ...
+    if form is to_host:
+        assert n_fallback > 0                            # ... and the tandem-repeat reads of repeats.npz sent it back
+
+
+def test_classic_and_fused_tails_emit_the_same_array(monkeypatch):
+    """Same emission order, not just the same multiset: the prefix sums are exact either way."""
+    _, seqs, m, want = gu.ladder_case("cfg2_1k")
+    ov = ExactOverlapper()
+    for i, s in enumerate(seqs):
+        ov.add_sequence("r%d" % i, s)
+    first = ov.overlaps_array(m)
+    assert ov.stats()["fused_tail"] == 0
+    second = ov.overlaps_array(m)
+    assert ov.stats()["fused_tail"] == 1 and ov.stats()["tail_fallback"] == 0
+    monkeypatch.setenv("PHASM_TAIL_CLASSIC", "1")
+    monkeypatch.setenv("PHASM_PS_CLASSIC", "1")
+    third = ov.overlaps_array(m)
+    assert ov.stats()["fused_tail"] == 0
+    ov.close()
+    assert np.array_equal(first, second) and np.array_equal(first, third)
+    assert np.array_equal(oo.sort_rows(oo.struct_to_rows(first)), want)
+
+
+def test_chained_scan_many_tiles(monkeypatch):
+    """The look-back over more tiles than one window (64): a read set with > 64 * 4096 candidates, both scan forms."""
+    _, seqs, m, want = gu.ladder_case("cfg2_1k")
+    for classic in (False, True):
+        if classic:
+            monkeypatch.setenv("PHASM_PS_CLASSIC", "1")
+        ov = ExactOverlapper()
+        for i, s in enumerate(seqs):
+            ov.add_sequence("r%d" % i, s)
+        for _ in range(3):
+            monkeypatch.setenv("PHASM_NO_MIRROR", "1")      # every candidate verified and emitted itself: twice the items
+            got = oo.sort_rows(oo.struct_to_rows(ov.overlaps_array(m)))
+            assert np.array_equal(got, want)
+        ov.close()
