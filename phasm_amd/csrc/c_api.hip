@@ -110,7 +110,7 @@ struct po_handle {
     hipEvent_t ev_sets[2][EV_N] = {};   // (two sets: the pieces of a streamed step alternate, a piece's stage times are read one piece later)
     hipEvent_t* ev = ev_sets[0];
     hipEvent_t ev_up0 = nullptr, ev_up1 = nullptr;
-    uint64_t* pinned = nullptr;  // host-pinned landing zone for device totals/counters (64 x u64)
+    uint64_t* pinned = nullptr;  // host-pinned landing zone for device totals/counters (128 x u64; [64..95]: the two zones of a streamed step's pieces)
     uint64_t* pinned_dev = nullptr;  // the same memory as the device sees it (kernels write totals there directly)
     int n_cu = 256;
     size_t lds_max = 64 * 1024;
@@ -180,6 +180,11 @@ struct po_handle {
     // up_stream while the pieces that have arrived go through the kernels and their rows travel back
     hipStream_t up_stream = nullptr;
     hipEvent_t ev_piece[PO_MAX_PIECES] = {};
+    // the odd reads (reverse complements) of piece k are written on a stream of their own the moment the piece has landed,
+    // beside whatever the handle's stream is doing for the piece before: ev_rc[k] = piece k is complete, both strands
+    hipStream_t rc_stream = nullptr;
+    hipEvent_t ev_rc[PO_MAX_PIECES] = {};
+    hipEvent_t ev_meta = nullptr;
     hipEvent_t ev_first = nullptr;   // the first words of the later pieces are in place
     HostBuf first_host;            // first packed word of every read (pinned), valid for first_n reads
     uint32_t first_n = 0;
@@ -199,10 +204,16 @@ struct po_handle {
         uint32_t k = 0;
         po_stats S = {};
         bool ver_timed = false;
-        bool tail = false;         // the piece's tail ran as k_tail: counts in pinned[48..], fallback flag in pinned[55]
+        bool tail = false;         // the piece's tail ran as k_tail: counts in pinned[zone..], fallback flag in pinned[zone + 7]
+        int zone = 48;
+        uint32_t cap_c = 0;        // > 0: the candidate count was predicted (real count in pinned[zone + 8])
         hipEvent_t* ev = nullptr;
     } st_pend;
     std::function<po_status()> st_harvest;
+    // candidates per piece of the last streamed call, valid for the same reads, cuts and min_length (st_pred_sig)
+    uint64_t st_pred_cand[PO_MAX_PIECES] = {};
+    std::vector<uint32_t> st_pred_sig;
+    bool st_pred_valid = false;
     bool st_tail_gave_up = false;  // the last streamed step was abandoned because of tandem-repeat reads (statistics / tests)
     bool st_on = false;            // run_overlaps works on piece [st_r_begin, st_r_end) of a streamed step
     uint32_t st_r_begin = 0, st_r_end = 0, st_defer_cap = 0;
@@ -360,6 +371,7 @@ void quiesce_store(po_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->up_stream) (void)hipStreamSynchronize(h->up_stream);
+    if (h->rc_stream) (void)hipStreamSynchronize(h->rc_stream);
 }
 
 // Pinned result pool, sized WHILE THE READS ARE ADDED.  A fresh 170 MB page-locked array costs 8 ms (hipHostMalloc maps
@@ -421,7 +433,7 @@ po_status init_device(po_handle* h) {
     for (int i = 0; i < 2 * EV_N; ++i) HIP_TRY(h, hipEventCreate(&h->ev_sets[i / EV_N][i % EV_N]));
     HIP_TRY(h, hipEventCreate(&h->ev_up0));
     HIP_TRY(h, hipEventCreate(&h->ev_up1));
-    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->pinned), 512, hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->pinned), 1024, hipHostMallocDefault));   // 128 slots
     HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pinned_dev), h->pinned, 0));
     if (const char* e = getenv("PHASM_POISON")) h->poison = (int)(strtol(e, nullptr, 0) & 0xFF);
     // the library's code object is loaded by the first launch out of it (15 ms in a fresh process): here, not in a call
@@ -890,8 +902,12 @@ void stage_times(po_stats& S, hipEvent_t* ev, bool ver_timed) {
 // been reused by now: the streamed step gives up and the call takes the chunked form).
 uint64_t finish_piece(po_handle* h, bool* needs_classic) {
     po_handle::Pending& P = h->st_pend;
-    const int o = P.tail ? 48 : 2, c = P.tail ? 49 : 4;
-    *needs_classic = P.tail && h->pinned[55] != 0;
+    const int o = P.tail ? P.zone : 2, c = P.tail ? P.zone + 1 : 4;
+    *needs_classic = P.tail && h->pinned[P.zone + 7] != 0;
+    if (P.cap_c) {   // the count that was predicted: more than the buffers held -> nothing was computed
+        P.S.n_candidates = h->pinned[P.zone + 8];
+        if (P.S.n_candidates > P.cap_c) *needs_classic = true;
+    }
     const uint64_t n_rows = h->pinned[o];
     P.S.n_rows = n_rows;
     P.S.n_verified = h->pinned[c];
@@ -976,7 +992,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     }
     if (ext_idx && !wide) return fail(h, PO_ERR_INVALID, "a sliced index was supplied, but this call uses the narrow index");
     bool rows_late = false;  // rows emitted into a kept buffer before their number reached the host
-    bool used_tail = false;  // the call's tail ran as k_tail (counts in pinned[48..], fallback flag in pinned[55])
+    bool used_tail = false;  // the call's tail ran as k_tail (counts in pinned[tail_zone..], fallback flag in pinned[tail_zone + 7])
+    int tail_zone = 48;
     std::function<po_status()> tail_fallback;
     bool ver_timed = false;  // the verify kernel ran (there were candidates): its own events are valid
     uint64_t n_keys = wide ? n_elig * W : n_elig;
@@ -1176,7 +1193,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     if (wide) {
         HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE0], st));
         auto wscan = streamed ? po::k_wide_scan<BITS, false, BITS == 2> : po::k_wide_scan<BITS, false, false>;
-        hipLaunchKernelGGL(wscan, dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA);
+        hipLaunchKernelGGL(wscan, dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA, po::CandGuard{nullptr, 0u});
         HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
     } else {
         const size_t scan_lds = (size_t)scan_waves * po::SCAN_LDS_PER_WAVE + bloom_bytes;
@@ -1232,26 +1249,61 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                          sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5], sum[3] / sum[5], sum[4] / sum[5], sum[5]);
     }
 #endif
+    // ---- a piece of a streamed step whose candidate count is PREDICTED (the same piece of the previous call): nothing
+    // waits for the counting pass -- the kernels behind it are launched at once, sized for `cap_c` candidates, and read
+    // the real count on the device (CandGuard); the host learns it with the piece's other numbers when it collects the
+    // piece.  Needs every per-piece buffer to hold cap_c already (a re-allocation would synchronise the device).
+    const int zone = 64 + 16 * (int)(shard & 1u);   // this piece's slots of the pinned landing area
+    uint32_t cap_c = 0;
+    bool async_count = false;
+    if (streamed && h->st_harvest && h->st_pred_valid && !dp && !want_cands && !getenv("PHASM_SYNC_COUNT")) {
+        uint64_t pred = h->st_pred_cand[shard];
+        uint64_t cap = pred + pred / 50 + 1024;
+        if (const char* e = getenv("PHASM_PRED_SCALE")) cap = pred = (uint64_t)((double)pred * atof(e));   // (tests: a prediction that is too small)
+        const uint64_t worst = cap * 4u;
+        bool order = pred >= 400000 && (r_end - r_begin) >= 4096;
+        if (const char* e = getenv("PHASM_VERIFY_ORDER")) order = atoi(e) != 0;
+        auto fits = [](const DevBuf& b, uint64_t bytes) { return b.p && b.cap >= bytes; };
+        async_count = pred > 0 && order && cap < (4u << 20) && cdiv(cap, po::TAIL_TILE) <= po::TAIL_MAX_TILES &&
+                      fits(h->d_cand_a, cap * 4) && fits(h->d_cand_p, cap * 4) && fits(h->d_cand_b, cap * 4) && fits(h->d_type, cap) &&
+                      fits(h->d_rowcnt, cap) && fits(h->d_row_off, (cap + 1) * 4) && fits(h->spare_rows, worst * sizeof(po_row)) &&
+                      fits(h->d_vlabel, (uint64_t)(r_end - r_begin) * 4) && fits(h->d_vperm, (uint64_t)(r_end - r_begin) * 4) &&
+                      fits(h->d_vrank, (uint64_t)(r_end - r_begin) * 4) && h->dev_words < 0xFFFFFFF0ull;
+        cap_c = (uint32_t)cap;
+    }
+    volatile uint64_t* count_slot = async_count ? &h->pinned[zone + 8] : &h->pinned[1];
+    volatile uint64_t* also_slot = async_count ? &h->pinned[zone + 9] : &h->pinned[8];
     if (ntiles <= po::PS_SMALL_MAX) {
         PO_TRY(prefix_sum_small(h, A.tile_count + tile_begin, wide ? nullptr : A.tile_extra + tile_begin, ntiles,
-                                h->d_tile_off.as<uint32_t>() + tile_begin, &h->pinned[1],
-                                reinterpret_cast<const uint64_t*>(scalars + 2), &h->pinned[8]));
+                                h->d_tile_off.as<uint32_t>() + tile_begin, count_slot,
+                                reinterpret_cast<const uint64_t*>(scalars + 2), also_slot));
     } else {
-        PO_TRY(prefix_sum<uint32_t>(h, A.tile_count + tile_begin, ntiles, h->d_tile_off.as<uint32_t>() + tile_begin, &h->pinned[1],
-                                    reinterpret_cast<const uint64_t*>(scalars + 2), &h->pinned[8],
+        PO_TRY(prefix_sum<uint32_t>(h, A.tile_count + tile_begin, ntiles, h->d_tile_off.as<uint32_t>() + tile_begin, count_slot,
+                                    reinterpret_cast<const uint64_t*>(scalars + 2), also_slot,
                                     wide ? nullptr : A.tile_extra + tile_begin));
     }
     HIP_TRY(h, hipEventRecord(h->ev[EV_COUNT], st));
-    if (h->st_pend.valid && h->st_harvest) {
-        // the previous piece of a streamed step returned with its kernels queued; this piece's counting pass is queued
-        // behind them now.  Wait for the previous piece alone, send its rows home, THEN wait for this piece's count:
-        // the device is never idle while the host does that, and the rows leave the moment they exist
-        HIP_TRY(h, hipEventSynchronize(h->st_pend.ev[EV_DONE]));
-        PO_TRY(h->st_harvest());
+    po::CandGuard G = {nullptr, 0u};
+    uint64_t n_cand64;
+    uint32_t n_selfrep_reads;
+    if (async_count) {
+        // (sizes and grids below are for cap_c candidates; the kernels read the real number from scalars[0])
+        n_cand64 = cap_c;
+        n_selfrep_reads = 0;
+        G.n_dev = scalars;
+        G.cap = cap_c;
+    } else {
+        if (h->st_pend.valid && h->st_harvest) {
+            // the previous piece of a streamed step returned with its kernels queued; this piece's counting pass is queued
+            // behind them now.  Wait for the previous piece alone, send its rows home, THEN wait for this piece's count:
+            // the device is never idle while the host does that, and the rows leave the moment they exist
+            HIP_TRY(h, hipEventSynchronize(h->st_pend.ev[EV_DONE]));
+            PO_TRY(h->st_harvest());
+        }
+        HIP_TRY(h, hipStreamSynchronize(st));
+        n_cand64 = h->pinned[1];
+        n_selfrep_reads = (uint32_t)h->pinned[8];
     }
-    HIP_TRY(h, hipStreamSynchronize(st));
-    const uint64_t n_cand64 = h->pinned[1];
-    uint32_t n_selfrep_reads = (uint32_t)h->pinned[8];
     if (nshards > 1 || streamed || wide || dpE) n_selfrep_reads |= 1u;  // k_select_local may hand repetitive reads to the global selection
     S.n_candidates = n_cand64;
     if (n_cand64 >= 0xFFFFFF00ull)
@@ -1282,10 +1334,10 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             WA.cand_p = A.cand_p;
             WA.cand_b = A.cand_b;
             auto wfill = streamed ? po::k_wide_scan<BITS, true, BITS == 2> : po::k_wide_scan<BITS, true, false>;
-            hipLaunchKernelGGL(wfill, dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA);
+            hipLaunchKernelGGL(wfill, dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA, G);
         } else {
             auto fill = streamed ? po::k_scan_fill<BITS, BITS == 2> : po::k_scan_fill<BITS, false>;
-            hipLaunchKernelGGL(fill, dim3(cdiv(ntiles, 4 * po::FILL_TILES)), dim3(256), 0, st, A);
+            hipLaunchKernelGGL(fill, dim3(cdiv(ntiles, 4 * po::FILL_TILES)), dim3(256), 0, st, A, G);
         }
         // locality order of the a-side reads (k_read_label): worth its ~50 us only when the verify is long
         const bool use_order_early = [&]() {
@@ -1402,7 +1454,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                 }
                 hipLaunchKernelGGL(po::k_read_label, dim3(cdiv((uint64_t)n_a * 16, 256)), dim3(256), 0, st,
                                    h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_b, r_begin, n_a, paired,
-                                   h->d_vlabel.as<uint32_t>(), dfo);
+                                   h->d_vlabel.as<uint32_t>(), dfo, G);
                 if (sort_lds > 48 * 1024)
                     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_read_sort),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
@@ -1429,7 +1481,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                                words, woff, len, h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_p,
                                A.cand_b, r_begin, lds_words, paired_ver,
                                h->n_exc_uploaded ? h->d_exc_off.as<uint32_t>() : nullptr, h->d_exc_pos.as<uint32_t>(),
-                               h->d_exc_byte.as<uint8_t>(), h->d_type.as<uint8_t>(), perm, n_a);
+                               h->d_exc_byte.as<uint8_t>(), h->d_type.as<uint8_t>(), perm, n_a, G);
             HIP_TRY(h, hipEventRecord(h->ev[EV_VER1], st));
             ver_timed = true;
         }
@@ -1453,7 +1505,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             static_assert(po::SEL_CAP == 512, "k_select_local hashes to 9 bits");
             hipLaunchKernelGGL(po::k_select_local, dim3(cdiv(r_end - r_begin, 256 / po::WAVE)), dim3(256), 0, st,
                                h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_b, h->d_type.as<uint8_t>(),
-                               r_begin, r_end - r_begin, selfrep, n_deferred);
+                               r_begin, r_end - r_begin, selfrep, n_deferred, G);
         }
         // A candidate gives at most 2 rows (4 with their mirrors: worst_rows).  When the row buffer kept from an earlier
         // call holds that many, the rows are written without asking the host for their number first.
@@ -1569,18 +1621,19 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             uint32_t* tail_done = tile_rows + po::TAIL_MAX_TILES;
             const uint32_t* tgate = n_selfrep_reads ? n_deferred : nullptr;
             hipLaunchKernelGGL(po::k_tile_rows, dim3(n_tt), dim3(po::TAIL_BLOCK), 0, st, A.cand_a, A.cand_b, h->d_type.as<uint8_t>(), n_cand,
-                               paired, tgate, tile_rows);
+                               paired, tgate, tile_rows, G);
             HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
             rows_late = true;
             used_tail = true;
             S.fused_tail = 1;
             res->d_rows = h->spare_rows;
             h->spare_rows = DevBuf();
-            h->pinned[48] = 0;
-            h->pinned[55] = 0;
+            tail_zone = async_count ? zone : 48;
+            h->pinned[tail_zone] = 0;
+            h->pinned[tail_zone + 7] = 0;
             hipLaunchKernelGGL(po::k_tail, dim3(n_tt), dim3(po::TAIL_BLOCK), 0, st, A.cand_a, A.cand_p, A.cand_b, h->d_type.as<uint8_t>(),
                                n_cand, len, res->d_rows.as<po::Row>(), (uint32_t)BITS, paired, tgate, tile_rows, n_tt, tail_done,
-                               scalars + 4, h->pinned_dev + 48);
+                               scalars + 4, h->pinned_dev + tail_zone, G);
             HIP_TRY(h, hipGetLastError());
         } else {
             PO_TRY(classic_tail());
@@ -1606,8 +1659,15 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     if (!used_tail) HIP_TRY(h, hipMemcpyAsync(counters, scalars + 4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     res->unique_twins = !want_cands && paired != 0 && !dpE;
     HIP_TRY(h, hipEventRecord(h->ev[EV_DONE], st));
+    if (async_count && h->st_pend.valid) {
+        // everything of this piece is queued; now collect the piece before it (its numbers sit in the other zone)
+        HIP_TRY(h, hipEventSynchronize(h->st_pend.ev[EV_DONE]));
+        PO_TRY(h->st_harvest());
+    }
     if (streamed && rows_late && h->st_harvest && !h->st_pend.valid) {
         h->st_pend.tail = used_tail;
+        h->st_pend.zone = tail_zone;
+        h->st_pend.cap_c = async_count ? cap_c : 0u;
         // a piece of a streamed step with its rows in a buffer known to be large enough: nothing here needs the host
         // to wait -- the counts are read when the next piece waits for ITS candidate count (finish_piece)
         h->st_pend.valid = true;
@@ -1619,7 +1679,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         return PO_OK;
     }
     HIP_TRY(h, hipStreamSynchronize(st));
-    if (used_tail && h->pinned[55]) {
+    if (async_count) return fail(h, PO_ERR_HIP, "internal: a piece with a predicted count must stay pending");
+    if (used_tail && h->pinned[tail_zone + 7]) {
         PO_TRY(tail_fallback());
         HIP_TRY(h, hipEventRecord(h->ev[EV_EMIT], st));
         HIP_TRY(h, hipMemcpyAsync(counters, scalars + 4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -1627,8 +1688,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         HIP_TRY(h, hipStreamSynchronize(st));
     }
     if (used_tail) {
-        n_rows64 = h->pinned[48];
-        for (int k = 0; k < 4; ++k) counters[k] = h->pinned[49 + k];
+        n_rows64 = h->pinned[tail_zone];
+        for (int k = 0; k < 4; ++k) counters[k] = h->pinned[tail_zone + 1 + k];
     } else if (rows_late) {
         n_rows64 = h->pinned[2];  // (<= worst_rows < 2^32 by construction of the fast path)
     }
@@ -2187,6 +2248,13 @@ void po_destroy(po_handle* h) {
         }
         for (hipEvent_t e : h->ev_piece)
             if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : h->ev_rc)
+            if (e) (void)hipEventDestroy(e);
+        if (h->ev_meta) (void)hipEventDestroy(h->ev_meta);
+        if (h->rc_stream) {
+            (void)hipStreamSynchronize(h->rc_stream);
+            (void)hipStreamDestroy(h->rc_stream);
+        }
         if (h->ev_first) (void)hipEventDestroy(h->ev_first);
         if (h->copy_stream) {
             (void)hipStreamSynchronize(h->copy_stream);
@@ -2695,6 +2763,22 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
     }
     for (uint32_t k = 1; k < P; ++k) PO_TRY(queue_piece(k));
     HIP_TRY(h, hipEventRecord(h->ev_up1, h->up_stream));
+    // reverse complements: piece k's odd reads as soon as piece k is there (needs the per-read tables of upload_meta and,
+    // for the later pieces, the first words in place: both are on the handle's stream up to here)
+    if (!h->rc_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->rc_stream, hipStreamNonBlocking));
+    if (!h->ev_meta) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_meta, hipEventDisableTiming));
+    HIP_TRY(h, hipEventRecord(h->ev_meta, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->rc_stream, h->ev_meta, 0));
+    for (uint32_t k = 0; k < P; ++k) {
+        if (!h->ev_rc[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_rc[k], hipEventDisableTiming));
+        HIP_TRY(h, hipStreamWaitEvent(h->rc_stream, h->ev_piece[k], 0));
+        const uint32_t p0 = bounds[k] / 2, p1 = bounds[k + 1] / 2;
+        if (p1 > p0)
+            hipLaunchKernelGGL(po::k_revcomp_store, dim3(cdiv((uint64_t)(p1 - p0) * 64, 256)), dim3(256), 0, h->rc_stream, dw,
+                               h->d_woff.as<uint64_t>(), h->d_len.as<uint32_t>(), p0, p1);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(h->ev_rc[k], h->rc_stream));
+    }
     // deferred containment list: [Cand x cap | counter]
     h->st_defer_cap = std::max<uint32_t>(1u << 16, h->defer_need + h->defer_need / 2);
     if (const char* e = getenv("PHASM_DEFER_CAP")) h->st_defer_cap = (uint32_t)std::max(1, atoi(e));   // (tests: force the overflow path)
@@ -2718,6 +2802,12 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
     const bool trace = getenv("PHASM_STREAM_TRACE") != nullptr;   // developer aid: host-clock marks of the pipeline on stderr
     const auto t_start = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    // the previous streamed call on the same reads, cuts and min_length tells how many candidates each piece will have
+    std::vector<uint32_t> sig(bounds);
+    sig.push_back(min_length);
+    sig.push_back((uint32_t)(h->total_bases & 0xFFFFFFFFu));
+    h->st_pred_valid = h->st_pred_valid && sig == h->st_pred_sig;
+    uint64_t new_pred[PO_MAX_PIECES] = {};
     PO_TRY(stream_begin(h, bounds));
     if (trace) std::fprintf(stderr, "[stream] %u pieces queued at %.3f ms\n", P, since());
     uint64_t* dw = h->d_words.as<uint64_t>();
@@ -2726,6 +2816,7 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
     // (a piece that emitted into a buffer known to be large enough returns with its kernels still queued), or below.
     auto completed = [&](uint32_t k, const po_stats& S, uint64_t nk) -> po_status {
         add_stats(sum, S);
+        new_pred[k] = S.n_candidates;
         const double seen = (double)bounds[k + 1] / (double)n;
         PO_TRY(append_rows(h, R, h->chunk_rows[k], nk, k, P, seen * seen));
         if (trace) {
@@ -2751,11 +2842,8 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
     };
     if (getenv("PHASM_STREAM_SYNC")) h->st_harvest = nullptr;   // (developer switch: every piece waits for its own end)
     for (uint32_t k = 0; k < P && st == PO_OK; ++k) {
-        // piece k has landed -> its odd reads (reverse complements) are written next to it
-        if (hipStreamWaitEvent(h->stream, h->ev_piece[k], 0) != hipSuccess) { st = fail(h, PO_ERR_HIP, "hipStreamWaitEvent"); break; }
-        const uint32_t p0 = bounds[k] / 2, p1 = bounds[k + 1] / 2;
-        hipLaunchKernelGGL(po::k_revcomp_store, dim3(cdiv((uint64_t)(p1 - p0) * 64, 256)), dim3(256), 0, h->stream, dw,
-                           h->d_woff.as<uint64_t>(), h->d_len.as<uint32_t>(), p0, p1);
+        // piece k has landed and its odd reads (reverse complements) have been written next to it (rc_stream, stream_begin)
+        if (hipStreamWaitEvent(h->stream, h->ev_rc[k], 0) != hipSuccess) { st = fail(h, PO_ERR_HIP, "hipStreamWaitEvent"); break; }
         h->st_on = true;
         h->st_r_begin = bounds[k];
         h->st_r_end = bounds[k + 1];
@@ -2794,16 +2882,23 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
         // unwritten: everything is uploaded again by the chunked form)
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamSynchronize(h->up_stream);
+        (void)hipStreamSynchronize(h->rc_stream);
         h->dirty = true;
         h->st_tail_gave_up = true;
+        h->st_pred_valid = false;
         *overflow = true;
         return PO_OK;
     }
     if (st != PO_OK) {
         (void)hipStreamSynchronize(h->up_stream);
+        (void)hipStreamSynchronize(h->rc_stream);
         h->dirty = true;   // (a piece may be missing on the device)
+        h->st_pred_valid = false;
         return st;
     }
+    h->st_pred_sig = sig;
+    std::memcpy(h->st_pred_cand, new_pred, sizeof(new_pred));
+    h->st_pred_valid = true;
     float ms = 0;
     (void)hipEventSynchronize(h->ev_up1);   // (recorded right behind the last piece's event, which the kernels waited for)
     (void)hipEventElapsedTime(&ms, h->ev_up0, h->ev_up1);
@@ -2920,6 +3015,7 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
     h->ev = h->ev_sets[0];
     if (h->dev_ready) (void)hipStreamSynchronize(h->stream);
     if (h->up_stream) (void)hipStreamSynchronize(h->up_stream);
+    if (h->rc_stream) (void)hipStreamSynchronize(h->rc_stream);
     if (h->copy_stream && hipStreamSynchronize(h->copy_stream) != hipSuccess && st == PO_OK) st = fail(h, PO_ERR_HIP, "row copy device->host");
     if (st != PO_OK) {
         R.hb.release();

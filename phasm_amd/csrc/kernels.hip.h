@@ -27,6 +27,16 @@ constexpr uint32_t NO_SELFREP = 0xFFFFFFFFu;
 constexpr uint64_t KEY_EMPTY = ~0ull;          // slot-claim sentinel; a real all-ones K-mer lives
                                                // in the dedicated extra slot at index 1<<tbits
 constexpr int WAVE = 64;
+
+// A piece of a streamed step whose candidate count is PREDICTED (the previous call's) rather than waited for: the
+// kernels behind the counting pass are launched without a host round trip, sized for `cap` candidates, and read the real
+// number from device memory (the counting pass's prefix-sum total).  Should the count exceed what the buffers hold,
+// every one of them does nothing -- the host sees the count at the end of the piece and takes the safe form of the call.
+struct CandGuard {
+    const unsigned long long* n_dev;   // nullptr: the host knows the count, no check
+    uint32_t cap;
+    __device__ __forceinline__ bool overflow() const { return n_dev && *n_dev > (unsigned long long)cap; }
+};
 #ifndef PO_FILTER_DEPTH
 #define PO_FILTER_DEPTH 6
 #endif
@@ -562,9 +572,10 @@ struct WideArgs {
 // One wave per tile, one word per lane: probe the table with the word itself.  FILL = false: count
 // candidates per tile and remember the slot per lane; FILL = true: write the candidates.
 template <int BITS, bool FILL, bool STREAM = false>
-__global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A) {
+__global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A, const CandGuard G) {
     constexpr uint32_t W = 64 / BITS;
     const uint32_t lane = lane_id();
+    if (FILL && G.overflow()) return;
     const uint32_t t = __builtin_amdgcn_readfirstlane(A.tile_begin + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     if (t >= A.tile_end) return;
     const TileRec rec = A.tiles[t];
@@ -1153,10 +1164,11 @@ __global__ void k_add_extra(uint32_t* __restrict__ tile_count, const uint32_t* _
 constexpr int FILL_TILES = PO_FILL_TILES;
 
 template <int BITS, bool STREAM = false>
-__global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A) {
+__global__ __launch_bounds__(256) void k_scan_fill(const ScanArgs A, const CandGuard G) {
     constexpr int W = 64 / BITS;
     __shared__ uint32_t q_src[4 * WAVE];
     __shared__ TileRec q_rec[4 * FILL_TILES];
+    if (G.overflow()) return;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t* qs = q_src + wave * WAVE;
     TileRec* qr = q_rec + wave * FILL_TILES;
@@ -1242,10 +1254,15 @@ struct DeferOut {
 };
 __global__ __launch_bounds__(256) void k_read_label(const uint32_t* __restrict__ read_tile0, const uint32_t* __restrict__ tile_off,
                                                     const uint32_t* __restrict__ cand_b, uint32_t r_begin, uint32_t n_reads,
-                                                    uint32_t paired, uint32_t* __restrict__ label, const DeferOut defer) {
+                                                    uint32_t paired, uint32_t* __restrict__ label, const DeferOut defer,
+                                                    const CandGuard G) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = t >> 4, sub = t & 15u;
     if (i >= n_reads) return;  // (whole 16-lane groups leave together)
+    if (G.overflow()) {        // (the sort behind this kernel still wants a label per read)
+        if (sub == 0) label[i] = r_begin + i;
+        return;
+    }
     const uint32_t a = r_begin + i;
     const uint32_t seg0 = tile_off[read_tile0[a]], seg1 = tile_off[read_tile0[a + 1]];
     const bool reversed = (paired & 3u) == 3u;   // (a streamed step's order: ~index)
@@ -1626,9 +1643,10 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
                                                          const uint32_t* __restrict__ exc_pos,
                                                          const uint8_t* __restrict__ exc_byte,
                                                          uint8_t* __restrict__ type,
-                                                         const uint32_t* __restrict__ perm, uint32_t n_a) {
+                                                         const uint32_t* __restrict__ perm, uint32_t n_a, const CandGuard G) {
     constexpr int W = 64 / BITS;
     extern __shared__ __attribute__((aligned(16))) uint64_t s_a64[];
+    if (G.overflow()) return;
     VST(const unsigned long long vt_start = __builtin_amdgcn_s_memtime(); unsigned long long vt[8] = {};)
     uint32_t a = r_begin + blockIdx.x;
     if (perm) {
@@ -1727,8 +1745,9 @@ constexpr uint32_t SEL_CAP = 512;  // LDS table entries per wave (load <= 1/2)
 __global__ __launch_bounds__(256) void k_select_local(const uint32_t* __restrict__ read_tile0, const uint32_t* __restrict__ tile_off,
                                                       const uint32_t* __restrict__ cand_b, uint8_t* __restrict__ type,
                                                       uint32_t r_begin, uint32_t n_reads, uint32_t* __restrict__ selfrep,
-                                                      uint32_t* __restrict__ n_deferred) {
+                                                      uint32_t* __restrict__ n_deferred, const CandGuard G) {
     __shared__ uint32_t s_key[256 / WAVE][SEL_CAP];  // b + 1, 0 = empty
+    if (G.overflow()) return;
     __shared__ uint32_t s_min[256 / WAVE][SEL_CAP];
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t i = blockIdx.x * (256 / WAVE) + wave;
@@ -2525,10 +2544,16 @@ constexpr uint32_t TAIL_MAX_TILES = 1u << 12;   // (a workgroup sums the tiles b
 
 __global__ __launch_bounds__(TAIL_BLOCK) void k_tile_rows(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_b,
                                                           const uint8_t* __restrict__ type, uint32_t n_cand, uint32_t paired,
-                                                          const uint32_t* __restrict__ gate, uint32_t* __restrict__ tile_rows) {
+                                                          const uint32_t* __restrict__ gate, uint32_t* __restrict__ tile_rows,
+                                                          const CandGuard G) {
     __shared__ uint32_t s_part[TAIL_BLOCK / WAVE];
     if (gate && *gate != 0u) return;
+    if (G.n_dev) {   // (predicted count: the grid covers G.cap candidates, the real number is on the device)
+        if (G.overflow()) return;
+        n_cand = (uint32_t)*G.n_dev;
+    }
     const uint32_t base = blockIdx.x * TAIL_TILE;
+    if (base >= n_cand) return;
     uint32_t n = 0;
 #pragma unroll
     for (int r = 0; r < TAIL_ITEMS; ++r) {
@@ -2552,13 +2577,26 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail(const uint32_t* __restrict_
                                                      uint32_t n_cand, const uint32_t* __restrict__ len, Row* __restrict__ rows,
                                                      uint32_t bits, uint32_t paired, const uint32_t* __restrict__ gate,
                                                      const uint32_t* __restrict__ tile_rows, uint32_t n_tiles, uint32_t* __restrict__ done,
-                                                     unsigned long long* __restrict__ counters, uint64_t* __restrict__ host_out) {
+                                                     unsigned long long* __restrict__ counters, uint64_t* __restrict__ host_out,
+                                                     const CandGuard G) {
     __shared__ uint32_t s_cnt[TAIL_ITEMS][TAIL_BLOCK / WAVE];
     __shared__ uint32_t s_pre[TAIL_BLOCK / WAVE];
     __shared__ uint32_t s_last;
-    if (gate && *gate != 0u) {   // (grid-uniform)
-        if (blockIdx.x == 0 && threadIdx.x == 0) host_out[7] = 1;
+    if ((gate && *gate != 0u) || G.overflow()) {   // (grid-uniform)
+        if (blockIdx.x == 0 && threadIdx.x == 0) host_out[7] = G.overflow() ? 2 : 1;
         return;
+    }
+    if (G.n_dev) {   // (predicted count: the grid covers G.cap candidates)
+        n_cand = (uint32_t)*G.n_dev;
+        n_tiles = (n_cand + TAIL_TILE - 1) / TAIL_TILE;
+        if (n_tiles == 0) {   // (no candidates after all: nothing to write but the zeros)
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                for (int k = 0; k < 5; ++k) host_out[k] = 0;
+                host_out[7] = 0;
+            }
+            return;
+        }
+        if (blockIdx.x >= n_tiles) return;
     }
     const uint32_t tile = blockIdx.x;
     const uint32_t base = tile * TAIL_TILE;

@@ -95,3 +95,33 @@ def test_chained_scan_many_tiles(monkeypatch):
             got = oo.sort_rows(oo.struct_to_rows(ov.overlaps_array(m)))
             assert np.array_equal(got, want)
         ov.close()
+
+
+@pytest.mark.parametrize("scale", [None, "0.6"])
+def test_streamed_pieces_with_a_predicted_candidate_count(scale, monkeypatch):
+    """From the second streamed call on the same reads on, a piece does not wait for its candidate count: the kernels
+    behind the counting pass are launched sized for the previous call's count and check the real one on the device.
+    scale = 0.6: the prediction is too small -- every kernel must stand down, the step is abandoned for the chunked form,
+    the rows are still the golden ones and the next call predicts again from a clean count."""
+    monkeypatch.setenv("PHASM_STREAM", "1")
+    monkeypatch.setenv("PHASM_STREAM_CUTS", "250,500,750")
+    monkeypatch.setenv("PHASM_VERIFY_ORDER", "1")       # (the predicted path needs the locality order, which small inputs skip)
+    for name in ("ladder_cfg2_mini", "cfg2_1k", "cfg3_1k", "ladder_varlen"):
+        _, seqs, m, want = gu.ladder_case(name)
+        ov = ExactOverlapper()
+        for i, s in enumerate(seqs):
+            ov.add_sequence("r%d" % i, s)
+        for call_no in range(4):
+            if scale and call_no == 2:
+                monkeypatch.setenv("PHASM_PRED_SCALE", scale)
+            else:
+                monkeypatch.delenv("PHASM_PRED_SCALE", raising=False)
+            rows = oo.sort_rows(oo.struct_to_rows(to_host(ov, m)))
+            st = ov.stats()
+            ck.assert_same_rows(rows, want, seqs, m, "%s call %d" % (name, call_no))
+            if scale and call_no == 2:
+                assert st["streamed"] == 0 and st["tail_fallback"] >= 1, (name, st)
+            else:
+                assert st["streamed"] == 1, (name, call_no, st)
+            assert st["n_candidates"] > 0 and st["n_rows"] == len(want)
+        ov.close()
