@@ -128,6 +128,7 @@ struct po_handle {
     std::vector<uint64_t> woff;
     WordStore words[2];
     bool all_pairs_rc = true;   // every complete (even, odd) pair so far: same length, odd == revcomp(even), no exception records
+    bool all_pairs_rcx = true;  // the same with exception records allowed: such a pair was compared byte by byte on the host (pair_state 1)
     uint64_t base1 = 0;         // first word of store 1 in the device buffer (set at upload)
     uint64_t dev_words = 0;     // words in the device buffer, padding included
     uint64_t upload_bytes = 0;  // bytes the last upload moved host->device
@@ -538,6 +539,7 @@ void widen_to_bytes(po_handle* h) {
     }
     h->bits = 8;
     h->all_pairs_rc = false;
+    h->all_pairs_rcx = false;
     h->exc_off.assign(1, 0);
     h->exc_pos.clear();
     h->exc_byte.clear();
@@ -682,8 +684,7 @@ po_status upload_meta(po_handle* h, bool* generate_out) {
     // rebuilt on the device, bit for bit what the host packed (k_revcomp_store).
     const uint64_t base1 = (h->words[0].size() + 1) & ~uint64_t(1);
     const uint64_t nwords = base1 + h->words[1].size() + 72;
-    const bool generate = h->bits == 2 && n >= 2 && (n % 2) == 0 && h->all_pairs_rc && h->exc_pos.empty() &&
-                          !getenv("PHASM_FULL_UPLOAD");
+    const bool generate = h->bits == 2 && n >= 2 && (n % 2) == 0 && h->all_pairs_rcx && !getenv("PHASM_FULL_UPLOAD");
     *generate_out = generate;
     h->base1 = base1;
     h->dev_words = nwords;
@@ -711,6 +712,19 @@ po_status upload_meta(po_handle* h, bool* generate_out) {
         hipLaunchKernelGGL(po::k_build_tiles, dim3(cdiv(h->n_tiles, 256)), dim3(256), 0, h->stream, h->d_woff.as<uint64_t>(),
                            h->d_len.as<uint32_t>(), h->d_read_tile0.as<uint32_t>(), n, h->n_tiles, h->d_tiles.as<po::TileRec>());
     }
+    // exception records (2-bit mode only; usually none).  Up before anything that looks at the reads: the kernel that
+    // rebuilds the odd reads on the device needs them, and so does every verify
+    const size_t n_exc = h->bits == 2 ? h->exc_pos.size() : 0;
+    if (n_exc) {
+        PO_TRY(ensure(h, h->d_exc_off, ((size_t)n + 1) * 4));
+        PO_TRY(ensure(h, h->d_exc_pos, n_exc * 4));
+        PO_TRY(ensure(h, h->d_exc_byte, n_exc));
+        HIP_TRY(h, hipMemcpyAsync(h->d_exc_off.p, h->exc_off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_exc_pos.p, h->exc_pos.data(), n_exc * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_exc_byte.p, h->exc_byte.data(), n_exc, hipMemcpyHostToDevice, h->stream));
+        h->upload_bytes += ((size_t)n + 1) * 4 + n_exc * 5;
+    }
+    h->n_exc_uploaded = n_exc;
     HIP_TRY(h, hipGetLastError());
     return PO_OK;
 }
@@ -742,7 +756,8 @@ po_status upload(po_handle* h) {
     }
     if (generate) {
         hipLaunchKernelGGL(po::k_revcomp_store, dim3(cdiv((uint64_t)(n / 2) * 64, 256)), dim3(256), 0, h->stream, dw,
-                           h->d_woff.as<uint64_t>(), h->d_len.as<uint32_t>(), 0u, n / 2);
+                           h->d_woff.as<uint64_t>(), h->d_len.as<uint32_t>(), 0u, n / 2,
+                           h->n_exc_uploaded ? h->d_exc_off.as<uint32_t>() : nullptr, h->d_exc_pos.as<uint32_t>());
         if (getenv("PHASM_VERIFY_GENERATED") && !h->words[1].empty()) {
             // test mode: the host's own store 1 is uploaded next to the generated one and compared word by word
             DevBuf tmp;
@@ -761,17 +776,7 @@ po_status upload(po_handle* h) {
         }
     }
     HIP_TRY(h, hipGetLastError());
-    // exception records (2-bit mode only; usually none)
-    const size_t n_exc = h->bits == 2 ? h->exc_pos.size() : 0;
-    if (n_exc) {
-        PO_TRY(ensure(h, h->d_exc_off, ((size_t)n + 1) * 4));
-        PO_TRY(ensure(h, h->d_exc_pos, n_exc * 4));
-        PO_TRY(ensure(h, h->d_exc_byte, n_exc));
-        HIP_TRY(h, hipMemcpyAsync(h->d_exc_off.p, h->exc_off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->d_exc_pos.p, h->exc_pos.data(), n_exc * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->d_exc_byte.p, h->exc_byte.data(), n_exc, hipMemcpyHostToDevice, h->stream));
-    }
-    h->n_exc_uploaded = n_exc;
+    const size_t n_exc = h->n_exc_uploaded;   // (exception records went up with the per-read tables, upload_meta)
     // strand pairing: decides whether po_overlaps may compute one member of each mirror pair
     h->paired = false;
     const bool mirror_ok = !getenv("PHASM_NO_MIRROR");
@@ -2292,8 +2297,16 @@ po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const cha
         h->ids_paired = -1;
         if (h->total_bases >= h->pool_bases && h->total_bases >= (64ull << 20)) result_pool_grow(h);
         if (h->bits == 2 && (h->len.size() & 1) == 0) {
-            if (!h->exc_pos.empty()) host_pair_check(h, h->len.size() - 1, s);
-            if (h->all_pairs_rc) h->all_pairs_rc = packed_is_revcomp(h, h->len.size() - 1);
+            const size_t r = h->len.size() - 1;
+            if (!h->exc_pos.empty()) host_pair_check(h, r, s);
+            const bool has_exc = h->exc_off[r - 1] != h->exc_off[r] || h->exc_off[r] != h->exc_off[r + 1];
+            if (h->all_pairs_rcx) {
+                const bool ok = has_exc ? (h->pair_state.size() > r / 2 && h->pair_state[r / 2] == 1) : packed_is_revcomp(h, r);
+                h->all_pairs_rcx = ok;
+                if (has_exc || !ok) h->all_pairs_rc = false;
+            } else {
+                h->all_pairs_rc = false;
+            }
         }
     } catch (const std::bad_alloc&) {
         return fail(h, PO_ERR_NOMEM, "out of host memory in po_add_sequence");
@@ -2652,7 +2665,7 @@ po_status run_chunk(po_handle* h, uint32_t min_length, uint32_t k, uint32_t n_ch
 // May this call take the streamed form?  (the index flavour is decided as run_overlaps decides it)
 bool stream_eligible(const po_handle* h, uint32_t min_length) {
     const uint32_t n = (uint32_t)h->len.size();
-    if (!h->dirty || h->bits != 2 || n < 4 || (n % 2) != 0 || !h->all_pairs_rc || !h->exc_pos.empty()) return false;
+    if (!h->dirty || h->bits != 2 || n < 4 || (n % 2) != 0 || !h->all_pairs_rcx) return false;
     if (h->asm_pieces || h->ex_on || h->sl_build_n > 1 || h->ext_index) return false;
     if (getenv("PHASM_FULL_UPLOAD") || getenv("PHASM_NO_MIRROR")) return false;
     // (worth it from ~16 MB of packed even reads on: below that a piece's fixed cost, ~0.2 ms of small launches, is more
@@ -2775,7 +2788,8 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
         const uint32_t p0 = bounds[k] / 2, p1 = bounds[k + 1] / 2;
         if (p1 > p0)
             hipLaunchKernelGGL(po::k_revcomp_store, dim3(cdiv((uint64_t)(p1 - p0) * 64, 256)), dim3(256), 0, h->rc_stream, dw,
-                               h->d_woff.as<uint64_t>(), h->d_len.as<uint32_t>(), p0, p1);
+                               h->d_woff.as<uint64_t>(), h->d_len.as<uint32_t>(), p0, p1,
+                               h->n_exc_uploaded ? h->d_exc_off.as<uint32_t>() : nullptr, h->d_exc_pos.as<uint32_t>());
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(h->ev_rc[k], h->rc_stream));
     }
@@ -2785,8 +2799,7 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
     PO_TRY(ensure(h, h->d_defer, (size_t)h->st_defer_cap * sizeof(po::Cand) + 16));
     if (!getenv("PHASM_DEFER_CAP")) h->st_defer_cap = (uint32_t)std::min<size_t>((h->d_defer.cap - 16) / sizeof(po::Cand), 0xFFFFFF00u);
     HIP_TRY(h, hipMemsetAsync(h->d_defer.as<char>() + (size_t)h->st_defer_cap * sizeof(po::Cand), 0, 16, h->stream));
-    h->n_exc_uploaded = 0;
-    h->paired = true;   // (checked word by word on the host as the reads arrived: all_pairs_rc)
+    h->paired = true;   // (checked on the host as the reads arrived: all_pairs_rcx)
     ++h->upload_gen;
     h->dirty = false;
     return PO_OK;
@@ -2920,7 +2933,8 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
         PO_TRY(ensure(h, h->d_row_off, ((size_t)n_def + 1) * 4));
         HIP_TRY(h, hipEventRecord(h->ev[EV_START], s));
         hipLaunchKernelGGL(po::k_verify_flat, dim3(cdiv((uint64_t)n_def * 64, 256)), dim3(256), 0, s, dw, h->d_woff.as<uint64_t>(),
-                           h->d_len.as<uint32_t>(), list, n_def);
+                           h->d_len.as<uint32_t>(), list, n_def, h->n_exc_uploaded ? h->d_exc_off.as<uint32_t>() : nullptr,
+                           h->d_exc_pos.as<uint32_t>(), h->d_exc_byte.as<uint8_t>());
         hipLaunchKernelGGL(po::k_deferred_rowcnt, dim3(cdiv(n_def, 256)), dim3(256), 0, s, list, n_def, 1u, h->d_rowcnt.as<uint8_t>());
         HIP_TRY(h, hipGetLastError());
         PO_TRY(prefix_sum<uint8_t>(h, h->d_rowcnt.as<uint8_t>(), n_def, h->d_row_off.as<uint32_t>(), &h->pinned[2]));

@@ -2065,10 +2065,14 @@ __global__ __launch_bounds__(256) void k_paired_check(const uint64_t* __restrict
 // host as the reads were added) only the even reads cross PCIe.  One wave per pair; lane l writes words l, l+64, ...
 // of read 2i+1 = the matching window of read 2i reversed (bit reverse + swap the two bits of every base) and
 // complemented (~), bits beyond the read's end cleared, plus the zero guard word -- bit for bit what the host packs.
+// exc_off / exc_pos (may be null): reads with exception records (non-ACGT bytes) carry code 0 at those positions in
+// BOTH strands -- the complement of code 0 is code 3, so the positions of the odd read's own records are cleared here.
 __global__ __launch_bounds__(256) void k_revcomp_store(uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
-                                                       const uint32_t* __restrict__ len, uint32_t pair0, uint32_t n_pairs) {
+                                                       const uint32_t* __restrict__ len, uint32_t pair0, uint32_t n_pairs,
+                                                       const uint32_t* __restrict__ exc_off, const uint32_t* __restrict__ exc_pos) {
     const uint32_t pair = pair0 + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6);   // pairs [pair0, n_pairs)
     if (pair >= n_pairs) return;
+    const uint32_t e0 = exc_off ? exc_off[2 * pair + 1] : 0u, e1 = exc_off ? exc_off[2 * pair + 2] : 0u;
     const uint32_t lane = lane_id();
     const uint32_t L = len[2 * pair];
     const uint64_t* __restrict__ R = words + woff[2 * pair];
@@ -2092,6 +2096,10 @@ __global__ __launch_bounds__(256) void k_revcomp_store(uint64_t* __restrict__ wo
             y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
             y = ~y;
             out = valid >= 32 ? y : (y & ((1ull << (valid * 2)) - 1ull));
+            for (uint32_t e = e0; e < e1; ++e) {   // (rare: a read with non-ACGT bytes)
+                const uint32_t pos = exc_pos[e];
+                if ((pos >> 5) == w) out &= ~(3ull << ((pos & 31u) * 2u));
+            }
         }
         S[w] = out;
     }
@@ -2130,7 +2138,9 @@ __global__ void k_defer_split(const uint32_t* __restrict__ cand_a, const uint32_
 // candidate, lane l compares words l, l + 64, ... of b with the window of a behind p.  2-bit reads without exception
 // records only (the streamed step's precondition).  type = 2 (B row) or 0.
 __global__ __launch_bounds__(256) void k_verify_flat(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
-                                                     const uint32_t* __restrict__ len, Cand* __restrict__ cands, uint32_t n) {
+                                                     const uint32_t* __restrict__ len, Cand* __restrict__ cands, uint32_t n,
+                                                     const uint32_t* __restrict__ exc_off, const uint32_t* __restrict__ exc_pos,
+                                                     const uint8_t* __restrict__ exc_byte) {
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= n) return;   // (whole waves leave together)
     const uint32_t lane = lane_id();
@@ -2147,7 +2157,9 @@ __global__ __launch_bounds__(256) void k_verify_flat(const uint64_t* __restrict_
             bad |= d != 0;
         }
     }
-    const bool any_bad = __any(bad);
+    bool any_bad = __any(bad);
+    // (reads with exception records -- non-ACGT bytes, stored as code 0: the codes agree, do the bytes?)
+    if (lane == 0 && !any_bad && exc_off && !exceptions_equal(exc_off, exc_pos, exc_byte, c.a, c.p, c.b, lb)) any_bad = true;
     if (lane == 0) cands[i].type = any_bad ? 0u : 2u;
 }
 

@@ -128,16 +128,62 @@ def test_streamed_fuzz_against_the_oracle(monkeypatch):
         ck.assert_same_rows(got, want, seqs, m, "fuzz trial %d, cuts %s, m %d" % (trial, cuts, m))
 
 
+def _with_exceptions(seqs, rng, n_hits):
+    """put non-ACGT bytes into strand pairs the way a FASTA with N / IUPAC / soft-masked bases gives them: byte c at
+    position i of x, its complement at the mirrored position of the reverse complement"""
+    comp = {b"N": b"N", b"n": b"n", b"R": b"Y", b"Y": b"R", b"a": b"t", b"c": b"g", b"g": b"c", b"t": b"a", b"W": b"W"}
+    keys = list(comp)
+    seqs = [bytearray(s) for s in seqs]
+    for _ in range(n_hits):
+        pair = int(rng.integers(0, len(seqs) // 2))
+        L = len(seqs[2 * pair])
+        # anywhere, with a bias to the ends and the anchor region (first / last 32 bases)
+        i = int(rng.choice([0, 1, 31, 32, L - 1, L - 2, L - 32, int(rng.integers(0, L))]))
+        c = keys[int(rng.integers(len(keys)))]
+        seqs[2 * pair][i] = c[0]
+        seqs[2 * pair + 1][L - 1 - i] = comp[c][0]
+    return [bytes(s) for s in seqs]
+
+
+@pytest.mark.parametrize("cuts", ["", "300,700", "100,200,300,400,500,600,700,800,900"])
+def test_reads_with_exception_records_stream_too(cuts, monkeypatch):
+    """N / IUPAC / lower-case bytes in a read and, mirrored, in its reverse complement (the reference compares raw
+    bytes, /root/reference/src/overlapper.h:26; assembler.py:37 passes sequences as they are): the reads are kept as
+    2-bit codes + sparse exception records, only the even reads travel, the odd ones are rebuilt on the device with
+    the records' positions cleared, every verify -- the deferred containments' too -- consults the records."""
+    monkeypatch.setenv("PHASM_STREAM", "1")
+    monkeypatch.setenv("PHASM_VERIFY_GENERATED", "1")    # the device's odd store must equal the host's, word for word
+    if cuts:
+        monkeypatch.setenv("PHASM_STREAM_CUTS", cuts)
+    rng = np.random.default_rng(61)
+    for trial in range(6):
+        base = _nested_reads(100 + trial, 60, 5000, 60, 1200)
+        seqs = _with_exceptions(base, rng, n_hits=int(rng.integers(1, 25)))
+        m = int(rng.choice([33, 40, 64]))
+        for (got, st) in streamed_rows(seqs, m, calls=2):
+            assert st["streamed"] == 1 and st["paired"] == 1 and st["bits_per_base"] == 2, st
+            ck.assert_same_rows(got, ck.oracle_overlaps(seqs, m), seqs, m, "exception records, trial %d, cuts %r" % (trial, cuts))
+        # the unstreamed forms of the same handle state: half upload + device rebuild as well
+        monkeypatch.setenv("PHASM_STREAM", "0")
+        (got, st), = streamed_rows(seqs, m)
+        monkeypatch.setenv("PHASM_STREAM", "1")
+        assert st["streamed"] == 0 and st["paired"] == 1 and st["upload_bytes"] < sum(len(x) for x in seqs) // 4 * 0.75
+        ck.assert_same_rows(got, ck.oracle_overlaps(seqs, m), seqs, m, "exception records, unstreamed")
+
+
 def test_streamed_step_is_not_taken_for_reads_it_cannot_serve(monkeypatch):
     monkeypatch.setenv("PHASM_STREAM", "1")
     rng = np.random.default_rng(5)
     genome = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=3000))
     plain = [genome[int(s):int(s) + 400] for s in rng.integers(0, 2600, size=20)]   # not strand pairs
-    withn = _nested_reads(9, 10, 2000, 100, 500)
-    withn[4] = withn[4][:50] + b"N" + withn[4][51:]                                  # exception record
-    for seqs in (plain, withn):
+    broken = _nested_reads(9, 10, 2000, 100, 500)
+    broken[4] = broken[4][:50] + b"N" + broken[4][51:]                               # N on one strand only: no longer a pair
+    dense = [bytes(b"ACGTNRYKM"[i] for i in rng.integers(0, 9, size=300)) for _ in range(6)]
+    comp = bytes.maketrans(b"ACGTNRYKM", b"TGCANYRMK")
+    dense = [x for r in dense for x in (r, r.translate(comp)[::-1])]                 # strand pairs, but 8 bits per base
+    for seqs, bits in ((plain, 2), (broken, 2), (dense, 8)):
         (got, st), = streamed_rows(seqs, 30)
-        assert st["streamed"] == 0
+        assert st["streamed"] == 0 and st["bits_per_base"] == bits
         ck.assert_same_rows(got, ck.oracle_overlaps(seqs, 30), seqs, 30, "not streamed")
 
 

@@ -17,12 +17,24 @@ def main():
     ap.add_argument("--steps", type=int, default=15)
     ap.add_argument("--cuts", nargs="*", default=["default", "off"])
     ap.add_argument("--trace", action="store_true", help="one more step per setting with PHASM_STREAM_TRACE")
+    ap.add_argument("--n-rate", type=float, default=0.0, help="turn this fraction of the bases into N (both strands consistently): exception records")
     args = ap.parse_args()
     cfg = synth.CONFIGS[args.config]
     if args.reads:
         cfg = synth.scaled(cfg, args.reads)
     ov = ExactOverlapper(device=0)
-    for name, seq in synth.oriented(synth.generate_reads(cfg)):
+    reads = synth.generate_reads(cfg)
+    if args.n_rate > 0:
+        import numpy as np
+        rng = np.random.default_rng(1)
+        out = []
+        for name, seq in reads:
+            b = bytearray(seq)
+            for pos in rng.integers(0, len(b), size=rng.poisson(len(b) * args.n_rate)):
+                b[int(pos)] = ord("N")
+            out.append((name, bytes(b)))
+        reads = out
+    for name, seq in synth.oriented(reads):
         ov.add_sequence(name, seq)
     m = cfg.min_overlap if hasattr(cfg, "min_overlap") else 1000
     for cuts in args.cuts:
