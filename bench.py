@@ -378,6 +378,13 @@ def main() -> int:
         if world == 1 and not args.dist_path:
             # (host to host: the pipelined call -- chunk k's rows travel while chunk k + 1 is computed)
             res = ov.overlaps_to_host_result(m) if inclusive else ov.overlaps_result(m)
+        elif inclusive:
+            # the pipelined N-rank step (phasm_amd/dist.py, CandidateExchange.rows_home): this rank's candidates go into the
+            # all-gather (the merged list ends up on every GPU), and WHILE they travel the rank expands its own candidates
+            # into rows and brings them home -- rank order = read order, the ranks' arrays together are the merged rows
+            merged, res = exchange.rows_home(m)
+            shard_st = ov.stats()
+            del merged
         else:
             # exchange the compact form (verified candidates, 16 B), expand to rows on every rank
             merged = exchange.candidates(m)   # shard + one all-gather of fixed slots (phasm_amd/dist.py)
@@ -387,23 +394,18 @@ def main() -> int:
         if inclusive:
             # ... and ends in host memory: the row array device -> host (po_result_rows; a view, no second copy)
             t_a = time.perf_counter()
-            if world == 1:
-                rows = res.rows_view()
-                assert len(rows) == n
-            else:
-                # every rank holds the merged rows on its GPU; the ranks of the node bring them home once between them
-                lo, hi = n * rank // world, n * (rank + 1) // world
-                rows = res.rows_range_view(lo, hi - lo)
-                assert len(rows) == hi - lo
+            rows = res.rows_view()     # (N > 1: this rank's own rows; already home, rows_home copied them under the collective)
+            assert len(rows) == n
             del rows
             if timed:
                 pcie["d2h_s"] += time.perf_counter() - t_a
         res.free()
         st = ov.stats()
         if world > 1 or args.dist_path:
-            # the expansion saw every rank's candidates: scale its byte counters to this rank's share
-            for k in ("verify_bytes_algo", "sum_overlap_bases", "n_rows"):
-                st[k] = st[k] // world
+            if not inclusive:
+                # the expansion saw every rank's candidates: scale its byte counters to this rank's share
+                for k in ("verify_bytes_algo", "sum_overlap_bases", "n_rows"):
+                    st[k] = st[k] // world
             for k in stage_keys:
                 if k not in ("ms_emit",):
                     st[k] = shard_st[k]
@@ -433,10 +435,14 @@ def main() -> int:
         n_rows = step(True)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or args.dist_path:
         t = torch.tensor([dt], dtype=torch.float64, device=merge_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank brought ITS rows home: the job's rows per step are the sum (outside the timed region)
+        t = torch.tensor([n_rows], dtype=torch.int64, device=merge_device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        n_rows = int(t.item())
     incl_acc = dict(acc)
     incl_last = dict(last)   # (statistics of the last host-to-host step, before the resident loop overwrites them)
     # the kernel pipeline alone (reads resident in HBM, rows left in HBM): an extra, never `value`
@@ -479,10 +485,11 @@ def main() -> int:
                                          if not args.no_stream else
                                          "host to host per step: po_invalidate + po_upload (H2D of the packed reads) + po_overlaps_to_host (kernels, D2H of the rows pipelined chunk by chunk) + po_result_rows")
                                         if world == 1 and not args.dist_path else
-                                        "host to host per step, every rank: po_invalidate + sharded upload (po_upload_piece: 1/N of the packed reads over this rank's PCIe link, "
-                                        "one all-gather over xGMI, po_upload_assemble) + po_candidates_shard + one all-gather of verified candidates + po_expand (all rows on every GPU) "
-                                        "+ po_result_rows_range (1/N of the merged rows to this rank's host)"),
-                       "parallelism": "each rank uploads 1/N of the packed reads, one RCCL all-gather over xGMI completes every rank's copy; a-side read shards x%d + one RCCL all-gather of verified candidates (16 B, fixed slots) per step + local row expansion on every rank; each rank copies 1/%d of the merged rows to its host" % (world, world) if world > 1
+                                        "host to host per step, every rank: po_invalidate + sharded upload in parts (po_upload_piece_part: 1/N of the packed reads over this rank's PCIe "
+                                        "link, the all-gather of part k over xGMI under the copy of part k + 1, po_upload_assemble_parts) + po_candidates_shard_into + ONE all-gather of "
+                                        "verified candidates (the merged list on every GPU) and, while it is in flight, po_expand of this rank's own candidates + po_result_rows "
+                                        "(this rank's rows to its host; the ranks' arrays together are the merged rows)"),
+                       "parallelism": "each rank uploads 1/N of the packed reads in parts, RCCL all-gathers over xGMI (async, under the next part's PCIe copy) complete every rank's copy; a-side read shards x%d + one RCCL all-gather of verified candidates (16 B, fixed slots) per step, under which each rank expands and brings home the rows of its own shard (1/%d of the job's rows)" % (world, world) if world > 1
                                       else "single GPU"},
             "rows_per_step": int(n_rows),
             "rccl_ranks": ranks_in_collective if args.dist_backend == "nccl" else 0,

@@ -137,6 +137,12 @@ po_status po_upload(po_handle* h);
 po_status po_upload_piece(po_handle* h, uint32_t shard, uint32_t nshards, void* dst_device, uint64_t capacity_words,
                           uint64_t* word_count, int* ok);
 po_status po_upload_assemble(po_handle* h, const void* pieces_device, uint64_t slot_words, uint32_t nshards);
+/* The same in `nparts` parts per shard (equal chunks of the shard's piece): the host->device copy of part k + 1 runs while
+ * the all-gather of part k is in flight.  The gathered buffer handed to po_upload_assemble_parts is laid out
+ * [part][shard][slot_words]. */
+po_status po_upload_piece_part(po_handle* h, uint32_t shard, uint32_t nshards, uint32_t part, uint32_t nparts, void* dst_device,
+                               uint64_t capacity_words, uint64_t* word_count, int* ok);
+po_status po_upload_assemble_parts(po_handle* h, const void* pieces_device, uint64_t slot_words, uint32_t nshards, uint32_t nparts);
 
 /* Forget the device copy of the read set: the next po_upload / po_overlaps* copies the packed reads host->device
  * again, as the first call of a fresh process does.  The reference's overlaps() starts from the host-side string

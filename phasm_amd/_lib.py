@@ -87,6 +87,9 @@ SYMBOLS = [
     ("po_upload_piece", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
                                        ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]),
     ("po_upload_assemble", ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32]),
+    ("po_upload_piece_part", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                            ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]),
+    ("po_upload_assemble_parts", ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32]),
     ("po_overlaps", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_overlaps_to_host", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(_P)]),
     ("po_overlaps_ex", ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),

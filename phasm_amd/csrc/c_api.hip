@@ -237,7 +237,7 @@ struct po_handle {
     // sharded upload (multi-GPU): store 0 arrives as nshards pieces that other ranks uploaded and xGMI carried here
     const uint64_t* asm_pieces = nullptr;
     uint64_t asm_slot_words = 0;
-    uint32_t asm_n = 0;
+    uint32_t asm_n = 0, asm_parts = 1;
     bool ex_on = false;
     uint32_t ex_E = 0, ex_W = 0;
     DevBuf d_end_a, d_end_b, d_dpcnt;
@@ -645,6 +645,17 @@ void store0_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint64_t
     *count = w1 > w0 ? w1 - w0 : 0;
 }
 
+// part `part` of `nparts` of that range (equal chunks of an even number of words, the last one shorter or empty): the
+// sharded upload is cut this way so that the host->device copy of one part runs under the all-gather of the part before
+void store0_part_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint32_t part, uint32_t nparts, uint64_t* begin, uint64_t* count) {
+    uint64_t wb = 0, wc = 0;
+    store0_range(h, shard, nshards, &wb, &wc);
+    const uint64_t cs = (((wc + nparts - 1) / nparts) + 1) & ~uint64_t(1);
+    const uint64_t lo = std::min(wc, (uint64_t)part * cs), hi = std::min(wc, (uint64_t)(part + 1) * cs);
+    *begin = wb + lo;
+    *count = hi - lo;
+}
+
 // Everything of an upload but the packed words themselves: scan tiles counted, device buffers sized, per-read
 // offsets / lengths / tile numbers copied, tile records built on the device (they need no read data).
 po_status upload_meta(po_handle* h, bool* generate_out) {
@@ -740,11 +751,15 @@ po_status upload(po_handle* h) {
     if (h->asm_pieces) {
         // sharded upload: piece k = the store-0 words of shard k's reads, uploaded by rank k, gathered over xGMI
         if (!generate) return fail(h, PO_ERR_INVALID, "po_upload_assemble needs reads added as (x, reverse complement of x) pairs");
-        for (uint32_t k = 0; k < h->asm_n; ++k) {
-            uint64_t wb = 0, wc = 0;
-            store0_range(h, k, h->asm_n, &wb, &wc);
-            if (wc > h->asm_slot_words) return fail(h, PO_ERR_INVALID, "po_upload_assemble: a piece is longer than the slot");
-            if (wc) HIP_TRY(h, hipMemcpyAsync(dw + wb, h->asm_pieces + (size_t)k * h->asm_slot_words, wc * 8, hipMemcpyDeviceToDevice, h->stream));
+        // (layout of the gathered buffer: [part][shard][slot])
+        for (uint32_t part = 0; part < h->asm_parts; ++part) {
+            for (uint32_t k = 0; k < h->asm_n; ++k) {
+                uint64_t wb = 0, wc = 0;
+                store0_part_range(h, k, h->asm_n, part, h->asm_parts, &wb, &wc);
+                if (wc > h->asm_slot_words) return fail(h, PO_ERR_INVALID, "po_upload_assemble: a piece is longer than the slot");
+                if (wc) HIP_TRY(h, hipMemcpyAsync(dw + wb, h->asm_pieces + ((size_t)part * h->asm_n + k) * h->asm_slot_words, wc * 8,
+                                                  hipMemcpyDeviceToDevice, h->stream));
+            }
         }
     } else if (!h->words[0].empty()) {
         HIP_TRY(h, hipMemcpyAsync(dw, h->words[0].data(), h->words[0].size() * 8, hipMemcpyHostToDevice, h->stream));
@@ -2443,9 +2458,9 @@ po_status po_upload(po_handle* h) {
 }
 
 // ---- sharded upload (multi-GPU): each rank brings 1/N of the packed reads over ITS PCIe link, xGMI does the rest ----
-po_status po_upload_piece(po_handle* h, uint32_t shard, uint32_t nshards, void* dst_device, uint64_t capacity_words,
-                          uint64_t* word_count, int* ok) {
-    if (!h || !word_count || !ok || nshards == 0 || shard >= nshards) return PO_ERR_INVALID;
+po_status po_upload_piece_part(po_handle* h, uint32_t shard, uint32_t nshards, uint32_t part, uint32_t nparts, void* dst_device,
+                               uint64_t capacity_words, uint64_t* word_count, int* ok) {
+    if (!h || !word_count || !ok || nshards == 0 || shard >= nshards || nparts == 0 || part >= nparts || nparts > 64) return PO_ERR_INVALID;
     *ok = 0;
     *word_count = 0;
     const uint32_t n = (uint32_t)h->len.size();
@@ -2454,25 +2469,31 @@ po_status po_upload_piece(po_handle* h, uint32_t shard, uint32_t nshards, void* 
     PO_TRY(init_device(h));
     uint64_t wb = 0, wc = 0;
     try {
-        store0_range(h, shard, nshards, &wb, &wc);
+        store0_part_range(h, shard, nshards, part, nparts, &wb, &wc);
     } catch (const std::bad_alloc&) {
         return fail(h, PO_ERR_NOMEM, "out of host memory");
     }
     *word_count = wc;
     *ok = 1;
-    if (!dst_device) return PO_OK;   // (a query: how many words is this shard's piece?)
+    if (!dst_device) return PO_OK;   // (a query: how many words is this part of the shard's piece?)
     if (wc > capacity_words) return fail(h, PO_ERR_INVALID, "po_upload_piece: the piece does not fit the destination");
     if (wc) HIP_TRY(h, hipMemcpyAsync(dst_device, h->words[0].data() + wb, wc * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->upload_bytes = wc * 8;
+    h->upload_bytes = (part == 0 ? 0 : h->upload_bytes) + wc * 8;
     return PO_OK;
 }
 
-po_status po_upload_assemble(po_handle* h, const void* pieces_device, uint64_t slot_words, uint32_t nshards) {
-    if (!h || !pieces_device || nshards == 0) return PO_ERR_INVALID;
+po_status po_upload_piece(po_handle* h, uint32_t shard, uint32_t nshards, void* dst_device, uint64_t capacity_words,
+                          uint64_t* word_count, int* ok) {
+    return po_upload_piece_part(h, shard, nshards, 0, 1, dst_device, capacity_words, word_count, ok);
+}
+
+po_status po_upload_assemble_parts(po_handle* h, const void* pieces_device, uint64_t slot_words, uint32_t nshards, uint32_t nparts) {
+    if (!h || !pieces_device || nshards == 0 || nparts == 0 || nparts > 64) return PO_ERR_INVALID;
     h->asm_pieces = static_cast<const uint64_t*>(pieces_device);
     h->asm_slot_words = slot_words;
     h->asm_n = nshards;
+    h->asm_parts = nparts;
     h->dirty = true;
     const uint64_t piece_bytes = h->upload_bytes;
     po_status st;
@@ -2482,12 +2503,17 @@ po_status po_upload_assemble(po_handle* h, const void* pieces_device, uint64_t s
         st = fail(h, PO_ERR_NOMEM, "out of host memory in po_upload_assemble");
     }
     h->asm_pieces = nullptr;
+    h->asm_parts = 1;
     if (st != PO_OK && h->dev_ready) (void)hipStreamSynchronize(h->stream);
     if (st == PO_OK) {
         h->upload_bytes += piece_bytes;   // (what THIS rank moved over PCIe: its piece + the per-read tables)
         h->stats.upload_bytes = h->upload_bytes;
     }
     return st;
+}
+
+po_status po_upload_assemble(po_handle* h, const void* pieces_device, uint64_t slot_words, uint32_t nshards) {
+    return po_upload_assemble_parts(h, pieces_device, slot_words, nshards, 1);
 }
 
 po_status po_invalidate(po_handle* h) {

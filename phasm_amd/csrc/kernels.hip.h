@@ -32,6 +32,21 @@ constexpr int WAVE = 64;
 // kernels behind the counting pass are launched without a host round trip, sized for `cap` candidates, and read the real
 // number from device memory (the counting pass's prefix-sum total).  Should the count exceed what the buffers hold,
 // every one of them does nothing -- the host sees the count at the end of the piece and takes the safe form of the call.
+// -DPO_VER_PAD=n / -DPO_SCAN_PAD=n (measurement builds, tools/pad_probe.sh): n extra full-rate VALU instructions per
+// 16-byte compare of the verify kernel / per position of the scan filter.  How much a kernel's time grows per added
+// VALU cycle says how far it is bound by VALU issue (slope 1) rather than by latency (slope 0).
+#ifndef PO_VER_PAD
+#define PO_VER_PAD 0
+#endif
+#ifndef PO_SCAN_PAD
+#define PO_SCAN_PAD 0
+#endif
+template <int N>
+__device__ __forceinline__ void valu_pad(uint32_t& r, uint32_t c) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r) : "v"(c));
+}
+
 struct CandGuard {
     const unsigned long long* n_dev;   // nullptr: the host knows the count, no check
     uint32_t cap;
@@ -739,6 +754,7 @@ __device__ inline uint32_t filter_tile(const uint32_t* __restrict__ s_bloom, uin
             // only bit 0 of the product enters: v_alignbit shifts it in at the top, after 32 rounds position s is bit s
             hitmask = __builtin_amdgcn_alignbit((b.x >> (t1 & 31)) & (b.x >> (sel2 & 31)) & (b.y >> (t2 & 31)), hitmask, 1);
             if (s + PO_FILTER_DEPTH < 32) blk[s % PO_FILTER_DEPTH] = block_of(s + PO_FILTER_DEPTH);
+            if constexpr (PO_SCAN_PAD > 0) valu_pad<PO_SCAN_PAD>(hitmask, 0u);   // (measurement builds only; x ^ 0)
             asm volatile("" : "+v"(hitmask));   // pins this position's arithmetic in front of the barrier
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1573,6 +1589,7 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
             a3 = ga32[q + dd + 3];
             a4 = ga32[q + dd + 4];
         }
+        if constexpr (PO_VER_PAD > 0) valu_pad<PO_VER_PAD>(a0, sh);   // (measurement builds only)
         uint32_t x0 = __builtin_amdgcn_alignbit(a1, a0, sh) ^ bv.x;
         uint32_t x1 = __builtin_amdgcn_alignbit(a2, a1, sh) ^ bv.y;
         uint32_t x2 = __builtin_amdgcn_alignbit(a3, a2, sh) ^ bv.z;

@@ -21,6 +21,7 @@ RCCL has no all-gatherv: ``merge_row_shards`` gathers counts first, then one pad
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import numpy as np
@@ -122,9 +123,14 @@ class ReadExchange:
         self.local = None
         self.gathered = None
         self.n_collectives = 0
+        self.n_parts = 1
 
-    def upload(self) -> bool:
-        """True: sharded upload done.  False: plain ``po_upload`` was used."""
+    def upload(self, parts: Optional[int] = None) -> bool:
+        """True: sharded upload done.  False: plain ``po_upload`` was used.
+
+        The piece travels in ``parts`` parts (default: one per ~8 MB of this rank's piece, at most 4): the host->device copy
+        of part k + 1 runs while the all-gather of part k is in flight (``async_op``), so the step costs about
+        ``max(PCIe, xGMI)`` plus one part instead of their sum."""
         if not self.on or self.ws < 2:
             self.ov.upload()
             return False
@@ -132,21 +138,32 @@ class ReadExchange:
         if not all(ok for ok, _ in sizes):
             self.ov.upload()
             return False
-        slot = max(n for _, n in sizes) + 1
-        if self.local is None or self.local.shape[0] != slot:
-            self.local = torch.empty(slot, dtype=torch.int64, device=self.device)
-            self.gathered = torch.empty(self.ws * slot, dtype=torch.int64, device=self.device)
+        longest = max(n for _, n in sizes)
+        if parts is None:
+            parts = int(os.environ.get("PHASM_UPLOAD_PARTS", "0")) or max(1, min(4, (longest * 8) >> 23))
+        parts = max(1, min(int(parts), 64))
+        # equal slots: the longest part of any shard (every rank computes every part's length from its own read table)
+        slot = max(self.ov.upload_piece_part(k, self.ws, p, parts)[1] for k in range(self.ws) for p in range(parts)) + 1
+        if self.local is None or self.local.shape != (parts, slot):
+            self.local = torch.empty((parts, slot), dtype=torch.int64, device=self.device)
+            self.gathered = torch.empty((parts, self.ws * slot), dtype=torch.int64, device=self.device)
             torch.cuda.current_stream(self.device).synchronize()
-        self.ov.upload_piece(self.rank, self.ws, self.local.data_ptr(), slot)      # host -> device, this rank's link
-        if self.via_host:
-            host = torch.empty(self.ws * slot, dtype=torch.int64)
-            dist.all_gather_into_tensor(host, self.local.cpu(), group=self.group)
-            self.gathered.copy_(host)
-        else:
-            dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)   # device -> devices, xGMI
-        self.n_collectives += 1
+        pending = []
+        for p in range(parts):
+            # host -> device, this rank's link (returns when the part has landed; the all-gather of the part before is in flight)
+            self.ov.upload_piece_part(self.rank, self.ws, p, parts, self.local[p].data_ptr(), slot)
+            if self.via_host:
+                host = torch.empty(self.ws * slot, dtype=torch.int64)
+                dist.all_gather_into_tensor(host, self.local[p].cpu(), group=self.group)
+                self.gathered[p].copy_(host)
+            else:
+                pending.append(dist.all_gather_into_tensor(self.gathered[p], self.local[p], group=self.group, async_op=True))   # xGMI
+            self.n_collectives += 1
+        for w in pending:
+            w.wait()
         torch.cuda.current_stream(self.device).synchronize()
-        self.ov.upload_assemble(self.gathered.data_ptr(), slot, self.ws)
+        self.n_parts = parts
+        self.ov.upload_assemble(self.gathered.data_ptr(), slot, self.ws, parts)
         return True
 
 
@@ -325,6 +342,64 @@ class CandidateExchange:
     def rows(self, min_length: int):
         """One full step: the merged rows as an ``OverlapResult`` resident on this rank's GPU."""
         return expand_candidates(self.ov, self.candidates(min_length))
+
+    def rows_home(self, min_length: int):
+        """The pipelined step: ``(merged candidates on the GPU, this rank's rows as a host array view + their result)``.
+
+        The rows a rank brings home are the rows of ITS OWN candidates (shard g's canonical candidates and their strand
+        mirrors): their expansion and their device->host copy need nothing from the other ranks, so they run while the
+        all-gather of the candidates is in flight.  Rank order = read order, so the ranks' row arrays concatenated are the
+        merged row multiset, and the merged CANDIDATE list -- north_star's "all-gather to merge the per-GPU lists" -- is on
+        every GPU for whoever consumes it next (``po_expand``, layout stage 1).  Before: every rank expanded all N shards
+        (N x the work) and copied 1/N of the merged rows only after the collective had finished."""
+        if not (self.on and self.slot and self.device.type == "cuda"):
+            # first step (slot not sized yet) or a host-side rehearsal: the plain sequence, own rows from the merged list
+            merged = self.candidates(min_length)
+            res = expand_candidates(self.ov, self._own_slice(merged))
+            return merged, res
+        idx = self.index.get(min_length) if self.index is not None else None
+        dst, cap = self.local.data_ptr() + 16, self.slot - 1
+        if idx is not None:
+            res, written = self.ov.candidates_result_indexed(min_length, self.rank, self.ws, idx["buf"].data_ptr(), idx["n_slices"],
+                                                             idx["bits"], idx["cap"], dst, cap)
+        else:
+            res, written = self.ov.candidates_result_into(min_length, self.rank, self.ws, dst, cap)
+        try:
+            n = len(res)
+            if not written:
+                # the shard outgrew its slot: the sized exchange below sorts that out (rare: one step after the data changed)
+                def fill(dst_t: torch.Tensor, take: int) -> None:
+                    res.copy_to_device(dst_t.data_ptr(), take)
+                merged = self._exchange(n, fill)
+                return merged, expand_candidates(self.ov, self._own_slice(merged))
+            if n < self.filled:
+                self.local[1 + n:1 + self.filled].zero_()
+            self.filled = n
+            self.local[0, 0] = n
+            work = dist.all_gather_into_tensor(self.gathered, self.local, group=self.group, async_op=True)
+            self.n_collectives += 1
+            # ... and while the candidates travel: this rank's rows (the library's stream; reads self.local[1:1+n] only)
+            own = self.ov.expand_result(self.local.data_ptr() + 16, n)
+            own.rows_view()                                   # device -> host, page-locked, on the library's copy path
+            work.wait()
+            slots = self.gathered.view(self.ws, self.slot, 4)
+            self.hdr_host.copy_(slots[:, 0, 0], non_blocking=True)
+            slots[:, 0, :] = 0
+            torch.cuda.current_stream(self.device).synchronize()
+            need = int(self.hdr_host.max().item()) + 1
+            if need > self.slot:                               # another rank outgrew the slot: repeat with room
+                self._resize(need)
+                own.free()
+                return self.rows_home(min_length)
+            return self.gathered, own
+        finally:
+            res.free()
+
+    def _own_slice(self, merged: torch.Tensor) -> torch.Tensor:
+        """This rank's candidates inside a merged slot buffer (or the whole tensor when nothing is distributed)."""
+        if not self.on or self.slot == 0 or merged.shape[0] != self.ws * self.slot:
+            return merged
+        return merged[self.rank * self.slot:(self.rank + 1) * self.slot]
 
 
 def sharded_overlaps(ov, min_length: int, group=None, device: Optional[torch.device] = None) -> torch.Tensor:

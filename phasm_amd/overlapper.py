@@ -300,8 +300,16 @@ class ExactOverlapper:
                                                   int(capacity_words), ctypes.byref(n), ctypes.byref(ok)))
         return bool(ok.value), int(n.value)
 
-    def upload_assemble(self, pieces_ptr: int, slot_words: int, nshards: int) -> None:
-        _check(self._h, self._lib.po_upload_assemble(self._h, ctypes.c_void_p(pieces_ptr), int(slot_words), int(nshards)))
+    def upload_assemble(self, pieces_ptr: int, slot_words: int, nshards: int, nparts: int = 1) -> None:
+        _check(self._h, self._lib.po_upload_assemble_parts(self._h, ctypes.c_void_p(pieces_ptr), int(slot_words), int(nshards), int(nparts)))
+
+    def upload_piece_part(self, shard: int, nshards: int, part: int, nparts: int, dst_ptr: int = 0, capacity_words: int = 0) -> Tuple[bool, int]:
+        """``po_upload_piece_part``: part ``part`` of ``nparts`` of shard ``shard``'s piece (see ``upload_piece``)."""
+        n, ok = ctypes.c_uint64(), ctypes.c_int()
+        _check(self._h, self._lib.po_upload_piece_part(self._h, int(shard), int(nshards), int(part), int(nparts),
+                                                       ctypes.c_void_p(dst_ptr) if dst_ptr else None, int(capacity_words),
+                                                       ctypes.byref(n), ctypes.byref(ok)))
+        return bool(ok.value), int(n.value)
 
     def invalidate(self) -> None:
         """``po_invalidate``: the next upload / overlaps call copies the packed reads to the device again."""

@@ -109,6 +109,18 @@ try:
         assert np.array_equal(r.rows(), whole)
         r.free()
     assert ex.n_collectives == 2 + 2 + 1 + 1
+    # the pipelined step: own rows expanded and copied home while the (async) all-gather of the candidates is in flight;
+    # a smaller and a larger problem in turn (the slot must grow in the middle of a pipelined step as well)
+    for mm in (m, 4 * m, m, m):
+        merged, own = ex.rows_home(mm)
+        got = oo.sort_rows(oo.struct_to_rows(own.rows_view()))
+        own.free()
+        ref = oo.sort_rows(oo.struct_to_rows(ov.overlaps_array(mm)))
+        assert np.array_equal(got, ref), (mm, len(got), len(ref))
+        assert merged.shape[1] == 4 and merged.is_cuda
+    # the sharded upload in parts through the same code path (one rank: the plain upload is taken)
+    from phasm_amd.dist import ReadExchange
+    assert ReadExchange(ov, device=dev).upload(parts=3) is False
     ov.close()
 finally:
     dist.destroy_process_group()
@@ -240,7 +252,8 @@ try:
         ov.add_sequence("r%%d" %% i, s)
     from phasm_amd.dist import ReadExchange
     rx = ReadExchange(ov)
-    assert rx.upload() is True and rx.n_collectives == 1            # each rank uploaded its half, the other half came over the wire
+    assert rx.upload(parts=3) is True and rx.n_collectives == 3     # each rank uploaded its share in three parts, the rest came over the wire
+    assert rx.upload() is True                                      # (default: one part for a piece this small)
     ex = CandidateExchange(ov, device=torch.device("cpu"))          # gloo carries the collectives, one GPU runs both ranks
     for step in range(2):
         res = ex.rows(m)
@@ -248,6 +261,16 @@ try:
         res.free()
         assert np.array_equal(rows, want), (rank, step, len(rows), len(want))
         assert ov.stats()["wide_index"] == 1
+    # the pipelined step: every rank brings home the rows of ITS shard; together they are the golden rows
+    for step in range(2):
+        merged, own = ex.rows_home(m)
+        mine = oo.struct_to_rows(own.rows_view()).copy()
+        own.free()
+        parts = [None] * ws
+        dist.all_gather_object(parts, mine)
+        rows = oo.sort_rows(np.concatenate(parts))
+        assert np.array_equal(rows, want), (rank, step, len(rows), len(want))
+        assert 0 < len(mine) < len(want)
     assert ex.index.index is not None and ex.index.index["n_slices"] == ws      # the sliced index was exchanged ...
     assert ex.index.n_collectives == 2                                           # ... once: the second step reused it
     ov.close()
