@@ -528,6 +528,11 @@ def main() -> int:
             tj = {}
         pmc_traffic = tj.get(args.config, {})
         pmc_ctr = tj.get(args.config + "_counters", {})
+        try:   # the VALU model: cycles per instruction class (calibrated), static mix per kernel, padding sensitivity
+            with open(os.path.join(ROOT, "profiles", "r03_valu_model.json")) as f:
+                valu_model = json.load(f)["kernels"] if args.config == "cfg2" and world == 1 else {}
+        except (OSError, ValueError, KeyError):
+            valu_model = {}
         positions = last["shard_bases"]                  # one filter lookup (8 B of LDS) per position of the scan
         # Launch durations: HIP events around the kernel in the RESIDENT loop (one whole-set launch per step, the same
         # launches the rocprofv3 --pmc passes profile); inside the host-to-host region the same work runs as 4 chunk
@@ -555,13 +560,23 @@ def main() -> int:
             if v.get("lds_bytes") and peaks.get("lds_random_b64_TBps") and t > 0:
                 lim["lds"] = {"GBps": v["lds_bytes"] / t / 1e9, "peak_GBps": peaks["lds_random_b64_TBps"] * 1e3}
             ctr = pmc_ctr.get(name, {})
-            if ctr.get("SQ_INSTS_VALU") and peaks.get("valu_wave_insts_per_sec_chip") and t > 0:
-                lim["valu"] = {"G_wave_insts_per_s": ctr["SQ_INSTS_VALU"] / t / 1e9,
-                               "peak_G_wave_insts_per_s": peaks["valu_wave_insts_per_sec_chip"] / 1e9,
-                               "wave_insts_per_launch": ctr["SQ_INSTS_VALU"]}
+            vm = valu_model.get(name, {})
+            if ctr.get("SQ_INSTS_VALU") and ctr.get("SQ_BUSY_CU_CYCLES") and vm.get("static_mean_cycles_per_valu_inst"):
+                # VALU busy = instructions x their issue cost / SIMD-cycles of the launch.  The cost per instruction is the
+                # kernel's static mix priced with the cycles tools/valu_calib.py measured (2.15 for VOP1/VOP2 forms, 4.05 for
+                # VOP3 integer forms -- SQ_ACTIVE_INST_VALU turned out to count instructions, not cycles, so it cannot say).
+                # In units of G SIMD-cycles per second: the peak is every SIMD busy every cycle of the launch.
+                simd_cycles = 4.0 * ctr["SQ_BUSY_CU_CYCLES"]
+                busy_cycles = ctr["SQ_INSTS_VALU"] * vm["static_mean_cycles_per_valu_inst"]
+                lim["valu"] = {"G_simd_cycles_per_s": busy_cycles / t / 1e9, "peak_G_simd_cycles_per_s": simd_cycles / t / 1e9,
+                               "wave_insts_per_launch": ctr["SQ_INSTS_VALU"],
+                               "mean_cycles_per_inst_static_mix": vm["static_mean_cycles_per_valu_inst"],
+                               "sensitivity": vm.get("valu_sensitivity"),
+                               "sensitivity_note": "tools/pad_probe.sh: kernel cycles gained per full-rate VALU cycle added to the hot loop "
+                                                   "(1 = VALU issue is what the kernel waits for, 0 = the pipe had room)"}
             for k2, x in lim.items():
-                ach = x.get("GBps", x.get("G_wave_insts_per_s"))
-                pk = x.get("peak_GBps", x.get("peak_G_wave_insts_per_s"))
+                ach = x.get("GBps", x.get("G_simd_cycles_per_s"))
+                pk = x.get("peak_GBps", x.get("peak_G_simd_cycles_per_s"))
                 x["frac"] = ach / pk
             v["limits"] = lim
             if lim:
@@ -571,9 +586,10 @@ def main() -> int:
         d = kern[dom]
         bl = d["limits"].get(d.get("bound", ""), {})
         out["roofline"] = {"bound": d.get("bound"), "kernel": dom,
-                           "achieved": bl.get("GBps", bl.get("G_wave_insts_per_s")),
-                           "peak": bl.get("peak_GBps", bl.get("peak_G_wave_insts_per_s")),
-                           "unit": "G wave-instructions/s" if d.get("bound") == "valu" else "GB/s",
+                           "achieved": bl.get("GBps", bl.get("G_simd_cycles_per_s")),
+                           "peak": bl.get("peak_GBps", bl.get("peak_G_simd_cycles_per_s")),
+                           "unit": "G SIMD-cycles/s (VALU busy)" if d.get("bound") == "valu" else "GB/s",
+                           "valu_sensitivity": bl.get("sensitivity"),
                            "frac": d.get("frac"), "traffic": d["traffic"],
                            "hbm_frac": d["limits"].get("hbm", {}).get("frac"),
                            "avg_launch_ms": d["avg_launch_ms"],
@@ -582,8 +598,9 @@ def main() -> int:
                            "algorithmic_note": "SURVEY 8d bytes / launch time; above the HBM peak because a comes from LDS, b from L2, and a "
                                                "strand-mirror pair is compared once and emitted twice -- not a roofline fraction",
                            "measured_peaks": peaks,
-                           "pmc_source": "profiles/traffic.json (rocprofv3 --pmc passes, tools/collect_pmc.sh + tools/pmc_to_traffic.py): "
-                                         "`traffic` and the VALU instruction counts are replayed from there, everything else is measured in this run",
+                           "pmc_source": "profiles/traffic.json (rocprofv3 --pmc passes, tools/collect_pmc.sh + tools/pmc_to_traffic.py) and "
+                                         "profiles/r03_valu_model.json (tools/valu_calib.py, tools/isa_mix.py, tools/pad_probe.sh): `traffic`, the VALU "
+                                         "instruction and CU-cycle counts and the VALU model are replayed from there, everything else is measured in this run",
                            "kernels": kern,
                            "job_algorithmic_bytes": int(job_bytes), "job_algorithmic_GBps": job_gbs}
         if world == 1:
