@@ -150,9 +150,13 @@ po_status po_upload_assemble_parts(po_handle* h, const void* pieces_device, uint
  * po_invalidate + po_overlaps_to_host + po_result_rows: the region bench.py times. */
 po_status po_invalidate(po_handle* h);
 
-/* overlaps(min_length)  -- src/overlapper.cpp:28-150.  Rows stay on the device until
- * po_result_rows() is called.  Stateless across calls like the reference (index rebuilt per
- * call, :33-36); min_length 0 behaves as 1 (a suffix array has no empty suffix).          */
+/* overlaps(min_length)  -- src/overlapper.cpp:28-150.  Rows stay on the device until po_result_rows() is called.
+ * Same rows on every call, like the reference.  The reference rebuilds its index inside every call (:33-36); this
+ * library does so whenever the device copy of the reads has changed (po_add_*, po_invalidate: what a reference call
+ * always faces) and otherwise REUSES the anchor index it built for the same upload, min_length and flavour
+ * (po_stats.index_reused = 1; PHASM_NO_INDEX_REUSE=1 rebuilds per call).  min_length 0 behaves as 1 (a suffix array
+ * has no empty suffix).  A handle also keeps its device workspaces, the pinned result buffers and -- for the streamed
+ * form of po_overlaps_to_host -- the candidate counts per piece of the previous call on the same reads.              */
 po_status po_overlaps(po_handle* h, uint32_t min_length, po_result** out);
 
 /* overlaps(min_length) the way the reference returns it -- the whole vector<OverlapT> in host memory

@@ -3128,7 +3128,15 @@ po_status po_index_slice_build(po_handle* h, uint32_t min_length, uint32_t slice
     return PO_OK;
 }
 
+// the triple a caller hands to the *_indexed entry points describes a buffer the library cannot see: refuse what cannot
+// be a sliced index at all (a shift by slice_bits >= 64 is undefined, the scan addresses 2^slice_bits slots per chunk)
+static bool slice_args_ok(uint32_t n_slices, uint32_t slice_bits, uint64_t chain_capacity) {
+    return n_slices >= 2 && n_slices <= 4096 && slice_bits >= 1 && slice_bits <= 30 && chain_capacity < (1ull << 36);
+}
+
 uint64_t po_index_chunk_bytes(uint32_t slice_bits, uint64_t chain_capacity, uint64_t* chain_offset_bytes) {
+    if (chain_offset_bytes) *chain_offset_bytes = 0;
+    if (slice_bits < 1 || slice_bits > 30 || chain_capacity >= (1ull << 36)) return 0;   // (not a sliced index)
     // [2^bits + 1 slots of 16 bytes | padding to 256 | chain_capacity entries of 8 bytes | padding to 256]
     const uint64_t off = ((((1ull << slice_bits) + 1ull) * sizeof(po::Slot)) + 255ull) & ~255ull;
     if (chain_offset_bytes) *chain_offset_bytes = off;
@@ -3153,7 +3161,9 @@ po_status po_candidates_shard_indexed(po_handle* h, uint32_t min_length, uint32_
                                       const void* index_device, uint32_t n_slices, uint32_t slice_bits, uint64_t chain_capacity,
                                       void* dst_device, uint64_t capacity, int* written, po_result** out) {
     if (written) *written = 0;
-    if (!h || !out || !index_device || n_slices < 2) return PO_ERR_INVALID;
+    if (!h || !out || !index_device) return PO_ERR_INVALID;
+    if (!slice_args_ok(n_slices, slice_bits, chain_capacity))
+        return fail(h, PO_ERR_INVALID, "sliced index: need 2..4096 slices of 2^1..2^30 slots (slice_bits as po_index_slice_build reported it)");
     if (!dst_device && capacity) return PO_ERR_INVALID;
     uint64_t off = 0;
     const uint64_t chunk = po_index_chunk_bytes(slice_bits, chain_capacity, &off);
@@ -3172,7 +3182,9 @@ po_status po_candidates_shard_indexed(po_handle* h, uint32_t min_length, uint32_
 // (test hook: the row form of the same call)
 po_status po_overlaps_shard_indexed(po_handle* h, uint32_t min_length, uint32_t shard, uint32_t nshards, const void* index_device,
                                     uint32_t n_slices, uint32_t slice_bits, uint64_t chain_capacity, po_result** out) {
-    if (!h || !out || !index_device || n_slices < 2) return PO_ERR_INVALID;
+    if (!h || !out || !index_device) return PO_ERR_INVALID;
+    if (!slice_args_ok(n_slices, slice_bits, chain_capacity))
+        return fail(h, PO_ERR_INVALID, "sliced index: need 2..4096 slices of 2^1..2^30 slots (slice_bits as po_index_slice_build reported it)");
     uint64_t off = 0;
     const uint64_t chunk = po_index_chunk_bytes(slice_bits, chain_capacity, &off);
     if ((chunk / 16) * n_slices >= 0xFFFFFFF0ull) return fail(h, PO_ERR_CAPACITY, "sliced index larger than 64 GB");

@@ -98,3 +98,27 @@ def test_importable_under_the_reference_module_name():
         sys.path.remove(os.path.join(ROOT, "integration"))
         sys.modules.pop("phasm.overlapper", None)
         sys.modules.pop("phasm", None)
+
+
+def test_sliced_index_arguments_are_checked_at_the_boundary():
+    """The *_indexed entry points take a (n_slices, slice_bits, chain_capacity) triple that describes a buffer the
+    library cannot see: what cannot be a sliced index is refused before anything is computed or addressed (a shift by
+    slice_bits >= 64 is undefined; the scan addresses 2^slice_bits slots per chunk)."""
+    lib = _lib.load()
+    assert lib.po_index_chunk_bytes(0, 10, None) == 0 and lib.po_index_chunk_bytes(31, 10, None) == 0
+    assert lib.po_index_chunk_bytes(64, 10, None) == 0 and lib.po_index_chunk_bytes(70, 10, None) == 0
+    off = ctypes.c_uint64()
+    assert lib.po_index_chunk_bytes(10, 100, ctypes.byref(off)) == ((1025 * 16 + 255) // 256 * 256) + (800 + 255) // 256 * 256
+    assert off.value == (1025 * 16 + 255) // 256 * 256
+    h = ctypes.c_void_p()
+    assert lib.po_create(ctypes.byref(h)) == 0
+    buf = (ctypes.c_char * 4096)()
+    out = ctypes.c_void_p()
+    written = ctypes.c_int()
+    for n_slices, bits, cap in ((2, 0, 8), (2, 31, 8), (2, 64, 8), (2, 200, 8), (1, 10, 8), (5000, 10, 8), (2, 10, 1 << 40)):
+        st = lib.po_candidates_shard_indexed(h, 100, 0, 2, ctypes.cast(buf, ctypes.c_void_p), n_slices, bits, cap, None, 0,
+                                             ctypes.byref(written), ctypes.byref(out))
+        assert st == _lib.PO_ERR_INVALID, (n_slices, bits, cap, st)
+        st = lib.po_overlaps_shard_indexed(h, 100, 0, 2, ctypes.cast(buf, ctypes.c_void_p), n_slices, bits, cap, ctypes.byref(out))
+        assert st == _lib.PO_ERR_INVALID, (n_slices, bits, cap, st)
+    lib.po_destroy(h)

@@ -668,6 +668,16 @@ def test_sliced_wide_index_equals_the_whole_index(n_slices, monkeypatch):
     import torch
     monkeypatch.setenv("PHASM_INDEX", "wide")
     cases = [gu.ladder_case("cfg3_1k")[1:], gu.ladder_case("ladder_varlen")[1:]] + [c[1:] for c in gu.repeats_cases()[2:]]
+    # skew: read sets with a handful of distinct K-mers -- every key of the index lands in one or two sub-tables, whose
+    # chain segments then hold (nearly) all entries while the other slices stay empty (the chunk is sized by the fullest)
+    rc = bytes.maketrans(b"ACGT", b"TGCA")
+    rng = np.random.default_rng(8)
+    one = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=260))
+    unit = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=7))
+    period = [(unit * 60)[k:k + 300] for k in range(0, 28, 2)]
+    for reads in ([one] * 40, period):
+        seqs = [x for r in reads for x in (r, r.translate(rc)[::-1])]
+        cases.append((seqs, 70, ck.oracle_overlaps(seqs, 70)))
     for seqs, m, want in cases:
         ov = ExactOverlapper(device=0)
         for i, s in enumerate(seqs):
