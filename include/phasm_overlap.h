@@ -88,7 +88,8 @@ typedef struct {
     uint32_t max_diff, band;     /*                 the parameters of the call (0, 0 for the exact entry points)     */
     uint32_t index_reused;       /* 1: the anchor index of the previous call on this handle was reused (same upload,   */
     uint32_t dp_lanes;           /*    same min_length and flavour); 0: built in this call.  dp_lanes (po_overlaps_ex):  */
-                                 /*    1 = lane-per-candidate DP kernel, 0 = wave-per-candidate (lane per diagonal)     */
+                                 /*    2 = lane per candidate, band row as a bit vector; 1 = lane per candidate, band row */
+                                 /*    in registers; 0 = wave per candidate (a lane per diagonal)                         */
     uint64_t upload_bytes;       /* bytes the last po_upload moved host->device (half the packed set when every   */
                                  /* odd read is the reverse complement of its even partner: the device rebuilds them) */
     uint32_t streamed;           /* po_overlaps_to_host: 1 = streamed step (reads uploaded piece by piece under the      */

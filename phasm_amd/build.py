@@ -66,5 +66,25 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+PYT_SRC = os.path.join(HERE, "csrc", "pytuples.c")
+PYT_LIB = os.path.join(HERE, "_pytuples.so")
+
+
+def build_pytuples(force: bool = False):
+    """The native list-of-tuples builder behind ExactOverlapper.overlaps() (plain C against Python.h; optional: without it
+    the shim builds the list in Python).  Returns the path, or None when it cannot be built here."""
+    import sysconfig
+    if not force and os.path.exists(PYT_LIB) and os.path.getmtime(PYT_LIB) >= os.path.getmtime(PYT_SRC):
+        return PYT_LIB
+    inc = sysconfig.get_paths().get("include")
+    if not inc or not os.path.exists(os.path.join(inc, "Python.h")):
+        return None
+    cmd = [os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-I" + inc, "-o", PYT_LIB, PYT_SRC]
+    if subprocess.call(cmd) != 0:
+        return None
+    return PYT_LIB
+
+
 if __name__ == "__main__":
+    build_pytuples(force=True)
     print(build_library(force=True, verbose="-v" in sys.argv))

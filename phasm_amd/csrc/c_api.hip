@@ -1404,12 +1404,21 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             // two mappings of the same DP (extend.hip.h): a LANE per candidate (2-bit reads, band <= 15: the one an
             // overlap job wants -- millions of candidates, narrow bands), or a WAVE per candidate with a lane per
             // diagonal (any encoding, band <= 30); PHASM_DP_KERNEL=wave|lanes forces one (tests run both)
+            // three mappings of the same DP (extend.hip.h), same rows bit for bit: a LANE per candidate with the band row as a
+            // BIT VECTOR (k_extend_bits: 2-bit reads, band <= 15 -- the default where it applies), a lane per candidate with
+            // the band row in registers (k_extend_lanes), a WAVE per candidate with a lane per diagonal (k_extend_dp: any
+            // encoding, band <= 30).  PHASM_DP_KERNEL=bits|lanes|wave forces one (the tests run all three)
             bool lanes = BITS == 2 && dpW <= 15;
+            bool bitvec = lanes;
             if (const char* e = getenv("PHASM_DP_KERNEL")) {
-                if (!strcmp(e, "wave")) lanes = false;
-                if (!strcmp(e, "lanes") && !(BITS == 2 && dpW <= 15)) return fail(h, PO_ERR_INVALID, "PHASM_DP_KERNEL=lanes needs 2-bit reads and band <= 15");
+                if (!strcmp(e, "wave")) lanes = bitvec = false;
+                if (!strcmp(e, "lanes")) bitvec = false;
+                if ((!strcmp(e, "lanes") || !strcmp(e, "bits")) && !(BITS == 2 && dpW <= 15))
+                    return fail(h, PO_ERR_INVALID, "PHASM_DP_KERNEL=lanes|bits needs 2-bit reads and band <= 15");
             }
-            S.dp_lanes = lanes ? 1u : 0u;
+            if (const char* e = getenv("PHASM_DP_KERNEL_SOFT"))   // (tests: "lanes" where a lane mapping applies at all, no error elsewhere)
+                if (!strcmp(e, "lanes")) bitvec = false;
+            S.dp_lanes = bitvec ? 2u : lanes ? 1u : 0u;
             HIP_TRY(h, hipEventRecord(h->ev[EV_VER0], st));
             if (lanes) {
                 // candidates ordered by the rows they need, so that the 64 lanes of a wave finish together
@@ -1437,7 +1446,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                                        h->d_vperm.as<uint32_t>());
                     perm = h->d_vperm.as<uint32_t>();
                 }
-                auto kern = dpW <= 4 ? po::k_extend_lanes<4> : dpW <= 8 ? po::k_extend_lanes<8> : po::k_extend_lanes<15>;
+                auto kern = bitvec ? po::k_extend_bits : dpW <= 4 ? po::k_extend_lanes<4> : dpW <= 8 ? po::k_extend_lanes<8> : po::k_extend_lanes<15>;
                 hipLaunchKernelGGL(kern, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, X, perm);
             } else {
                 hipLaunchKernelGGL((po::k_extend_dp<BITS>), dim3(cdiv(n_cand, 256 / po::WAVE)), dim3(256), 0, st, X);

@@ -488,6 +488,160 @@ __global__ __launch_bounds__(256) void k_extend_lanes(const ExtArgs A, const uin
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// Mapping (3): one lane per candidate, the band row as a BIT VECTOR (Myers 1999 / Hyyro 2003, diagonal band).
+//
+// k_extend_lanes spends six instructions on each of the 2W + 1 cells of a row (102 per row at W = 8).  The cells of a
+// row differ from their neighbours by -1, 0 or +1, so the whole row is two bit masks -- HP / HN: bit k set iff
+// C[k] - C[k-1] = +1 / -1, C[k] = D[i][i - W + k] -- plus ONE number, the main-diagonal cell S = D[i][i].  One row of
+// the DP is then ~35 instructions whatever the band (W <= 15: 31 bits):
+//   the previous row seen through the window shifted by one diagonal step: P'[k] = C_prev[k + 1], so its deltas are the
+//   previous row's, shifted right by one (the cell beyond the band's top edge counts as one higher: never the minimum);
+//   Eq = match bits of x[i-1] against the 2W + 1 bases of y facing the band (two bit planes of y slide along);
+//   D0 = (((Eq & VP) + VP) ^ VP) | Eq | VN      -- bit k: D[i][j] == D[i-1][j-1]   (the carry runs along the row)
+//   vertical deltas hp = VN | ~(D0 | VP), hn = D0 & VP; this row's HP = (hn << 1) | ~(D0 | (hp << 1 | 1)),
+//   HN = D0 & (hp << 1 | 1)   (the cell below the band's bottom edge counts as one higher as well);  S += 1 - D0[W].
+// Cells left of the matrix (j < 0, the first W rows) are the virtual cells D[i][j] = i + |j| with every comparison a
+// mismatch: consistent with the recurrence and never on a best path.  A cell's value, where one is wanted -- the ends, the
+// band minimum every 16 rows -- is S plus the deltas between: popcounts.  Same rows, bit for bit, as the other two
+// mappings (tests/test_gpu_extend.py runs all three against oracle/extend_oracle.c; the prototype of this recurrence
+// was held against the plain DP on 40 000 random cases first).
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_extend_bits(const ExtArgs A, const uint32_t* __restrict__ perm) {
+    const uint32_t c0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = c0 < A.n_cand;
+    const uint32_t c = in_range ? (perm ? perm[c0] : c0) : 0u;
+    const uint32_t a = A.cand_a[c], p = A.cand_p[c], b = A.cand_b[c];
+    const uint32_t la = A.len[a], lb = A.len[b];
+    const uint32_t rem = la - p;
+    const uint32_t E = A.max_diff;
+    const uint32_t W = __builtin_amdgcn_readfirstlane(E ? A.band : 0u);   // (wave-uniform: shifts by W are scalar operands)
+    const uint32_t N = 2u * W + 1u;
+    const uint32_t ALL = (1u << N) - 1u, TOP = 1u << (N - 1u);
+    bool canA = rem <= lb + W, canB = lb <= rem + W;
+    if (A.paired) {
+        const uint32_t kb = keep_bits(a, b, rem, lb, A.paired);
+        canA = canA && (kb & 1u);
+        canB = canB && (kb & 2u);
+    }
+    if (!in_range || a == b) canA = canB = false;
+    const uint32_t* __restrict__ gx = reinterpret_cast<const uint32_t*>(A.words + A.woff[a]);
+    const uint32_t* __restrict__ gy = reinterpret_cast<const uint32_t*>(A.words + A.woff[b]);
+    auto ybase = [&](int32_t q) __attribute__((always_inline)) -> uint32_t {
+        if (q < 0 || (uint32_t)q >= lb) return 0u;
+        return (gy[(uint32_t)q >> 4] >> (((uint32_t)q & 15u) * 2u)) & 3u;
+    };
+    // row 0: C[k] = |k - W|
+    uint32_t HP = ALL & ~((2u << W) - 1u), HN = ((2u << W) - 1u) & ~1u;   // bits W+1 .. N-1 / bits 1 .. W
+    uint32_t S = 0;
+    // the two bit planes of the y window of row 1: bit k = base y[k - W]
+    uint32_t plo = 0, phi = 0;
+    for (uint32_t k = 0; k < N; ++k) {
+        const uint32_t v = ybase((int32_t)k - (int32_t)W);
+        plo |= (v & 1u) << k;
+        phi |= (v >> 1) << k;
+    }
+    uint32_t vm = ALL & ~((1u << W) - 1u);   // row 1: columns j >= 1 are the cells k >= W
+    const uint32_t rows = canA ? rem : (canB ? min(rem, lb + W) : 0u);
+    uint32_t bestA = 0xFFFFFFFFu, bestB = 0xFFFFFFFFu, endA_j = 0, endB_i = 0;
+    uint32_t xw = 0, yw = 0, steps = 0;
+    bool dead = false;
+    const uint32_t above = ALL & ~((2u << W) - 1u), below = ((2u << W) - 1u) & ~1u;   // delta bits above / at-and-below the diagonal
+    auto cell = [&](uint32_t k) __attribute__((always_inline)) -> uint32_t {   // C[k] from S and the deltas between
+        if (k >= W) {
+            const uint32_t m = ((2u << k) - 1u) & above;          // bits W+1 .. k
+            return S + (uint32_t)__popc(HP & m) - (uint32_t)__popc(HN & m);
+        }
+        const uint32_t m = below & ~((2u << k) - 1u);             // bits k+1 .. W
+        return S - (uint32_t)__popc(HP & m) + (uint32_t)__popc(HN & m);
+    };
+    for (uint32_t i = 1; i <= rows; ++i) {
+        const uint32_t xpos = p + i - 1u, ypos = i + W;
+        if (i == 1u || (xpos & 15u) == 0u) xw = gx[xpos >> 4] >> ((xpos & 15u) * 2u);
+        if (i == 1u || (ypos & 15u) == 0u) yw = gy[ypos >> 4] >> ((ypos & 15u) * 2u);
+        const uint32_t xb = xw & 3u;
+        xw >>= 2;
+        const uint32_t xl = 0u - (xb & 1u), xh = 0u - (xb >> 1);
+        const uint32_t Eq = ~((plo ^ xl) | (phi ^ xh)) & vm;
+        const uint32_t VP = (HP >> 1) | TOP, VN = HN >> 1;
+        const uint32_t D0 = ((((Eq & VP) + VP) ^ VP) | Eq | VN) & ALL;
+        const uint32_t hp = (VN | ~(D0 | VP)) & ALL, hn = D0 & VP;
+        const uint32_t hps = ((hp << 1) | 1u) & ALL, hns = (hn << 1) & ALL;
+        HP = (hns | ~(D0 | hps)) & ALL;
+        HN = D0 & hps;
+        S += 1u - ((D0 >> W) & 1u);
+        ++steps;
+        if (canB && i + W >= lb && i <= lb + W) {   // B: column lb is cell k = lb - i + W of this row
+            const uint32_t kb = lb + W - i;
+            const uint32_t v = cell(kb);
+            const int32_t dl = (int32_t)kb - (int32_t)W;
+            if (v <= E) {
+                const uint32_t key = (v << 8) | ((uint32_t)(dl >= 0 ? dl : -dl) << 1) | (dl < 0 ? 1u : 0u);
+                if (key < bestB) {
+                    bestB = key;
+                    endB_i = i;
+                }
+            }
+        }
+        if (canA && i == rem) {   // A: row rem, columns 1 .. lb
+            for (uint32_t k = 0; k < N; ++k) {
+                const int32_t dl = (int32_t)k - (int32_t)W;
+                const int64_t j = (int64_t)rem + dl;
+                if (j >= 1 && j <= (int64_t)lb) {
+                    const uint32_t v = cell(k);
+                    if (v <= E) {
+                        const uint32_t key = (v << 8) | ((uint32_t)(dl >= 0 ? dl : -dl) << 1) | (dl > 0 ? 1u : 0u);
+                        if (key < bestA) {
+                            bestA = key;
+                            endA_j = (uint32_t)j;
+                        }
+                    }
+                }
+            }
+        }
+        if ((i & 15u) == 0u) {   // every 16 rows: the band minimum (walk the deltas up and down from the diagonal)
+            uint32_t rowmin = S, v = S;
+            for (uint32_t k = W + 1u; k < N; ++k) {
+                v += ((HP >> k) & 1u) - ((HN >> k) & 1u);
+                rowmin = min(rowmin, v);
+            }
+            v = S;
+            for (uint32_t k = W; k >= 1u; --k) {
+                v -= ((HP >> k) & 1u) - ((HN >> k) & 1u);
+                // (cells left of the matrix are virtual -- i + |j| -- and never the smallest of a row that has real cells)
+                rowmin = min(rowmin, v);
+            }
+            if (rowmin > E) {
+                dead = i < rows;
+                break;
+            }
+        }
+        // slide the y window: drop y[i - W - 1], take in y[i + W]; one more column is inside the matrix
+        const uint32_t nv = yw & 3u;
+        yw >>= 2;
+        plo = (plo >> 1) | ((nv & 1u) << (N - 1u));
+        phi = (phi >> 1) | ((nv >> 1) << (N - 1u));
+        vm |= vm >> 1;
+    }
+    uint32_t t = 0;
+    if (bestA != 0xFFFFFFFFu) {
+        t |= 1u;
+        A.end_a[c] = endA_j;
+    }
+    if (bestB != 0xFFFFFFFFu) {
+        t |= 2u;
+        A.end_b[c] = endB_i;
+    }
+    if (t && A.exc_off && E == 0 && !exceptions_equal(A.exc_off, A.exc_pos, A.exc_byte, a, p, b, (t & 1u) ? rem : lb)) t = 0;
+    if (in_range) A.type[c] = (uint8_t)t;
+    const uint64_t ws = wave_sum64(2ull * steps);
+    const uint32_t wd = wave_sum(dead ? 1u : 0u);
+    if (lane_id() == 0) {
+        atomicAdd(&A.counters[0], (unsigned long long)ws);
+        if (wd) atomicAdd(&A.counters[1], (unsigned long long)wd);
+    }
+}
+
 // Rows of the inexact mode: ends come from the DP (no strand-mirror shortcut: every candidate was extended itself).
 __global__ __launch_bounds__(256) void k_emit_ex(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
                                                  const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,

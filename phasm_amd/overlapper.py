@@ -29,6 +29,24 @@ from ._lib import CAND_DTYPE, EDGE_DTYPE, ROW_DTYPE, PoLayoutParams, PoLayoutSta
 
 OverlapT = Tuple[str, str, int, int, int, int]
 
+_PYT = [False, None]
+
+
+def _pytuples():
+    """``po_rows_to_tuples`` of phasm_amd/_pytuples.so (built by phasm_amd.build.build_pytuples), or None."""
+    if not _PYT[0]:
+        _PYT[0] = True
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_pytuples.so")
+        if os.path.exists(path) and not os.environ.get("PHASM_NO_PYTUPLES"):
+            try:
+                lib = ctypes.PyDLL(path)
+                lib.po_rows_to_tuples.restype = ctypes.py_object
+                lib.po_rows_to_tuples.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.py_object]
+                _PYT[1] = lib.po_rows_to_tuples
+            except (OSError, AttributeError):
+                _PYT[1] = None
+    return _PYT[1]
+
 
 def _to_bytes(x, what: str) -> bytes:
     if isinstance(x, bytes):
@@ -164,12 +182,21 @@ class ExactOverlapper:
         return int(n.value)
 
     def overlaps(self, min_length: int) -> List[OverlapT]:
-        arr = self.overlaps_array(min_length)
-        ids = self.ids()
-        a_ids = [ids[i] for i in arr["a_idx"].tolist()]
-        b_ids = [ids[i] for i in arr["b_idx"].tolist()]
-        return list(zip(a_ids, b_ids, arr["astart"].tolist(), arr["aend"].tolist(),
-                        arr["bstart"].tolist(), arr["bend"].tolist()))
+        res = self.overlaps_to_host_result(min_length)
+        try:
+            ids = self.ids()
+            fn = _pytuples()
+            if fn is not None and len(res):
+                # the list of tuples built natively from the page-locked row array (phasm_amd/csrc/pytuples.c), as
+                # pybind11 builds the reference's from std::vector<OverlapT> (src/phasm.cpp:15)
+                return fn(self._lib.po_result_rows(res._ptr), len(res), ids)
+            arr = res.rows_view()
+            a_ids = [ids[i] for i in arr["a_idx"].tolist()]
+            b_ids = [ids[i] for i in arr["b_idx"].tolist()]
+            return list(zip(a_ids, b_ids, arr["astart"].tolist(), arr["aend"].tolist(),
+                            arr["bstart"].tolist(), arr["bend"].tolist()))
+        finally:
+            res.free()
 
     # ---- bulk / multi-GPU extensions ------------------------------------------------------
     @staticmethod

@@ -122,3 +122,30 @@ def test_sliced_index_arguments_are_checked_at_the_boundary():
         st = lib.po_overlaps_shard_indexed(h, 100, 0, 2, ctypes.cast(buf, ctypes.c_void_p), n_slices, bits, cap, ctypes.byref(out))
         assert st == _lib.PO_ERR_INVALID, (n_slices, bits, cap, st)
     lib.po_destroy(h)
+
+
+def test_native_tuple_builder_matches_the_python_one():
+    """ExactOverlapper.overlaps() returns the reference's list of 6-tuples (src/phasm.cpp:15); the list is built natively
+    from the row array (phasm_amd/csrc/pytuples.c) -- same objects as the pure-Python form, shared id strings."""
+    from phasm_amd import build, overlapper
+    if build.build_pytuples() is None:
+        pytest.skip("Python.h not available: the shim builds the tuples in Python")
+    fn = overlapper._pytuples()
+    assert fn is not None
+    rng = np.random.default_rng(3)
+    n = 5000
+    arr = np.zeros(n, dtype=_lib.ROW_DTYPE)
+    ids = ["read%d%s" % (i // 2, "+-"[i & 1]) for i in range(40)]
+    arr["a_idx"], arr["b_idx"] = rng.integers(0, 40, n), rng.integers(0, 40, n)
+    for f in ("astart", "aend", "bstart", "bend"):
+        arr[f] = rng.integers(-5, 2_000_000_000, n)
+    arr["bstart"][::2] = 0
+    got = fn(arr.ctypes.data, n, ids)
+    want = list(zip([ids[i] for i in arr["a_idx"].tolist()], [ids[i] for i in arr["b_idx"].tolist()], arr["astart"].tolist(),
+                    arr["aend"].tolist(), arr["bstart"].tolist(), arr["bend"].tolist()))
+    assert got == want and all(type(t) is tuple and type(t[2]) is int for t in got[:50])
+    assert got[0][0] is ids[int(arr["a_idx"][0])]          # the id strings are shared, not copied
+    assert fn(arr.ctypes.data, 0, ids) == []
+    arr["a_idx"][7] = 40
+    with pytest.raises(IndexError):
+        fn(arr.ctypes.data, n, ids)

@@ -19,16 +19,20 @@ from phasm_amd.overlapper import ExactOverlapper
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["lanes", "wave"], autouse=True)
+@pytest.fixture(params=["bits", "lanes", "wave"], autouse=True)
 def dp_kernel(request, monkeypatch):
-    """Every test runs through both mappings of the DP: a lane per candidate (k_extend_lanes: 2-bit reads, band <= 15)
-    and a wave per candidate with a lane per diagonal (k_extend_dp).  Where `lanes` does not apply the library picks
-    the wave kernel by itself (no forcing), so the default selection is exercised too."""
+    """Every test runs through all three mappings of the DP: a lane per candidate with the band row as a bit vector
+    (k_extend_bits, the default: 2-bit reads, band <= 15), a lane per candidate with the band row in registers
+    (k_extend_lanes) and a wave per candidate with a lane per diagonal (k_extend_dp).  Where a lane mapping does not apply
+    the library picks the wave kernel by itself, so the default selection is exercised too."""
     if request.param == "wave":
         monkeypatch.setenv("PHASM_DP_KERNEL", "wave")
+    elif request.param == "lanes":
+        monkeypatch.setenv("PHASM_DP_SORT", "1")     # candidates ordered by length (what large calls do), also on small inputs
+        monkeypatch.setenv("PHASM_DP_KERNEL_SOFT", "lanes")
     else:
         monkeypatch.delenv("PHASM_DP_KERNEL", raising=False)
-        monkeypatch.setenv("PHASM_DP_SORT", "1")     # candidates ordered by length (what large calls do), also on small inputs
+        monkeypatch.setenv("PHASM_DP_SORT", "1")
     return request.param
 
 
@@ -102,7 +106,7 @@ def test_inexact_rows_equal_the_cpu_restatement(seed, max_diff, band, dp_kernel)
     got, st = ex_rows(seqs, m, max_diff, band)
     want = ck.oracle_overlaps_ex(seqs, m, max_diff, band, anchor=32)
     assert st["paired"] == 0 and st["max_diff"] == max_diff and st["band"] == band
-    assert st["dp_lanes"] == (1 if (dp_kernel == "lanes" and band <= 15) else 0)
+    assert st["dp_lanes"] == ((2 if dp_kernel == "bits" else 1) if (dp_kernel != "wave" and band <= 15) else 0)
     assert np.array_equal(got, want), (len(got), len(want), [tuple(r) for r in got[:5]], [tuple(r) for r in want[:5]])
     exact = ck.oracle_overlaps(seqs, m)
     assert len(want) >= len(exact)          # tolerance only ever adds overlaps of a pair / occurrences

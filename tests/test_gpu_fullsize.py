@@ -182,7 +182,7 @@ def test_full_size_cfg4_banded_dp_equals_truth_and_the_cpu_dp(monkeypatch):
       candidate near the threshold, every candidate that can have a B row (p <= band) and a random 200 k sample, the CPU
       restatement's DP (oracle/extend_oracle.c:extend_one, on the listed pairs) decides -- HIP must equal it everywhere;
     * a closed 300-read neighbourhood equals oracle_overlaps_ex (which searches its anchors itself);
-    * both DP mappings agree on a 5 k-read slice."""
+    * all three DP mappings agree on a 5 k-read slice."""
     from oracle import extend_oracle as eo          # pair-level helpers (pure functions on host arrays)
     cfg = synth.CONFIGS["cfg4"]
     codes, _ = synth.generate_codes(cfg)
@@ -195,7 +195,7 @@ def test_full_size_cfg4_banded_dp_equals_truth_and_the_cpu_dp(monkeypatch):
     ov.close()
     rows = oo.struct_to_rows(arr)
     del arr
-    assert st["dp_lanes"] == 1 and st["max_diff"] == DP_E and st["band"] == DP_W and st["n_rows"] == len(rows)
+    assert st["dp_lanes"] == 2 and st["max_diff"] == DP_E and st["band"] == DP_W and st["n_rows"] == len(rows)
 
     c = synth.expected_candidates(cfg, M, 32, codes)
     a, b, p = c["a"], c["b"], c["p"]
@@ -270,13 +270,13 @@ def test_full_size_cfg4_banded_dp_equals_truth_and_the_cpu_dp(monkeypatch):
     cfg_s = synth.scaled(cfg, 5000)
     _, _, ov = load("cfg4", cfg_s)
     got = {}
-    for kern in ("lanes", "wave"):
+    for kern in ("bits", "lanes", "wave"):
         monkeypatch.setenv("PHASM_DP_KERNEL", kern)
         got[kern] = oo.sort_rows(oo.struct_to_rows(ov.overlaps_ex_array(M, DP_E, DP_W)))
-        assert ov.stats()["dp_lanes"] == (1 if kern == "lanes" else 0)
+        assert ov.stats()["dp_lanes"] == {"bits": 2, "lanes": 1, "wave": 0}[kern]
     monkeypatch.delenv("PHASM_DP_KERNEL")
     ov.close()
-    assert len(got["lanes"]) > 500_000 and np.array_equal(got["lanes"], got["wave"])
+    assert len(got["lanes"]) > 500_000 and np.array_equal(got["lanes"], got["wave"]) and np.array_equal(got["bits"], got["wave"])
 
 
 @pytest.mark.parametrize("cfg_name", ["cfg2", "cfg4"])

@@ -118,7 +118,14 @@ def test_byte_mode_matches_oracle_on_mixed_alphabet():
         same(got, ck.oracle_overlaps(seqs, m), m)
 
 
-def test_repeated_calls_and_incremental_adds():
+@pytest.mark.parametrize("stream", ["0", "1"])
+def test_repeated_calls_and_incremental_adds(stream, monkeypatch):
+    """Row ORDER is not part of the contract (the reference's is std::unordered_map iteration order,
+    /root/reference/src/overlapper.cpp:30,:68).  What this library promises: the same call FORM on the same reads gives
+    the same array -- the resident form (a-major in insertion order) and the streamed form (pieces in index order, a
+    pair's rows attached to its later read) each have their own order, and a changed read set makes overlaps_array's
+    host-to-host call take the streamed form once (stream = 1 forces it for this small input)."""
+    monkeypatch.setenv("PHASM_STREAM", stream)
     _, seqs, m, want = gu.ladder_case("ladder_small")
     ov = ExactOverlapper()
     half = len(seqs) // 2
@@ -128,10 +135,25 @@ def test_repeated_calls_and_incremental_adds():
     same(first, ck.oracle_overlaps(seqs[:half], m))
     for i, s in enumerate(seqs[half:]):
         ov.add_sequence("r%d" % (half + i), s)
-    a = ov.overlaps_array(m)
-    b = ov.overlaps_array(m)
-    assert np.array_equal(a, b)  # same rows in the same (deterministic) order
-    assert np.array_equal(oo.sort_rows(oo.struct_to_rows(a)), want)
+    a = ov.overlaps_array(m)     # (the read set changed: with PHASM_STREAM=1 this call is the streamed form ...)
+    st_a = ov.stats()["streamed"]
+    b = ov.overlaps_array(m)     # (... and this one the resident, chunked form)
+    c2 = ov.overlaps_array(m)
+    assert st_a == int(stream) and ov.stats()["streamed"] == 0
+    assert np.array_equal(b, c2)  # the same form twice: the same rows in the same order
+    if stream == "0":
+        assert np.array_equal(a, b)
+    for x in (a, b):
+        assert np.array_equal(oo.sort_rows(oo.struct_to_rows(x)), want)
+    # two handles, the same reads, the same (streamed or not) first call: the same array
+    ov2 = ExactOverlapper()
+    for i, s in enumerate(seqs):
+        ov2.add_sequence("r%d" % i, s)
+    a2 = ov2.overlaps_array(m)
+    ov2.close()
+    assert sorted(map(tuple, a2.tolist())) == sorted(map(tuple, a.tolist()))
+    if stream == "0":
+        assert np.array_equal(a2, a)
     # a different min_length on the same handle (index is rebuilt per call, overlapper.cpp:33-36)
     c = oo.sort_rows(oo.struct_to_rows(ov.overlaps_array(m * 3)))
     same(c, ck.oracle_overlaps(seqs, m * 3))
