@@ -546,6 +546,17 @@ __global__ __launch_bounds__(256) void k_extend_bits(const ExtArgs A, const uint
     uint32_t bestA = 0xFFFFFFFFu, bestB = 0xFFFFFFFFu, endA_j = 0, endB_i = 0;
     uint32_t xw = 0, yw = 0, steps = 0;
     bool dead = false;
+    // the bases come in 16-byte pieces (64 bases), the NEXT piece requested while the current one is walked: a 4-byte
+    // load every 16 rows per lane and side (64 different cache lines per wave instruction, each line fetched again for
+    // every one of its 16 dwords once the other candidates have pushed it out) made this kernel wait for memory --
+    // 129 ms whatever the band
+    const u32x4* __restrict__ gx4 = reinterpret_cast<const u32x4*>(gx);
+    const u32x4* __restrict__ gy4 = reinterpret_cast<const u32x4*>(gy);
+    u32x4 xc = gx4[p >> 6], xn = gx4[(p >> 6) + 1u];
+    u32x4 yc = gy4[(1u + W) >> 6], yn = gy4[((1u + W) >> 6) + 1u];
+    auto pick = [](const u32x4& q, uint32_t dw) __attribute__((always_inline)) -> uint32_t {
+        return dw == 0u ? q.x : dw == 1u ? q.y : dw == 2u ? q.z : q.w;
+    };
     const uint32_t above = ALL & ~((2u << W) - 1u), below = ((2u << W) - 1u) & ~1u;   // delta bits above / at-and-below the diagonal
     auto cell = [&](uint32_t k) __attribute__((always_inline)) -> uint32_t {   // C[k] from S and the deltas between
         if (k >= W) {
@@ -557,8 +568,16 @@ __global__ __launch_bounds__(256) void k_extend_bits(const ExtArgs A, const uint
     };
     for (uint32_t i = 1; i <= rows; ++i) {
         const uint32_t xpos = p + i - 1u, ypos = i + W;
-        if (i == 1u || (xpos & 15u) == 0u) xw = gx[xpos >> 4] >> ((xpos & 15u) * 2u);
-        if (i == 1u || (ypos & 15u) == 0u) yw = gy[ypos >> 4] >> ((ypos & 15u) * 2u);
+        if (i != 1u && (xpos & 63u) == 0u) {
+            xc = xn;
+            xn = gx4[(xpos >> 6) + 1u];
+        }
+        if (i != 1u && (ypos & 63u) == 0u) {
+            yc = yn;
+            yn = gy4[(ypos >> 6) + 1u];
+        }
+        if (i == 1u || (xpos & 15u) == 0u) xw = pick(xc, (xpos >> 4) & 3u) >> ((xpos & 15u) * 2u);
+        if (i == 1u || (ypos & 15u) == 0u) yw = pick(yc, (ypos >> 4) & 3u) >> ((ypos & 15u) * 2u);
         const uint32_t xb = xw & 3u;
         xw >>= 2;
         const uint32_t xl = 0u - (xb & 1u), xh = 0u - (xb >> 1);
