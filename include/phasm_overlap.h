@@ -104,7 +104,10 @@ typedef struct {
 po_status po_create(po_handle** out);
 void po_destroy(po_handle* h);
 
-/* Choose the HIP device (default 0).  Must precede the first po_overlaps* call. */
+/* Choose the HIP device (default 0).  Call it BEFORE adding reads: once the read set is large (64 M bases) the library
+ * brings the device up while reads are still being added -- runtime start, stream, a pinned result pool sized from
+ * the bases seen so far -- so that the first po_overlaps* call does not pay for it; after that a different device is
+ * refused (PO_ERR_INVALID). */
 po_status po_set_device(po_handle* h, int device);
 
 /* addSequence(id, seq)  -- src/overlapper.cpp:22-26.  Copies id and seq (the caller may

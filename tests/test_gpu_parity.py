@@ -769,6 +769,20 @@ def test_sharded_upload_pieces_assemble_to_the_same_read_set(nshards, monkeypatc
         _last.update(seqs=seqs, m=m)
         same(oo.sort_rows(oo.struct_to_rows(ov.overlaps_result(m).rows())), want, "%s, %d pieces" % (name, nshards))
         assert ov.stats()["paired"] == 1 and ov.stats()["upload_bytes"] < 8 * (sizes[0][1] + slot) + 16 * len(seqs) + 4096
+        # the same in parts (the H2D of part k + 1 runs under the all-gather of part k): gathered layout [part][shard][slot]
+        for parts in (2, 5):
+            psz = [[ov.upload_piece_part(k, nshards, q, parts) for q in range(parts)] for k in range(nshards)]
+            assert all(sum(n for _, n in row) == sizes[k][1] for k, row in enumerate(psz))    # the parts tile the piece
+            pslot = max(n for row in psz for _, n in row) + 1
+            pbuf = torch.full((parts * nshards * pslot,), -1, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            ov.invalidate()
+            for q in range(parts):
+                for k in range(nshards):
+                    ok, n = ov.upload_piece_part(k, nshards, q, parts, pbuf.data_ptr() + 8 * (q * nshards + k) * pslot, pslot)
+                    assert ok and n == psz[k][q][1]
+            ov.upload_assemble(pbuf.data_ptr(), pslot, nshards, parts)
+            same(oo.sort_rows(oo.struct_to_rows(ov.overlaps_result(m).rows())), want, "%s, %d pieces x %d parts" % (name, nshards, parts))
         ov.close()
     # reads that are not strand pairs: no sharded upload
     ov = ExactOverlapper(device=0)
