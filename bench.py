@@ -622,6 +622,7 @@ def main() -> int:
                            "pcie_floor_duplex_ms": max(h2d_bytes, d2h_bytes) / 64e9 * 1e3,
                            "streamed": bool(pcie.get("streamed_steps")),
                            "deferred_containments": int(incl_last.get("n_deferred", 0)),
+                           "predicted_pieces": int(incl_last.get("n_predicted", 0)), "fused_tails": int(incl_last.get("fused_tail", 0)),
                            "note": ("streamed step: the packed reads go up piece by piece (h2d_ms = first copy starts -> last piece landed, device events) "
                                     "while the pieces that have arrived are scanned, verified and emitted and their rows travel home -- PCIe carries both "
                                     "directions at once, so kernels_plus_d2h_ms overlaps h2d_ms and the two do not add up to ms_per_step. "

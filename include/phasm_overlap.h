@@ -98,6 +98,8 @@ typedef struct {
     uint32_t fused_tail;         /* chunks / pieces of the call whose select + row offsets + emission ran as ONE kernel   */
     uint32_t tail_fallback;      /*    (k_tail: needs a kept row buffer that holds the worst case); tail_fallback = how   */
                                  /*    often that kernel met tandem-repeat reads and the classic kernels ran instead      */
+    uint32_t n_predicted;        /* streamed step: pieces whose candidate count was predicted from the previous call on   */
+    uint32_t reserved0;          /*    the same reads (no host round trip between the counting pass and the rest)         */
 } po_stats;
 
 /* ExactOverlapper()  -- src/overlapper.cpp:19, py::init at src/phasm.cpp:13. */

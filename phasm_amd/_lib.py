@@ -64,6 +64,7 @@ class PoStats(ctypes.Structure):
         ("dp_lanes", ctypes.c_uint32), ("upload_bytes", ctypes.c_uint64),
         ("streamed", ctypes.c_uint32), ("n_deferred", ctypes.c_uint32),
         ("fused_tail", ctypes.c_uint32), ("tail_fallback", ctypes.c_uint32),
+        ("n_predicted", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
     ]
 
     def as_dict(self) -> dict:

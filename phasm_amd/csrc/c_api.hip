@@ -311,6 +311,7 @@ po_status ensure(po_handle* h, DevBuf& b, size_t bytes, double scale = 1.0) {
     b.release();
     size_t want = bytes + bytes / 8 + 256;
     if (scale > 1.0) want = (size_t)((double)bytes * scale) + 256;   // (a streamed piece: room for the largest piece)
+    if (h && h->st_on) want += 8192;   // (... and for the next call's predicted count plus its slack, small inputs included)
     constexpr size_t ARENA_CHUNK = 64u << 20, ARENA_MAX = 8u << 20;
     if (h && first && want <= ARENA_MAX && !getenv("PHASM_NO_ARENA")) {
         // (only a buffer's FIRST allocation: one that has to grow moves out, so a chunk never fills up with dead pieces)
@@ -1278,7 +1279,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     bool async_count = false;
     if (streamed && h->st_harvest && h->st_pred_valid && !dp && !want_cands && !getenv("PHASM_SYNC_COUNT")) {
         uint64_t pred = h->st_pred_cand[shard];
-        uint64_t cap = pred + pred / 50 + 1024;
+        uint64_t cap = pred + pred / 50 + 256;
         if (const char* e = getenv("PHASM_PRED_SCALE")) cap = pred = (uint64_t)((double)pred * atof(e));   // (tests: a prediction that is too small)
         const uint64_t worst = cap * 4u;
         bool order = pred >= 400000 && (r_end - r_begin) >= 4096;
@@ -1310,6 +1311,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         // (sizes and grids below are for cap_c candidates; the kernels read the real number from scalars[0])
         n_cand64 = cap_c;
         n_selfrep_reads = 0;
+        S.n_predicted = 1;
         G.n_dev = scalars;
         G.cap = cap_c;
     } else {
@@ -1623,7 +1625,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             if (!rows_late) {
                 // (room for the worst case up to 2 GiB, so that the next call of this size need not ask)
                 const size_t exact = n_rows64 * sizeof(po_row);
-                const size_t roomy = worst_rows * sizeof(po_row) <= (2ull << 30) ? (size_t)(worst_rows * sizeof(po_row)) : 0;
+                size_t roomy = worst_rows * sizeof(po_row) <= (2ull << 30) ? (size_t)(worst_rows * sizeof(po_row)) : 0;
+                if (roomy && streamed) roomy += 4096 * sizeof(po_row);   // (room for the next call's predicted count and its slack)
                 PO_TRY(ensure(h, res->d_rows, std::max<size_t>(std::max(exact, roomy), 256)));
             }
             if (dpE)
@@ -2669,6 +2672,7 @@ void add_stats(po_stats& sum, const po_stats& S) {
     sum.shard_bases += S.shard_bases;
     sum.fused_tail += S.fused_tail;
     sum.tail_fallback += S.tail_fallback;
+    sum.n_predicted += S.n_predicted;
     sum.ms_index += S.ms_index;
     sum.ms_scan_count += S.ms_scan_count;
     sum.ms_scan_fill += S.ms_scan_fill;
@@ -3091,6 +3095,7 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
     S.ms_scan_probe = sum.ms_scan_probe;
     S.ms_verify_kernel = sum.ms_verify_kernel;
     S.fused_tail = sum.fused_tail;
+    S.n_predicted = sum.n_predicted;
     S.tail_fallback = sum.tail_fallback + (h->st_tail_gave_up ? 1u : 0u);
     h->st_tail_gave_up = false;
     S.streamed = streamed ? 1u : 0u;

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_row_struct_is_24_bytes():
     assert _lib.ROW_DTYPE.itemsize == 24
-    assert ctypes.sizeof(_lib.PoStats) == 4 * 4 + 10 * 8 + 10 * 4 + 16 + 24 + 8 + 8 + 8
+    assert ctypes.sizeof(_lib.PoStats) == 4 * 4 + 10 * 8 + 10 * 4 + 16 + 24 + 8 + 8 + 8 + 8
 
 
 def test_host_side_store_and_shard_ranges():

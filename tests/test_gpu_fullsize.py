@@ -145,6 +145,13 @@ def test_full_size_large_configs(cfg_name, expect_rows):
     got = signature(oo.struct_to_rows(res.rows_view()))
     res.free()
     assert st2["streamed"] == 1 and st2["wide_index"] == 1 and got == sig == expected(cfg_name)[0]
+    # ... and once more on the same reads: pieces small enough for it run on their predicted candidate counts
+    ov.invalidate()
+    res = ov.overlaps_to_host_result(M)
+    st3 = ov.stats()
+    got3 = signature(oo.struct_to_rows(res.rows_view()))
+    res.free()
+    assert st3["streamed"] == 1 and got3 == sig, st3
     ov.close()
 
 
@@ -308,4 +315,14 @@ def test_full_size_streamed_step_equals_the_resident_call(cfg_name, monkeypatch)
         assert st2["streamed"] == 1 and st2["paired"] == 1 and st2["n_rows"] == sig[0]
         # (candidate counts differ a little: a K-mer hit that does not verify has no counterpart on the mirror side)
         assert got == sig, "streamed step, cuts %r" % cuts
+        # the same call again: every piece now runs on its PREDICTED candidate count (no host round trip) and ends in
+        # the two-kernel tail -- the same multiset
+        ov.invalidate()
+        res = ov.overlaps_to_host_result(M)
+        st3 = ov.stats()
+        got3 = signature(oo.struct_to_rows(res.rows_view()))
+        res.free()
+        assert st3["streamed"] == 1 and got3 == sig, "streamed step with predicted counts, cuts %r" % cuts
+        if cfg_name == "cfg2" and cuts == "":     # (pieces of fewer than 400 k candidates keep the host round trip)
+            assert st3["n_predicted"] >= 6 and st3["fused_tail"] >= 6, st3
     ov.close()

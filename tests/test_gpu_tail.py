@@ -123,5 +123,57 @@ def test_streamed_pieces_with_a_predicted_candidate_count(scale, monkeypatch):
                 assert st["streamed"] == 0 and st["tail_fallback"] >= 1, (name, st)
             else:
                 assert st["streamed"] == 1, (name, call_no, st)
+                # (call 0 has nothing to predict from; the call after an abandoned step neither)
+                assert (st["n_predicted"] > 0) == (call_no in ((1, 2, 3) if not scale else (1,))), (name, call_no, st)
             assert st["n_candidates"] > 0 and st["n_rows"] == len(want)
         ov.close()
+
+
+def test_predicted_pieces_fuzz(monkeypatch):
+    """Several streamed calls per handle with the cuts, min_length and the read set changing in between: a prediction
+    must be used only for the same reads, cuts and min_length, and a wrong one must never show in the rows."""
+    import os
+    monkeypatch.setenv("PHASM_STREAM", "1")
+    monkeypatch.setenv("PHASM_VERIFY_ORDER", "1")
+    rng = np.random.default_rng(20260)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    n_pred = 0
+    for trial in range(int(os.environ.get("PHASM_SOAK_TRIALS", "8"))):
+        glen = int(rng.integers(800, 5000))
+        genome = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=glen))
+        seqs = []
+        for _ in range(int(rng.integers(8, 70))):
+            ln = int(rng.integers(40, max(60, glen // 3)))
+            s = int(rng.integers(0, glen - ln))
+            r = genome[s:s + ln]
+            seqs += [r, r.translate(comp)[::-1]]
+        ov = ExactOverlapper()
+        for i, s in enumerate(seqs):
+            ov.add_sequence("r%d" % i, s)
+        m = int(rng.choice([33, 40, 70]))
+        cuts = "300,600"
+        for call in range(6):
+            what = int(rng.integers(0, 5))
+            if what == 0:
+                cuts = ",".join(str(c) for c in sorted(set(int(c) for c in rng.integers(50, 950, size=int(rng.integers(1, 6))))))
+            elif what == 1:
+                m = int(rng.choice([33, 40, 70]))
+            elif what == 2:       # the read set grows: the old counts are too small for the pieces they belonged to
+                for _ in range(int(rng.integers(1, 12))):
+                    ln = int(rng.integers(40, max(60, glen // 3)))
+                    s = int(rng.integers(0, glen - ln))
+                    r = genome[s:s + ln]
+                    for x in (r, r.translate(comp)[::-1]):
+                        ov.add_sequence("r%d" % len(seqs), x)
+                        seqs.append(x)
+            monkeypatch.setenv("PHASM_STREAM_CUTS", cuts)
+            if what == 3:
+                monkeypatch.setenv("PHASM_PRED_SCALE", "0.5")
+            else:
+                monkeypatch.delenv("PHASM_PRED_SCALE", raising=False)
+            got = oo.sort_rows(oo.struct_to_rows(to_host(ov, m)))
+            st = ov.stats()
+            n_pred += st["n_predicted"]
+            ck.assert_same_rows(got, ck.oracle_overlaps(seqs, m), seqs, m, "trial %d call %d (%d, cuts %s, m %d)" % (trial, call, what, cuts, m))
+        ov.close()
+    assert n_pred > 10
