@@ -2723,11 +2723,14 @@ bool stream_eligible(const po_handle* h, uint32_t min_length) {
 // pieces are made small, their rows are what is left to send home after the upload has ended.
 std::vector<uint32_t> stream_bounds(const po_handle* h) {
     const uint32_t n = (uint32_t)h->len.size();
-    // one piece per ~16 MB, 2 to 8 of them, cut at 1 - (1 - i/P)^1.25: 154/302/444/580/707/823/926 thousandths at P = 8
+    // one piece per ~16 MB, 2 to 12 of them (8 until a piece's fixed device cost fell in round 3: config 2 5.18 -> 5.11 ms,
+    // config 3 19.6 -> 19.0), cut at 1 - (1 - i/P)^1.25: 154/302/444/580/707/823/926 thousandths at P = 8
     // (config 2, 190 MB: 5.3 ms per step; 5 to 10 pieces measure within 3 % of it.  Config 2 scaled to 12 k reads, 45 MB:
     // 8 pieces 2.24 ms, 3 pieces 1.83, none 2.38; to 6 k reads, 22 MB: 8 pieces 1.74, 2 pieces 1.15, none 1.52)
     const uint64_t bytes0 = (uint64_t)h->words[0].size() * 8;
-    const uint32_t n_pieces = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(2, (bytes0 + (8ull << 20)) / (16ull << 20)));
+    uint64_t max_pieces = 12;
+    if (const char* e = getenv("PHASM_STREAM_MAX_PIECES")) max_pieces = (uint64_t)std::max(2, std::min(PO_MAX_PIECES - 1, atoi(e)));
+    const uint32_t n_pieces = (uint32_t)std::min<uint64_t>(max_pieces, std::max<uint64_t>(2, (bytes0 + (8ull << 20)) / (16ull << 20)));
     std::vector<uint32_t> cuts;
     for (uint32_t i = 1; i < n_pieces; ++i) cuts.push_back((uint32_t)(1000.0 * (1.0 - std::pow(1.0 - (double)i / n_pieces, 1.25))));
     if (const char* e = getenv("PHASM_STREAM_CUTS")) {
