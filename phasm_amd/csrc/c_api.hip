@@ -187,7 +187,9 @@ struct po_handle {
     hipEvent_t ev_rc[PO_MAX_PIECES] = {};
     hipEvent_t ev_meta = nullptr;
     hipEvent_t ev_first = nullptr;   // the first words of the later pieces are in place
-    HostBuf first_host;            // first packed word of every read (pinned), valid for first_n reads
+    // first two packed words of every read, appended as the reads are added (registered memory: the streamed step sends
+    // them ahead of the pieces straight from here); first_n = reads it covers (a bulk ingest fills it in afterwards)
+    WordStore first_words;
     uint32_t first_n = 0;
     // per-read metadata of the upload, kept page-locked while the read set is unchanged (reads are only ever appended):
     // [woff x n | len x n | first tile x (n + 1)]; meta_n = reads it covers, meta_bits = encoding it was counted for
@@ -438,6 +440,16 @@ po_status init_device(po_handle* h) {
     HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->pinned), 1024, hipHostMallocDefault));   // 128 slots
     HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pinned_dev), h->pinned, 0));
     if (const char* e = getenv("PHASM_POISON")) h->poison = (int)(strtol(e, nullptr, 0) & 0xFF);
+    // the streams and events of the host-to-host call: created here (a few tenths of a millisecond each), not in its first call
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->rc_stream, hipStreamNonBlocking));
+    for (int k = 0; k < PO_MAX_PIECES; ++k) {
+        HIP_TRY(h, hipEventCreate(&h->ev_piece[k]));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_rc[k], hipEventDisableTiming));
+    }
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_first, hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_meta, hipEventDisableTiming));
     // the library's code object is loaded by the first launch out of it (15 ms in a fresh process): here, not in a call
     hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->stream, reinterpret_cast<uint32_t*>(h->pinned_dev + 63), (uint64_t)1, 0u);
     (void)hipGetLastError();
@@ -541,6 +553,8 @@ void widen_to_bytes(po_handle* h) {
     h->bits = 8;
     h->all_pairs_rc = false;
     h->all_pairs_rcx = false;
+    h->first_n = 0;
+    h->first_words.clear();
     h->exc_off.assign(1, 0);
     h->exc_pos.clear();
     h->exc_byte.clear();
@@ -618,6 +632,26 @@ bool packed_is_revcomp(const po_handle* h, size_t r) {
 }
 
 inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// first_words covers every read: the first two packed words of read r (a read owns its data words and a zero guard
+// word; the word behind an EMPTY read is alignment padding, or -- for the last read of a store -- not part of the host
+// store at all: zero on the device either way)
+void note_first_words(po_handle* h) {
+    const uint32_t n = (uint32_t)h->len.size();
+    if (h->first_n == n && h->first_words.size() == 2 * (size_t)n) return;
+    if (h->first_n > n || h->first_words.size() != 2 * (size_t)h->first_n) {
+        h->first_n = 0;
+        h->first_words.clear();
+    }
+    if (n - h->first_n > 1) h->first_words.reserve(2 * (size_t)n);   // (a bulk fill; one read at a time grows geometrically)
+    for (uint32_t r = h->first_n; r < n; ++r) {
+        const WordStore& store = h->words[r & 1];
+        const uint64_t o = h->woff[r];
+        h->first_words.push_back(o < store.size() ? store[o] : 0);
+        h->first_words.push_back(o + 1 < store.size() ? store[o + 1] : 0);
+    }
+    h->first_n = n;
+}
 
 // reads that can take part in an overlap of m bases or more
 uint64_t count_eligible(po_handle* h, uint32_t m) {
@@ -2270,7 +2304,6 @@ void po_destroy(po_handle* h) {
         for (DevBuf& b : h->chunk_rows) b.release();
         h->d_first.release();
         h->d_defer.release();
-        h->first_host.release();
         h->meta_host.release();
         for (void* c : h->arena_chunks) (void)hipFree(c);
         h->arena_chunks.clear();
@@ -2323,6 +2356,7 @@ po_status po_add_sequence(po_handle* h, const char* id, size_t id_len, const cha
         h->dirty = true;
         h->ids_paired = -1;
         if (h->total_bases >= h->pool_bases && h->total_bases >= (64ull << 20)) result_pool_grow(h);
+        if (h->bits == 2 && h->first_n + 1 == h->len.size()) note_first_words(h);   // (O(1): this read's two words)
         if (h->bits == 2 && (h->len.size() & 1) == 0) {
             const size_t r = h->len.size() - 1;
             if (!h->exc_pos.empty()) host_pair_check(h, r, s);
@@ -2373,6 +2407,7 @@ po_status po_add_fasta(po_handle* h, const char* path, int both_strands, uint64_
         ::close(fd);
         if (done) {
             if (h->total_bases >= h->pool_bases && h->total_bases >= (64ull << 20)) result_pool_grow(h);
+            if (h->bits == 2) note_first_words(h);
             return PO_OK;
         }
     }
@@ -2728,7 +2763,9 @@ std::vector<uint32_t> stream_bounds(const po_handle* h) {
     // (config 2, 190 MB: 5.3 ms per step; 5 to 10 pieces measure within 3 % of it.  Config 2 scaled to 12 k reads, 45 MB:
     // 8 pieces 2.24 ms, 3 pieces 1.83, none 2.38; to 6 k reads, 22 MB: 8 pieces 1.74, 2 pieces 1.15, none 1.52)
     const uint64_t bytes0 = (uint64_t)h->words[0].size() * 8;
-    uint64_t max_pieces = 12;
+    // (the FIRST streamed call on a handle has no kept row buffers yet: every piece then costs two host round trips, and
+    // eight pieces are the better cut -- 7.9 against 10.5 ms for the cold call at config 2)
+    uint64_t max_pieces = h->chunk_rows[0].p ? 12 : 8;
     if (const char* e = getenv("PHASM_STREAM_MAX_PIECES")) max_pieces = (uint64_t)std::max(2, std::min(PO_MAX_PIECES - 1, atoi(e)));
     const uint32_t n_pieces = (uint32_t)std::min<uint64_t>(max_pieces, std::max<uint64_t>(2, (bytes0 + (8ull << 20)) / (16ull << 20)));
     std::vector<uint32_t> cuts;
@@ -2791,22 +2828,10 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
         // first words of the reads of the later pieces (both strands: the host packed the odd store too, it just does
         // not travel), put in place on the handle's stream while piece 0 is crossing; the later pieces' copies are
         // ordered behind that kernel -- they bring the same values, but two writers of one word want an order
-        if (h->first_n != n || !h->first_host.p) {
-            PO_TRY(ensure_host(h, h->first_host, (size_t)n * 16));
-            uint64_t* f = static_cast<uint64_t*>(h->first_host.p);
-            for (uint32_t r = 0; r < n; ++r) {
-                // (a read owns its data words and a zero guard word; the word behind an EMPTY read is alignment padding,
-                // or -- for the last read of a store -- not part of the host store at all: zero on the device either way)
-                const WordStore& store = h->words[r & 1];
-                const uint64_t o = h->woff[r];
-                f[2 * (size_t)r] = store[o];
-                f[2 * (size_t)r + 1] = o + 1 < store.size() ? store[o + 1] : 0;
-            }
-            h->first_n = n;
-        }
+        note_first_words(h);   // (nothing to do when po_add_sequence kept them up to date)
         const uint32_t r0 = bounds[1];
         PO_TRY(ensure(h, h->d_first, (size_t)n * 16));
-        HIP_TRY(h, hipMemcpyAsync(h->d_first.as<uint64_t>() + 2 * (size_t)r0, static_cast<uint64_t*>(h->first_host.p) + 2 * (size_t)r0,
+        HIP_TRY(h, hipMemcpyAsync(h->d_first.as<uint64_t>() + 2 * (size_t)r0, h->first_words.data() + 2 * (size_t)r0,
                                   (size_t)(n - r0) * 16, hipMemcpyHostToDevice, h->stream));
         h->upload_bytes += (size_t)(n - r0) * 16;
         hipLaunchKernelGGL(po::k_scatter_first, dim3(cdiv(n - r0, 256)), dim3(256), 0, h->stream, dw, h->d_woff.as<uint64_t>(),
