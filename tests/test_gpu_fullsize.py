@@ -323,6 +323,15 @@ def test_full_size_streamed_step_equals_the_resident_call(cfg_name, monkeypatch)
         got3 = signature(oo.struct_to_rows(res.rows_view()))
         res.free()
         assert st3["streamed"] == 1 and got3 == sig, "streamed step with predicted counts, cuts %r" % cuts
-        if cfg_name == "cfg2" and cuts == "":     # (pieces of fewer than 400 k candidates keep the host round trip)
-            assert st3["n_predicted"] >= 6 and st3["fused_tail"] >= 6, st3
+        if cuts == "":
+            # (the default schedule has 8 pieces on a handle's first streamed call and up to 12 from then on: the call
+            # after the change of schedule has nothing to predict from, the one after that does)
+            ov.invalidate()
+            res = ov.overlaps_to_host_result(M)
+            st4 = ov.stats()
+            got4 = signature(oo.struct_to_rows(res.rows_view()))
+            res.free()
+            assert st4["streamed"] == 1 and got4 == sig
+            if cfg_name == "cfg2":     # (pieces of fewer than 400 k candidates keep the host round trip)
+                assert st4["n_predicted"] >= 6 and st4["fused_tail"] >= 6, st4
     ov.close()
