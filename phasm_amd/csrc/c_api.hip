@@ -217,7 +217,9 @@ struct po_handle {
     uint64_t st_pred_cand[PO_MAX_PIECES] = {};
     std::vector<uint32_t> st_pred_sig;
     bool st_pred_valid = false;
+    bool st_early_index = false;   // this streamed step builds its index before piece 0 has landed
     bool st_tail_gave_up = false;  // the last streamed step was abandoned because of tandem-repeat reads (statistics / tests)
+    bool idx_only = false;         // run_overlaps stops behind the index build (the streamed step builds it ahead of piece 0)
     bool st_on = false;            // run_overlaps works on piece [st_r_begin, st_r_end) of a streamed step
     uint32_t st_r_begin = 0, st_r_end = 0, st_defer_cap = 0;
     uint64_t last_host_rows = 0;   // rows of the previous po_overlaps_to_host call (sizes the pinned buffer up front)
@@ -1187,6 +1189,17 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     }
     if (ext_idx) {
         WA_ext = true;
+    }
+    if (h->idx_only) {
+        // (streamed step: the index is built from the first words of every read while piece 0 is still on the wire; the
+        // pieces find it valid -- same upload, min_length, flavour -- and reuse it)
+        h->idx_valid = true;
+        h->idx_gen = h->upload_gen;
+        h->idx_m = m;
+        h->idx_wide = wide;
+        h->idx_tbits = tbits;
+        h->idx_bits = (uint32_t)BITS;
+        return PO_OK;
     }
     h->idx_valid = !ext_idx;
     h->idx_gen = h->upload_gen;
@@ -2829,7 +2842,10 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
         // not travel), put in place on the handle's stream while piece 0 is crossing; the later pieces' copies are
         // ordered behind that kernel -- they bring the same values, but two writers of one word want an order
         note_first_words(h);   // (nothing to do when po_add_sequence kept them up to date)
-        const uint32_t r0 = bounds[1];
+        // With the index built ahead of piece 0 (overlaps_streamed) the first words of piece 0's reads go up too: the index
+        // build behind this kernel is then their only reader before the piece itself has landed, and the piece brings
+        // the same values.
+        const uint32_t r0 = h->st_early_index ? 0u : bounds[1];
         PO_TRY(ensure(h, h->d_first, (size_t)n * 16));
         HIP_TRY(h, hipMemcpyAsync(h->d_first.as<uint64_t>() + 2 * (size_t)r0, h->first_words.data() + 2 * (size_t)r0,
                                   (size_t)(n - r0) * 16, hipMemcpyHostToDevice, h->stream));
@@ -2888,8 +2904,30 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
     sig.push_back((uint32_t)(h->total_bases & 0xFFFFFFFFu));
     h->st_pred_valid = h->st_pred_valid && sig == h->st_pred_sig;
     uint64_t new_pred[PO_MAX_PIECES] = {};
+    // the index ahead of piece 0: it needs every read's first word(s) only, and at 400 k reads (wide index, 2.9 ms; 16 ms at
+    // 2 M reads) building it inside piece 0 -- after the piece has landed -- kept every later piece 2-3 ms behind its data
+    h->st_early_index = P > 1 && h->poison < 0 && !getenv("PHASM_NO_INDEX_REUSE") && !getenv("PHASM_LATE_INDEX");
     PO_TRY(stream_begin(h, bounds));
     if (trace) std::fprintf(stderr, "[stream] %u pieces queued at %.3f ms\n", P, since());
+    if (h->st_early_index) {
+        po_result part;
+        part.h = h;
+        h->st_on = true;
+        h->st_r_begin = bounds[0];
+        h->st_r_end = bounds[1];
+        h->idx_only = true;
+        const po_status ist = run_overlaps<2>(h, min_length, 0, P, false, &part);
+        h->idx_only = false;
+        h->st_on = false;
+        part.d_rows.release();
+        if (ist != PO_OK) {
+            (void)hipStreamSynchronize(h->stream);
+            (void)hipStreamSynchronize(h->up_stream);
+            (void)hipStreamSynchronize(h->rc_stream);
+            h->dirty = true;
+            return ist;
+        }
+    }
     uint64_t* dw = h->d_words.as<uint64_t>();
     po_status st = PO_OK;
     // a finished piece: statistics, rows queued for home.  Called by run_overlaps at the next piece's first host wait
