@@ -120,6 +120,7 @@ struct po_handle {
     int bits = 2;
     std::vector<std::string> ids;
     std::vector<uint32_t> len;
+    std::vector<uint64_t> cum_len;   // running sum of len (shard_range), extended as reads are added
     // Packed reads live in TWO host stores: words[0] holds the reads with an even index, words[1] those with an odd
     // index, woff[r] is read r's first word inside ITS store.  `phasm overlap` adds every read as (x, revcomp x):
     // when every odd read is exactly the reverse complement of its even partner (all_pairs_rc, checked word by word
@@ -865,8 +866,15 @@ po_status upload(po_handle* h) {
 // a-side shard: contiguous read ranges balanced by bases
 void shard_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint32_t* r_begin, uint32_t* r_end, uint64_t* bases) {
     const uint32_t n = (uint32_t)h->len.size();
-    std::vector<uint64_t> cum((size_t)n + 1, 0);
-    for (uint32_t r = 0; r < n; ++r) cum[r + 1] = cum[r] + h->len[r];
+    // (the running sum of the read lengths is kept on the handle: a step of an N-rank job asks for dozens of shard and
+    // piece ranges, and 100 k additions each time were milliseconds of host time per step)
+    std::vector<uint64_t>& cum = const_cast<po_handle*>(h)->cum_len;
+    if (cum.size() != (size_t)n + 1) {
+        size_t have = cum.empty() ? 0 : std::min(cum.size() - 1, (size_t)n);   // (reads are only ever appended)
+        cum.resize((size_t)n + 1);
+        if (have == 0) cum[0] = 0;
+        for (size_t r = have; r < n; ++r) cum[r + 1] = cum[r] + h->len[r];
+    }
     auto cut = [&](uint32_t s) -> uint32_t {
         if (s == 0) return 0;
         if (s >= nshards) return n;

@@ -124,6 +124,7 @@ class ReadExchange:
         self.gathered = None
         self.n_collectives = 0
         self.n_parts = 1
+        self._plan = None      # ((reads, parts asked for), parts, slot words) of the current read set
 
     def upload(self, parts: Optional[int] = None) -> bool:
         """True: sharded upload done.  False: plain ``po_upload`` was used.
@@ -134,16 +135,25 @@ class ReadExchange:
         if not self.on or self.ws < 2:
             self.ov.upload()
             return False
-        sizes = [self.ov.upload_piece(k, self.ws) for k in range(self.ws)]
-        if not all(ok for ok, _ in sizes):
+        key = (len(self.ov), parts)
+        if self._plan is None or self._plan[0] != key:
+            # (once per state of the read set: every rank computes every piece's length from its own read table)
+            sizes = [self.ov.upload_piece(k, self.ws) for k in range(self.ws)]
+            if not all(ok for ok, _ in sizes):
+                self._plan = (key, None, 0)
+            else:
+                longest = max(n for _, n in sizes)
+                np_ = parts
+                if np_ is None:
+                    np_ = int(os.environ.get("PHASM_UPLOAD_PARTS", "0")) or max(1, min(4, (longest * 8) >> 23))
+                np_ = max(1, min(int(np_), 64))
+                # equal slots: the longest part of any shard
+                slot = max(self.ov.upload_piece_part(k, self.ws, p, np_)[1] for k in range(self.ws) for p in range(np_)) + 1
+                self._plan = (key, np_, slot)
+        _, parts, slot = self._plan
+        if parts is None:
             self.ov.upload()
             return False
-        longest = max(n for _, n in sizes)
-        if parts is None:
-            parts = int(os.environ.get("PHASM_UPLOAD_PARTS", "0")) or max(1, min(4, (longest * 8) >> 23))
-        parts = max(1, min(int(parts), 64))
-        # equal slots: the longest part of any shard (every rank computes every part's length from its own read table)
-        slot = max(self.ov.upload_piece_part(k, self.ws, p, parts)[1] for k in range(self.ws) for p in range(parts)) + 1
         if self.local is None or self.local.shape != (parts, slot):
             self.local = torch.empty((parts, slot), dtype=torch.int64, device=self.device)
             self.gathered = torch.empty((parts, self.ws * slot), dtype=torch.int64, device=self.device)
