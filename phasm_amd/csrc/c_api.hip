@@ -57,6 +57,13 @@ struct HostBuf {
     }
 };
 
+// Stage-boundary timing events (po_stats.ms_index .. ms_emit).  A recorded event is a marker the command processor has to
+// retire between two kernels (~5 us each, measured): a whole-set call records all of them, the pieces of a streamed step only
+// the pairs around the two big kernels (ms_scan_probe, ms_verify_kernel) unless PHASM_PHASE_EVENTS=1 / PHASM_STREAM_TRACE ask.
+inline int phase_events_env() {
+    const int v = getenv("PHASM_PHASE_EVENTS") ? (atoi(getenv("PHASM_PHASE_EVENTS")) != 0 ? 1 : 0) : (getenv("PHASM_STREAM_TRACE") ? 1 : -1);
+    return v;
+}
 enum { EV_START = 0, EV_INDEX, EV_COUNT, EV_FILL, EV_VERIFY, EV_SELECT, EV_EMIT, EV_PROBE0, EV_PROBE1, EV_VER0, EV_VER1, EV_DONE, EV_N };
 
 }  // namespace
@@ -208,6 +215,7 @@ struct po_handle {
         uint32_t k = 0;
         po_stats S = {};
         bool ver_timed = false;
+        bool full_events = true;
         bool tail = false;         // the piece's tail ran as k_tail: counts in pinned[zone..], fallback flag in pinned[zone + 7]
         int zone = 48;
         uint32_t cap_c = 0;        // > 0: the candidate count was predicted (real count in pinned[zone + 8])
@@ -218,6 +226,7 @@ struct po_handle {
     uint64_t st_pred_cand[PO_MAX_PIECES] = {};
     std::vector<uint32_t> st_pred_sig;
     bool st_pred_valid = false;
+    bool phase_events = true;   // this call records the stage-boundary events (phase_events_env)
     bool st_early_index = false;   // this streamed step builds its index before piece 0 has landed
     bool st_tail_gave_up = false;  // the last streamed step was abandoned because of tandem-repeat reads (statistics / tests)
     bool idx_only = false;         // run_overlaps stops behind the index build (the streamed step builds it ahead of piece 0)
@@ -948,7 +957,15 @@ po_status prefix_sum_small(po_handle* h, uint32_t* in, const uint32_t* extra, ui
     return PO_OK;
 }
 
-void stage_times(po_stats& S, hipEvent_t* ev, bool ver_timed) {
+void stage_times(po_stats& S, hipEvent_t* ev, bool ver_timed, bool full) {
+    if (!full) {
+        S.ms_index = S.ms_scan_count = S.ms_scan_fill = S.ms_verify = S.ms_select = S.ms_emit = 0.f;
+        (void)hipEventElapsedTime(&S.ms_total, ev[EV_START], ev[EV_EMIT]);
+        (void)hipEventElapsedTime(&S.ms_scan_probe, ev[EV_PROBE0], ev[EV_PROBE1]);
+        S.ms_verify_kernel = 0.f;
+        if (ver_timed) (void)hipEventElapsedTime(&S.ms_verify_kernel, ev[EV_VER0], ev[EV_VER1]);
+        return;
+    }
     (void)hipEventElapsedTime(&S.ms_index, ev[EV_START], ev[EV_INDEX]);
     (void)hipEventElapsedTime(&S.ms_scan_count, ev[EV_INDEX], ev[EV_COUNT]);
     (void)hipEventElapsedTime(&S.ms_scan_fill, ev[EV_COUNT], ev[EV_FILL]);
@@ -979,7 +996,7 @@ uint64_t finish_piece(po_handle* h, bool* needs_classic) {
     P.S.sum_overlap_bases = h->pinned[c + 1];
     P.S.verify_bytes_algo = h->pinned[c + 2];
     P.S.verify_bytes_exec = h->pinned[c + 3];
-    stage_times(P.S, P.ev, P.ver_timed);
+    stage_times(P.S, P.ev, P.ver_timed, P.full_events);
     P.valid = false;
     return n_rows;
 }
@@ -1129,6 +1146,10 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     // call (overlapper.cpp:33-36) -- unless THIS handle built exactly this index for exactly this device copy of the
     // reads already (same upload, min_length, flavour, size): the chunks of po_overlaps_to_host and the shards of a
     // multi-GPU step then share one build instead of repeating it (the replicated part of a sharded step).
+    {
+        const int pe = phase_events_env();
+        h->phase_events = pe >= 0 ? pe == 1 : !streamed;
+    }
     HIP_TRY(h, hipEventRecord(h->ev[EV_START], st));
     const bool reuse_index = !slice_build && !ext_idx && h->idx_valid && h->idx_gen == h->upload_gen && h->idx_m == m &&
                              h->idx_wide == wide && h->idx_tbits == tbits && h->idx_bits == (uint32_t)BITS && h->poison < 0 &&
@@ -1186,13 +1207,13 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     // pass over all positions cost 2.2 ms at config 3 with the wide index, and more than the shard's own scan at 8
     // shards -- and settle duplicates inside each read's own candidate list instead (k_select_local, below).
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(h->ev[EV_INDEX], st));
+    if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_INDEX], st));
     if (slice_build) {
         // the sub-table and its chain segment are complete in the workspaces: po_index_slice_export copies them out
         HIP_TRY(h, hipStreamSynchronize(st));
         h->sl_tbits = tbits;
         h->sl_entries = h->pinned[0];   // (the prefix sum's total = chain entries of this sub-table)
-        (void)hipEventElapsedTime(&S.ms_index, h->ev[EV_START], h->ev[EV_INDEX]);
+        if (h->phase_events) (void)hipEventElapsedTime(&S.ms_index, h->ev[EV_START], h->ev[EV_INDEX]);
         return PO_OK;
     }
     if (ext_idx) {
@@ -1358,7 +1379,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                                     reinterpret_cast<const uint64_t*>(scalars + 2), also_slot,
                                     wide ? nullptr : A.tile_extra + tile_begin));
     }
-    HIP_TRY(h, hipEventRecord(h->ev[EV_COUNT], st));
+    if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_COUNT], st));
     po::CandGuard G = {nullptr, 0u};
     uint64_t n_cand64;
     uint32_t n_selfrep_reads;
@@ -1430,7 +1451,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                                r_end, h->d_defer.as<po::Cand>(), h->st_defer_cap, h->d_defer.as<uint32_t>() + (size_t)h->st_defer_cap * 4);
         }
         HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipEventRecord(h->ev[EV_FILL], st));
+        if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_FILL], st));
         // ---- verify
         if (dp) {
             // banded seed-extension DP, one wave per candidate (extend.hip.h); max_diff = 0 gives the packed compare's answer
@@ -1585,7 +1606,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                              sum[0] / sum[6], sum[1] / sum[6], sum[2] / sum[6], sum[3] / sum[6], sum[4] / sum[6], sum[5] / sum[6], sum[7] / sum[5], sum[6]);
         }
 #endif
-        HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
+        if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
         // ---- select + row offsets
         if (nshards > 1 || streamed || wide || dpE) {
             static_assert(po::SEL_CAP == 512, "k_select_local hashes to 9 bits");
@@ -1638,7 +1659,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         // trip less per step); the number arrives with the counters at the end.
         if (!want_cands) {
             PO_TRY(prefix_sum<uint8_t>(h, h->d_rowcnt.as<uint8_t>(), n_cand, h->d_row_off.as<uint32_t>(), &h->pinned[2]));
-            HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
+            if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
             rows_late = h->spare_rows.p && h->spare_rows.cap >= worst_rows * sizeof(po_row);
             if (!rows_late) {
                 HIP_TRY(h, hipStreamSynchronize(st));
@@ -1649,7 +1670,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         if (want_cands) {
             // ---- multi-GPU form: hand out the verified candidates (one per strand-mirror pair), compacted
             PO_TRY(prefix_sum<uint8_t>(h, h->d_flag.as<uint8_t>(), n_cand, h->d_row_off.as<uint32_t>(), &h->pinned[3]));
-            HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
+            if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
             HIP_TRY(h, hipStreamSynchronize(st));
             const uint64_t n_ver = h->pinned[3];
             po::Cand* dst;
@@ -1709,7 +1730,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             const uint32_t* tgate = n_selfrep_reads ? n_deferred : nullptr;
             hipLaunchKernelGGL(po::k_tile_rows, dim3(n_tt), dim3(po::TAIL_BLOCK), 0, st, A.cand_a, A.cand_b, h->d_type.as<uint8_t>(), n_cand,
                                paired, tgate, tile_rows, G);
-            HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
+            if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
             rows_late = true;
             used_tail = true;
             S.fused_tail = 1;
@@ -1737,9 +1758,9 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             return PO_OK;
         };
     } else {
-        HIP_TRY(h, hipEventRecord(h->ev[EV_FILL], st));
-        HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
-        HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
+        if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_FILL], st));
+        if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
+        if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
     }
     HIP_TRY(h, hipEventRecord(h->ev[EV_EMIT], st));
     uint64_t* counters = h->pinned + 4;
@@ -1761,6 +1782,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         h->st_pend.k = shard;
         h->st_pend.S = S;
         h->st_pend.ver_timed = ver_timed;
+        h->st_pend.full_events = h->phase_events;
         h->st_pend.ev = h->ev;
         res->count = 0;
         return PO_OK;
@@ -1790,7 +1812,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         S.dp_steps = h->pinned[32];
         S.dp_stopped = h->pinned[33];
     }
-    stage_times(S, h->ev, ver_timed);
+    stage_times(S, h->ev, ver_timed, h->phase_events);
     return PO_OK;
 }
 

@@ -59,7 +59,7 @@ def main():
         ms = (time.perf_counter() - t0) / args.steps * 1e3
         st = ov.stats()
         print("cuts %-60s %7.3f ms/step  rows %d  streamed %d  deferred %d  upload %.3f ms  kernels %.3f ms (scan %.3f verify %.3f)  predicted pieces %d  fused tails %d" % (
-            cuts, ms, n, st["streamed"], st["n_deferred"], st["ms_upload"], st["ms_total"], st["ms_scan_count"], st["ms_verify"],
+            cuts, ms, n, st["streamed"], st["n_deferred"], st["ms_upload"], st["ms_total"], st["ms_scan_probe"], st["ms_verify_kernel"],
             st["n_predicted"], st["fused_tail"]), flush=True)
         if args.trace and st["streamed"]:
             os.environ["PHASM_STREAM_TRACE"] = "1"
