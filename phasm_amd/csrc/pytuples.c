@@ -3,7 +3,9 @@
  * (/root/reference/src/phasm.cpp:15, pybind11/stl.h casters).  This is the same conversion for the 24-byte row array of
  * include/phasm_overlap.h: one tuple per row, the id strings shared (not copied) from the caller's list.
  * Loaded with ctypes.PyDLL (the GIL is held); no link-time dependency on libpython -- the symbols come from the running
- * interpreter.  7 M rows: 0.4 s against 1.45 s for the zip-of-lists form in Python. */
+ * interpreter.  Coordinates below 2^16 (every read of up to 65 kb) come from a table of shared int objects filled on first
+ * use -- ints are immutable, a shared one is indistinguishable from a fresh one -- which saves four allocations per row and
+ * 0.8 GB of int objects for 7 M rows.  7 M rows: 0.3 s against 1.45 s for the zip-of-lists form in Python. */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
@@ -12,6 +14,23 @@ typedef struct {
     uint32_t a_idx, b_idx;
     int32_t astart, aend, bstart, bend;
 } po_row;
+
+#define INT_CACHE 65536
+static PyObject* int_cache[INT_CACHE];   /* (references kept for the life of the process, like CPython's own small ints) */
+
+static inline PyObject* shared_int(int32_t v) {
+    if (v >= 0 && v < INT_CACHE) {
+        PyObject* c = int_cache[v];
+        if (!c) {
+            c = PyLong_FromLong(v);
+            if (!c) return NULL;
+            int_cache[v] = c;
+        }
+        Py_INCREF(c);
+        return c;
+    }
+    return PyLong_FromLong(v);
+}
 
 PyObject* po_rows_to_tuples(const void* rows_ptr, uint64_t n, PyObject* ids) {
     const po_row* rows = (const po_row*)rows_ptr;
@@ -22,7 +41,6 @@ PyObject* po_rows_to_tuples(const void* rows_ptr, uint64_t n, PyObject* ids) {
     const Py_ssize_t n_ids = PyList_GET_SIZE(ids);
     PyObject* out = PyList_New((Py_ssize_t)n);
     if (!out) return NULL;
-    PyObject* zero = PyLong_FromLong(0);
     /* millions of fresh containers in a row: the cyclic collector would walk them over and over (none is garbage) */
     const int gc_was_on = PyGC_Disable();
     for (uint64_t i = 0; i < n; ++i) {
@@ -31,14 +49,12 @@ PyObject* po_rows_to_tuples(const void* rows_ptr, uint64_t n, PyObject* ids) {
             PyErr_SetString(PyExc_IndexError, "row names a read the handle does not hold");
             if (gc_was_on) PyGC_Enable();
             Py_DECREF(out);
-            Py_XDECREF(zero);
             return NULL;
         }
         PyObject* t = PyTuple_New(6);
         if (!t) {
             if (gc_was_on) PyGC_Enable();
             Py_DECREF(out);
-            Py_XDECREF(zero);
             return NULL;
         }
         PyObject* a = PyList_GET_ITEM(ids, (Py_ssize_t)r->a_idx);
@@ -47,18 +63,26 @@ PyObject* po_rows_to_tuples(const void* rows_ptr, uint64_t n, PyObject* ids) {
         Py_INCREF(b);
         PyTuple_SET_ITEM(t, 0, a);
         PyTuple_SET_ITEM(t, 1, b);
-        PyTuple_SET_ITEM(t, 2, PyLong_FromLong(r->astart));
-        PyTuple_SET_ITEM(t, 3, PyLong_FromLong(r->aend));
-        if (r->bstart == 0) {
-            Py_INCREF(zero);
-            PyTuple_SET_ITEM(t, 4, zero);
-        } else {
-            PyTuple_SET_ITEM(t, 4, PyLong_FromLong(r->bstart));
+        PyObject* v2 = shared_int(r->astart);
+        PyObject* v3 = shared_int(r->aend);
+        PyObject* v4 = shared_int(r->bstart);
+        PyObject* v5 = shared_int(r->bend);
+        if (!v2 || !v3 || !v4 || !v5) {
+            Py_XDECREF(v2);
+            Py_XDECREF(v3);
+            Py_XDECREF(v4);
+            Py_XDECREF(v5);
+            Py_DECREF(t);   /* (slots 2..5 still empty: the tuple releases the two ids) */
+            if (gc_was_on) PyGC_Enable();
+            Py_DECREF(out);
+            return NULL;
         }
-        PyTuple_SET_ITEM(t, 5, PyLong_FromLong(r->bend));
+        PyTuple_SET_ITEM(t, 2, v2);
+        PyTuple_SET_ITEM(t, 3, v3);
+        PyTuple_SET_ITEM(t, 4, v4);
+        PyTuple_SET_ITEM(t, 5, v5);
         PyList_SET_ITEM(out, (Py_ssize_t)i, t);
     }
-    Py_XDECREF(zero);
     if (gc_was_on) PyGC_Enable();
     return out;
 }

@@ -140,6 +140,8 @@ def test_native_tuple_builder_matches_the_python_one():
     for f in ("astart", "aend", "bstart", "bend"):
         arr[f] = rng.integers(-5, 2_000_000_000, n)
     arr["bstart"][::2] = 0
+    arr["aend"][::3] = rng.integers(0, 70000, len(arr["aend"][::3]))     # both sides of the shared-int table's 2^16 bound
+    arr["astart"][:4] = (0, 65535, 65536, -1)
     got = fn(arr.ctypes.data, n, ids)
     want = list(zip([ids[i] for i in arr["a_idx"].tolist()], [ids[i] for i in arr["b_idx"].tolist()], arr["astart"].tolist(),
                     arr["aend"].tolist(), arr["bstart"].tolist(), arr["bend"].tolist()))
