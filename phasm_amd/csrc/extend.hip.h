@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void k_extend_lanes(const ExtArgs A, const uin
 // k_extend_lanes spends six instructions on each of the 2W + 1 cells of a row (102 per row at W = 8).  The cells of a
 // row differ from their neighbours by -1, 0 or +1, so the whole row is two bit masks -- HP / HN: bit k set iff
 // C[k] - C[k-1] = +1 / -1, C[k] = D[i][i - W + k] -- plus ONE number, the main-diagonal cell S = D[i][i].  One row of
-// the DP is then ~35 instructions whatever the band (W <= 15: 31 bits):
+// the DP is then ~25 vector instructions whatever the band (W <= 15: 31 bits):
 //   the previous row seen through the window shifted by one diagonal step: P'[k] = C_prev[k + 1], so its deltas are the
 //   previous row's, shifted right by one (the cell beyond the band's top edge counts as one higher: never the minimum);
 //   Eq = match bits of x[i-1] against the 2W + 1 bases of y facing the band (two bit planes of y slide along);
@@ -545,18 +545,7 @@ __global__ __launch_bounds__(256) void k_extend_bits(const ExtArgs A, const uint
     const uint32_t rows = canA ? rem : (canB ? min(rem, lb + W) : 0u);
     uint32_t bestA = 0xFFFFFFFFu, bestB = 0xFFFFFFFFu, endA_j = 0, endB_i = 0;
     uint32_t xw = 0, yw = 0, steps = 0;
-    bool dead = false;
-    // the bases come in 16-byte pieces (64 bases), the NEXT piece requested while the current one is walked: a 4-byte
-    // load every 16 rows per lane and side (64 different cache lines per wave instruction, each line fetched again for
-    // every one of its 16 dwords once the other candidates have pushed it out) made this kernel wait for memory --
-    // 129 ms whatever the band
-    const u32x4* __restrict__ gx4 = reinterpret_cast<const u32x4*>(gx);
-    const u32x4* __restrict__ gy4 = reinterpret_cast<const u32x4*>(gy);
-    u32x4 xc = gx4[p >> 6], xn = gx4[(p >> 6) + 1u];
-    u32x4 yc = gy4[(1u + W) >> 6], yn = gy4[((1u + W) >> 6) + 1u];
-    auto pick = [](const u32x4& q, uint32_t dw) __attribute__((always_inline)) -> uint32_t {
-        return dw == 0u ? q.x : dw == 1u ? q.y : dw == 2u ? q.z : q.w;
-    };
+    bool dead = false, stop = false;
     const uint32_t above = ALL & ~((2u << W) - 1u), below = ((2u << W) - 1u) & ~1u;   // delta bits above / at-and-below the diagonal
     auto cell = [&](uint32_t k) __attribute__((always_inline)) -> uint32_t {   // C[k] from S and the deltas between
         if (k >= W) {
@@ -566,18 +555,30 @@ __global__ __launch_bounds__(256) void k_extend_bits(const ExtArgs A, const uint
         const uint32_t m = below & ~((2u << k) - 1u);             // bits k+1 .. W
         return S - (uint32_t)__popc(HP & m) + (uint32_t)__popc(HN & m);
     };
-    for (uint32_t i = 1; i <= rows; ++i) {
+    auto band_min = [&]() __attribute__((always_inline)) -> uint32_t {   // walk the deltas up and down from the diagonal
+        uint32_t rowmin = S, v = S;
+        for (uint32_t k = W + 1u; k < N; ++k) {
+            v += ((HP >> k) & 1u) - ((HN >> k) & 1u);
+            rowmin = min(rowmin, v);
+        }
+        v = S;
+        for (uint32_t k = W; k >= 1u; --k) {
+            v -= ((HP >> k) & 1u) - ((HN >> k) & 1u);
+            // (cells left of the matrix are virtual -- i + |j| -- and never the smallest of a row that has real cells)
+            rowmin = min(rowmin, v);
+        }
+        return rowmin;
+    };
+    // One row of the recurrence, with everything a row can need: the end cells of B (rows lb - W .. lb + W) and of A (row
+    // rem), the band minimum every 16 rows, validity of the cells left of the matrix (the first W rows).  Its bases come
+    // from 4-byte loads as it crosses a dword -- this is the path of a candidate's FIRST rows (until the band is inside
+    // the matrix and x stands at a 64-base boundary) and of its LAST ones; everything between runs in fast_block below.
+    bool fresh = true;   // (re)load the two base dwords: at the start of a slow phase
+    auto slow_row = [&](uint32_t i) __attribute__((always_inline)) {
         const uint32_t xpos = p + i - 1u, ypos = i + W;
-        if (i != 1u && (xpos & 63u) == 0u) {
-            xc = xn;
-            xn = gx4[(xpos >> 6) + 1u];
-        }
-        if (i != 1u && (ypos & 63u) == 0u) {
-            yc = yn;
-            yn = gy4[(ypos >> 6) + 1u];
-        }
-        if (i == 1u || (xpos & 15u) == 0u) xw = pick(xc, (xpos >> 4) & 3u) >> ((xpos & 15u) * 2u);
-        if (i == 1u || (ypos & 15u) == 0u) yw = pick(yc, (ypos >> 4) & 3u) >> ((ypos & 15u) * 2u);
+        if (fresh || (xpos & 15u) == 0u) xw = gx[xpos >> 4] >> ((xpos & 15u) * 2u);
+        if (fresh || (ypos & 15u) == 0u) yw = gy[ypos >> 4] >> ((ypos & 15u) * 2u);
+        fresh = false;
         const uint32_t xb = xw & 3u;
         xw >>= 2;
         const uint32_t xl = 0u - (xb & 1u), xh = 0u - (xb >> 1);
@@ -618,22 +619,9 @@ __global__ __launch_bounds__(256) void k_extend_bits(const ExtArgs A, const uint
                 }
             }
         }
-        if ((i & 15u) == 0u) {   // every 16 rows: the band minimum (walk the deltas up and down from the diagonal)
-            uint32_t rowmin = S, v = S;
-            for (uint32_t k = W + 1u; k < N; ++k) {
-                v += ((HP >> k) & 1u) - ((HN >> k) & 1u);
-                rowmin = min(rowmin, v);
-            }
-            v = S;
-            for (uint32_t k = W; k >= 1u; --k) {
-                v -= ((HP >> k) & 1u) - ((HN >> k) & 1u);
-                // (cells left of the matrix are virtual -- i + |j| -- and never the smallest of a row that has real cells)
-                rowmin = min(rowmin, v);
-            }
-            if (rowmin > E) {
-                dead = i < rows;
-                break;
-            }
+        if ((i & 15u) == 0u && band_min() > E) {   // every 16 rows: the band minimum
+            dead = i < rows;
+            stop = true;
         }
         // slide the y window: drop y[i - W - 1], take in y[i + W]; one more column is inside the matrix
         const uint32_t nv = yw & 3u;
@@ -641,6 +629,98 @@ __global__ __launch_bounds__(256) void k_extend_bits(const ExtArgs A, const uint
         plo = (plo >> 1) | ((nv & 1u) << (N - 1u));
         phi = (phi >> 1) | ((nv >> 1) << (N - 1u));
         vm |= vm >> 1;
+    };
+    // Sixteen rows without a branch: x stands at a dword boundary, every cell of the band is inside the matrix (vm = ALL),
+    // no row of the block is an end row.  The sixteen bases of y that slide into the window come as two 16-bit planes
+    // behind the window's own bits (P, Q: up to 47 bits), so the window of row r is ONE funnel shift of the block's start;
+    // the diagonal cell's sixteen match bits are summed in place (bit W of D0) and folded into S once per block.
+    const uint32_t DIAG = 1u << W;
+    auto even_bits = [](uint32_t v) __attribute__((always_inline)) -> uint32_t {   // bits 0, 2, 4 .. 30 packed into 16
+        v &= 0x55555555u;
+        v = (v | (v >> 1)) & 0x33333333u;
+        v = (v | (v >> 2)) & 0x0F0F0F0Fu;
+        v = (v | (v >> 4)) & 0x00FF00FFu;
+        return (v | (v >> 8)) & 0x0000FFFFu;
+    };
+    auto fast_block = [&](const uint32_t xd, const uint32_t yd) __attribute__((always_inline)) {
+        const uint32_t ylo = even_bits(yd), yhi = even_bits(yd >> 1);
+        const uint32_t Plo = plo | (ylo << N), Phi = ylo >> (32u - N);   // (N <= 31, ylo < 2^16: nothing is lost)
+        const uint32_t Qlo = phi | (yhi << N), Qhi = yhi >> (32u - N);
+        uint32_t sacc = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < 16u; ++r) {
+            const uint32_t xl = (uint32_t)((int32_t)(xd << (31u - 2u * r)) >> 31);
+            const uint32_t xh = (uint32_t)((int32_t)(xd << (30u - 2u * r)) >> 31);
+            const uint32_t wl = r ? __builtin_amdgcn_alignbit(Phi, Plo, r) : Plo;
+            const uint32_t wh = r ? __builtin_amdgcn_alignbit(Qhi, Qlo, r) : Qlo;
+            const uint32_t Eq = ~(wl ^ xl) & ~(wh ^ xh) & ALL;
+            const uint32_t VP = (HP >> 1) | TOP, VN = HN >> 1;
+            const uint32_t D0 = ((((Eq & VP) + VP) ^ VP) | Eq | VN) & ALL;
+            const uint32_t hp = VN | ~(D0 | VP), hn = D0 & VP;
+            const uint32_t hps = (hp << 1) | 1u, hns = hn << 1;
+            HP = (hns | ~(D0 | hps)) & ALL;
+            HN = D0 & hps;
+            sacc += D0 & DIAG;
+        }
+        S += 16u - (sacc >> W);
+        plo = __builtin_amdgcn_alignbit(Phi, Plo, 16u) & ALL;
+        phi = __builtin_amdgcn_alignbit(Qhi, Qlo, 16u) & ALL;
+    };
+    uint32_t i = 1;
+    // the last row a fast block may contain: before the end rows of B and of A
+    uint32_t lim = rows;
+    if (canA) lim = min(lim, rem - 1u);
+    if (canB) lim = min(lim, lb > W + 1u ? lb - W - 1u : 0u);
+    // ---- the first rows: until the band has left the matrix's left edge and x stands at a dword boundary ...
+    while (i <= rows && !stop && (i <= W + 1u || ((p + i - 1u) & 15u) != 0u)) {
+        slow_row(i);
+        ++i;
+    }
+    // ... then single blocks (their three dwords loaded on the spot) up to a 64-base boundary of x
+    auto single_blocks = [&](bool to_boundary) __attribute__((always_inline)) {
+        while (!stop && i + 15u <= lim && (!to_boundary || ((p + i - 1u) & 63u) != 0u)) {
+            const uint32_t* yq = gy + ((i + W) >> 4);
+            fast_block(gx[(p + i - 1u) >> 4], __builtin_amdgcn_alignbit(yq[1], yq[0], ((i + W) & 15u) * 2u));
+            i += 16u;
+            steps += 16u;
+        }
+    };
+    single_blocks(true);
+    // ---- 64 rows at a time: x in one aligned 16-byte piece, the 64 bases of y that slide in as five dwords from wherever
+    // they start (4-byte aligned loads), both requested one round ahead
+    if (!stop && i + 63u <= lim) {
+        const uint32_t* yp = gy + ((i + W) >> 4);
+        const uint32_t ysh = ((i + W) & 15u) * 2u;
+        const u32x4* xp = reinterpret_cast<const u32x4*>(gx) + ((p + i - 1u) >> 6);
+        u32x4 xa = xp[0];
+        u32x4 ya = {yp[0], yp[1], yp[2], yp[3]};
+        u32x4 yb = {yp[4], yp[5], yp[6], yp[7]};
+        do {
+            xp += 1;
+            yp += 4;
+            const u32x4 xn = xp[0];                             // (past the end of a read: the next read, or the buffer's 72 zero words)
+            const u32x4 yc = {yp[4], yp[5], yp[6], yp[7]};
+            fast_block(xa.x, __builtin_amdgcn_alignbit(ya.y, ya.x, ysh));
+            fast_block(xa.y, __builtin_amdgcn_alignbit(ya.z, ya.y, ysh));
+            fast_block(xa.z, __builtin_amdgcn_alignbit(ya.w, ya.z, ysh));
+            fast_block(xa.w, __builtin_amdgcn_alignbit(yb.x, ya.w, ysh));
+            xa = xn;
+            ya = yb;
+            yb = yc;
+            i += 64u;
+            steps += 64u;
+            if (band_min() > E) {   // (the band minimum never falls from one row to the next: any row may test it)
+                dead = i - 1u < rows;
+                stop = true;
+            }
+        } while (!stop && i + 63u <= lim);
+    }
+    single_blocks(false);
+    fresh = true;
+    // ---- the last rows, end rows included
+    while (i <= rows && !stop) {
+        slow_row(i);
+        ++i;
     }
     uint32_t t = 0;
     if (bestA != 0xFFFFFFFFu) {
