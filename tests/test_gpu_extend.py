@@ -113,6 +113,24 @@ def test_inexact_rows_equal_the_cpu_restatement(seed, max_diff, band, dp_kernel)
     assert len(want) > len(exact)           # ... and on this noise it does
 
 
+@pytest.mark.parametrize("seed,max_diff,band", [(11, 30, 8), (12, 60, 15), (13, 12, 7), (14, 25, 11), (15, 6, 3), (16, 0, 8)])
+def test_long_candidates_run_through_the_blocked_rows(seed, max_diff, band, dp_kernel):
+    """k_extend_bits walks a candidate in three phases (general rows until x stands at a dword boundary, blocks of 16 rows
+    without a test, general rows for the end rows): reads of up to 2 600 bases starting anywhere, so that every alignment
+    of x and y, every number of blocks and both kinds of end row (suffix-prefix and containment of short reads) occur, with
+    indels that move the path across the band.  All three mappings against the CPU restatement."""
+    rng = np.random.default_rng(2000 + seed)
+    seqs = noisy_reads(rng, n_reads=56, glen=5000, lo=100, hi=2600, sub=0.008, indel=0.004, both_strands=seed % 2 == 1)
+    m = int(rng.choice([64, 90, 128]))
+    got, st = ex_rows(seqs, m, max_diff, band)
+    want = ck.oracle_overlaps_ex(seqs, m, max_diff, band, anchor=32)
+    assert st["dp_lanes"] == ((2 if dp_kernel == "bits" else 1) if dp_kernel != "wave" else 0)
+    assert len(want) > (50 if max_diff else 0)       # (max_diff 0 on noisy reads: the few exact overlaps, still through the DP)
+    assert np.array_equal(got, want), (len(got), len(want), [tuple(r) for r in got[:5]], [tuple(r) for r in want[:5]])
+    if max_diff:
+        assert st["dp_steps"] > 100 * len(want)      # (the rows were walked: long candidates, most of them in blocks)
+
+
 def test_inexact_mode_on_8bit_reads_and_errors():
     rng = np.random.default_rng(77)
     alpha = np.frombuffer(b"ACGTNacgt", dtype=np.uint8)
