@@ -129,7 +129,7 @@ def cfg4_leg(dev_idx: int, m: int, max_diff: int, band: int) -> dict:
             cells = st["dp_steps"] * (2 * band + 1) / 2.0     # half of the band's lanes hold a cell of each antidiagonal
             out[key].update({"max_diff": max_diff, "band": band, "antidiagonals": st["dp_steps"], "stopped_early": st["dp_stopped"],
                              "G_cell_updates_per_sec": cells / (st["ms_verify_kernel"] * 1e-3) / 1e9,
-                             "kernel": {2: "k_extend_bits: one LANE per candidate, the band row as a bit vector (Myers / Hyyro diagonal band: 25 vector instructions per row "
+                             "kernel": {2: "k_extend_bits: one LANE per candidate, the band row as a bit vector (Myers / Hyyro diagonal band: 20 vector instructions per row "
                                            "whatever the band, rows in branch-free blocks of 16), bases fetched 64 at a time one round ahead, candidates sorted by length",
                                         1: "k_extend_lanes: one LANE per candidate (band row in registers, 64 candidates per wave, candidates sorted by length)",
                                         0: "k_extend_dp<2>: one WAVE per candidate, one lane per diagonal, antidiagonal sweep with whole-wave DPP shifts"}[st["dp_lanes"]],

@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void k_extend_lanes(const ExtArgs A, const uin
 // k_extend_lanes spends six instructions on each of the 2W + 1 cells of a row (102 per row at W = 8).  The cells of a
 // row differ from their neighbours by -1, 0 or +1, so the whole row is two bit masks -- HP / HN: bit k set iff
 // C[k] - C[k-1] = +1 / -1, C[k] = D[i][i - W + k] -- plus ONE number, the main-diagonal cell S = D[i][i].  One row of
-// the DP is then ~25 vector instructions whatever the band (W <= 15: 31 bits):
+// the DP is then ~20 vector instructions whatever the band (W <= 15: 31 bits):
 //   the previous row seen through the window shifted by one diagonal step: P'[k] = C_prev[k + 1], so its deltas are the
 //   previous row's, shifted right by one (the cell beyond the band's top edge counts as one higher: never the minimum);
 //   Eq = match bits of x[i-1] against the 2W + 1 bases of y facing the band (two bit planes of y slide along);
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void k_extend_lanes(const ExtArgs A, const uin
 // mappings (tests/test_gpu_extend.py runs all three against oracle/extend_oracle.c; the prototype of this recurrence
 // was held against the plain DP on 40 000 random cases first).
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_extend_bits(const ExtArgs A, const uint32_t* __restrict__ perm) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_extend_bits(const ExtArgs A, const uint32_t* __restrict__ perm) {
     const uint32_t c0 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = c0 < A.n_cand;
     const uint32_t c = in_range ? (perm ? perm[c0] : c0) : 0u;
@@ -647,21 +647,35 @@ __global__ __launch_bounds__(256) void k_extend_bits(const ExtArgs A, const uint
         const uint32_t Plo = plo | (ylo << N), Phi = ylo >> (32u - N);   // (N <= 31, ylo < 2^16: nothing is lost)
         const uint32_t Qlo = phi | (yhi << N), Qhi = yhi >> (32u - N);
         uint32_t sacc = 0;
+        // Inside the block the state is the NEXT row's view of the deltas, VP = (HP >> 1) | TOP and VN = HN >> 1: with
+        // hp / hn this row's vertical deltas, HP >> 1 = hn | ~((D0 >> 1) | hp) below the top bit and HN >> 1 =
+        // (D0 >> 1) & hp -- one shift of D0 instead of the four shifts of HP, HN, hp and hn (bit 0 of HP / HN, the delta
+        // towards the cell below the band, is never read).
+        uint32_t VP = (HP >> 1) | TOP, VN = HN >> 1;
+        const uint32_t ALLS = ALL >> 1;
 #pragma unroll
         for (uint32_t r = 0; r < 16u; ++r) {
             const uint32_t xl = (uint32_t)((int32_t)(xd << (31u - 2u * r)) >> 31);
             const uint32_t xh = (uint32_t)((int32_t)(xd << (30u - 2u * r)) >> 31);
             const uint32_t wl = r ? __builtin_amdgcn_alignbit(Phi, Plo, r) : Plo;
             const uint32_t wh = r ? __builtin_amdgcn_alignbit(Qhi, Qlo, r) : Qlo;
-            const uint32_t Eq = ~(wl ^ xl) & ~(wh ^ xh) & ALL;
-            const uint32_t VP = (HP >> 1) | TOP, VN = HN >> 1;
-            const uint32_t D0 = ((((Eq & VP) + VP) ^ VP) | Eq | VN) & ALL;
-            const uint32_t hp = VN | ~(D0 | VP), hn = D0 & VP;
-            const uint32_t hps = (hp << 1) | 1u, hns = hn << 1;
-            HP = (hns | ~(D0 | hps)) & ALL;
-            HN = D0 & hps;
+            // (three-input boolean functions spelled as v_bitop3 truth tables -- inputs 0xF0, 0xCC, 0xAA -- because the
+            // compiler's own factoring of these expressions came out four instructions per row longer)
+            const uint32_t e1 = __builtin_amdgcn_bitop3_b32(wl, xl, ALL, 0x82);        // ~(wl ^ xl) & ALL
+            const uint32_t Eq = __builtin_amdgcn_bitop3_b32(e1, wh, xh, 0x90);         // e1 & ~(wh ^ xh)
+            const uint32_t t = (Eq & VP) + VP;
+            const uint32_t u = __builtin_amdgcn_bitop3_b32(t, VP, Eq, 0xBE);           // (t ^ VP) | Eq
+            const uint32_t D0 = __builtin_amdgcn_bitop3_b32(u, VN, ALL, 0xA8);         // (u | VN) & ALL
+            const uint32_t hp = __builtin_amdgcn_bitop3_b32(VN, D0, VP, 0xF1);         // VN | ~(D0 | VP)
+            const uint32_t hn = D0 & VP;
+            const uint32_t D0s = D0 >> 1;
+            const uint32_t x = __builtin_amdgcn_bitop3_b32(hn, D0s, hp, 0xF1);         // hn | ~(D0s | hp)
+            VP = __builtin_amdgcn_bitop3_b32(x, ALLS, TOP, 0xEA);                      // (x & ALLS) | TOP
+            VN = D0s & hp;
             sacc += D0 & DIAG;
         }
+        HP = (VP << 1) & ALL;
+        HN = (VN << 1) & ALL;
         S += 16u - (sacc >> W);
         plo = __builtin_amdgcn_alignbit(Phi, Plo, 16u) & ALL;
         phi = __builtin_amdgcn_alignbit(Qhi, Qlo, 16u) & ALL;
