@@ -1991,10 +1991,13 @@ struct Cand {
 __global__ void k_compact(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
                           const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,
                           const uint8_t* __restrict__ flag, const uint32_t* __restrict__ flag_off, uint32_t n_cand,
-                          Cand* __restrict__ out) {
+                          Cand* __restrict__ out, uint32_t cap) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_cand || flag[i] == 0) return;
-    out[flag_off[i]] = Cand{cand_a[i], cand_p[i], cand_b[i], type[i]};
+    // (cap: `out` may have been chosen before the number of kept candidates reached the host -- what does not fit is
+    // not written, the host sees the number afterwards and compacts again into a buffer that holds them all)
+    const uint32_t o = flag_off[i];
+    if (o < cap) out[o] = Cand{cand_a[i], cand_p[i], cand_b[i], type[i]};
 }
 
 __global__ void k_flag(const uint8_t* __restrict__ rowcnt, uint32_t n, uint8_t* __restrict__ flag) {
