@@ -1196,7 +1196,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         }
         uint64_t* chain64 = h->d_chain.as<uint64_t>();
         hipLaunchKernelGGL(po::k_wide_chain_fill<BITS>, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, read_slot,
-                           (uint64_t)n_entries, slot_start, slot_cur, chain64);
+                           (uint64_t)n_entries, slot_start, slot_cur, chain64, len);
         hipLaunchKernelGGL(po::k_chain_sort_short<uint64_t>, dim3(cdiv(nslots, 256)), dim3(256), 0, st, slot_cnt, slot_start,
                            nslots, chain64, h->d_long_list.as<uint32_t>(), n_long);
         hipLaunchKernelGGL(po::k_chain_sort_long<uint64_t>, dim3(64), dim3(256), 0, st, slot_cnt, slot_start,

@@ -456,10 +456,25 @@ __global__ void k_chain_sort_long(const uint32_t* __restrict__ slot_cnt, const u
 // positions) against a table of W entries per read: linear in the input, at the price of random
 // access into a table that lives in HBM.  Needs min_length >= 2W-1 (63 bases at 2 bit).
 //
-// Slot: {key, start, count} as in the narrow index.  Chain entries are 64-bit (W-1-j) << 32 | b, so
+// Slot: {key, start, count} as in the narrow index.  Chain entries are 64-bit [W-1-j | b | len(b)] (wide_chain_entry), so
 // that ascending order = ascending candidate position p = W*word - j, then ascending b.  One-entry
 // chains are embedded: start = b, count = SLOT_SINGLE | j << 26 | len[b]  (len < 2^26).
 constexpr uint32_t WIDE_LEN_BITS = 26;
+// A chain entry of the wide index, 64 bits: [W-1-j : 5 | read : 32 | length of the read : 27] -- sorted as a number it is
+// ordered by offset, then read (what the candidate order needs); the read's length rides along so that walking a chain
+// is ONE load per entry instead of two dependent ones (chain, then len[read]).  A length that does not fit (all ones)
+// sends the reader to len[].
+constexpr uint32_t CHAIN_LEN_BITS = 27;
+constexpr uint32_t CHAIN_LEN_ESC = (1u << CHAIN_LEN_BITS) - 1u;
+__host__ __device__ inline uint64_t wide_chain_entry(uint32_t wj, uint32_t read, uint32_t len) {
+    return ((uint64_t)wj << 59) | ((uint64_t)read << CHAIN_LEN_BITS) | (len < CHAIN_LEN_ESC ? len : CHAIN_LEN_ESC);
+}
+__host__ __device__ inline uint32_t wide_chain_read(uint64_t e) { return (uint32_t)(e >> CHAIN_LEN_BITS); }
+__host__ __device__ inline uint32_t wide_chain_wj(uint64_t e) { return (uint32_t)(e >> 59); }
+__device__ inline uint32_t wide_chain_len(uint64_t e, const uint32_t* __restrict__ len) {
+    const uint32_t l = (uint32_t)e & CHAIN_LEN_ESC;
+    return l != CHAIN_LEN_ESC ? l : len[wide_chain_read(e)];
+}
 
 // Sliced wide index (multi-GPU): the table is N sub-tables, a key lives in sub-table wide_slice(key); rank g builds
 // sub-table g only and the sub-tables travel in one all-gather (phasm_amd/dist.py: IndexExchange).  The all-ones key
@@ -508,14 +523,15 @@ __global__ void k_wide_insert(const uint64_t* __restrict__ words, const uint64_t
 
 template <int BITS>
 __global__ void k_wide_chain_fill(const uint32_t* __restrict__ entry_slot, uint64_t n_entries,
-                                  const uint32_t* __restrict__ slot_start, uint32_t* slot_cur, uint64_t* chain) {
+                                  const uint32_t* __restrict__ slot_start, uint32_t* slot_cur, uint64_t* chain,
+                                  const uint32_t* __restrict__ len) {
     constexpr uint32_t W = 64 / BITS;
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_entries) return;
     const uint32_t s = entry_slot[e];
     if (s == 0xFFFFFFFFu) return;
     const uint32_t r = (uint32_t)(e / W), j = (uint32_t)(e % W);
-    chain[slot_start[s] + atomicAdd(&slot_cur[s], 1u)] = ((uint64_t)(W - 1 - j) << 32) | r;
+    chain[slot_start[s] + atomicAdd(&slot_cur[s], 1u)] = wide_chain_entry(W - 1 - j, r, len[r]);
 }
 
 template <int BITS>
@@ -530,8 +546,8 @@ __global__ void k_wide_finalize(Slot* tab, uint32_t nslots, const uint32_t* __re
     tab[i].count = c;
     if (c == 1) {
         const uint64_t e = chain[slot_start[i]];
-        const uint32_t b = (uint32_t)e, j = W - 1 - (uint32_t)(e >> 32);
-        const uint32_t lb = len[b];
+        const uint32_t b = wide_chain_read(e), j = W - 1 - wide_chain_wj(e);
+        const uint32_t lb = wide_chain_len(e, len);
         if (lb < (1u << WIDE_LEN_BITS)) {
             tab[i].start = b;
             tab[i].count = SLOT_SINGLE | (j << WIDE_LEN_BITS) | lb;
@@ -557,8 +573,7 @@ __device__ inline void for_each_candidate_wide(const uint64_t* __restrict__ chai
     } else {
         for (uint32_t i = 0; i < w; ++i) {
             const uint64_t e = chain[z + i];
-            const uint32_t b = (uint32_t)e;
-            one(b, W - 1 - (uint32_t)(e >> 32), len[b]);
+            one(wide_chain_read(e), W - 1 - wide_chain_wj(e), wide_chain_len(e, len));
         }
     }
 }

@@ -16,6 +16,9 @@ def pytest_configure(config):
     if "not gpu" not in (config.getoption("-m", default="") or ""):
         import checker
         checker.start()
+        # a mismatch of a GPU run leaves its evidence behind (rows of both sides and the reads: tests/checker.py;
+        # a read that changed under a call: tests/test_gpu_parity.py) -- gpurun_out/ travels back from the GPU box
+        os.environ.setdefault("PHASM_MISMATCH_DIR", os.path.join(ROOT, "gpurun_out", "mismatch"))
 
 
 def pytest_unconfigure(config):
