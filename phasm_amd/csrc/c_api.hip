@@ -109,6 +109,12 @@ struct RegAlloc {
     template <class U> bool operator!=(const RegAlloc<U>&) const { return false; }
 };
 using WordStore = std::vector<uint64_t, RegAlloc<uint64_t>>;
+inline bool store_is_pinned(const WordStore& w) {
+    if (w.capacity() == 0) return false;
+    const RegHeader* hd = reinterpret_cast<const RegHeader*>(reinterpret_cast<const char*>(w.data()) - REG_PAGE);
+    return hd->registered != 0;
+}
+constexpr size_t STAGE_MAX = 4u << 20;   // larger sources are registered stores (or, failing that, go as they are)
 
 struct po_handle {
     int device = 0;
@@ -202,6 +208,11 @@ struct po_handle {
     // per-read metadata of the upload, kept page-locked while the read set is unchanged (reads are only ever appended):
     // [woff x n | len x n | first tile x (n + 1)]; meta_n = reads it covers, meta_bits = encoding it was counted for
     HostBuf meta_host;
+    // Small host->device copies out of ordinary heap memory (a packed store below the registration size, the exception
+    // records, the pair states) go through this page-locked block: handed a pageable source, the HIP runtime pins -- and
+    // keeps a cache of the pin of -- whatever range of the PROCESS heap it lies in, next to the caller's own objects.
+    HostBuf stage_host;
+    size_t stage_used = 0;
     uint32_t meta_n = 0xFFFFFFFFu;
     int meta_bits = 0;
     uint64_t elig_n = ~0ull, elig_val = 0;   // reads of length >= elig_m among the first elig_n (cache of a 100 k-iteration loop)
@@ -705,9 +716,30 @@ void store0_part_range(const po_handle* h, uint32_t shard, uint32_t nshards, uin
 
 // Everything of an upload but the packed words themselves: scan tiles counted, device buffers sized, per-read
 // offsets / lengths / tile numbers copied, tile records built on the device (they need no read data).
+// a page-locked copy of `bytes` bytes at `src` (valid until the next upload starts), or `src` itself when the block is
+// too small for it / the source is large
+const void* staged(po_handle* h, const void* src, size_t bytes) {
+    if (!bytes || bytes > STAGE_MAX || !h->stage_host.p) return src;
+    const size_t off = (h->stage_used + 63) & ~size_t(63);
+    if (off + bytes > h->stage_host.cap) return src;
+    std::memcpy(static_cast<char*>(h->stage_host.p) + off, src, bytes);
+    h->stage_used = off + bytes;
+    return static_cast<const char*>(h->stage_host.p) + off;
+}
+
 po_status upload_meta(po_handle* h, bool* generate_out) {
     const uint32_t n = (uint32_t)h->len.size();
     const size_t per = 64 / h->bits;
+    {
+        // (every copy of the previous upload has completed: upload() and the streamed step end with a synchronisation)
+        size_t need = 0;
+        for (const WordStore& w : h->words)
+            if (!store_is_pinned(w) && w.size() * 8 <= STAGE_MAX) need += w.size() * 8 + 64;
+        if (h->bits == 2) need += ((size_t)n + 1) * 4 + h->exc_pos.size() * 5 + 192;
+        need += n / 2 + 64;
+        h->stage_used = 0;
+        if (need > 256) PO_TRY(ensure_host(h, h->stage_host, need));
+    }
     // tiles: 64 words each, never spanning reads.  The host only counts them (first tile of every read); the
     // 32-byte records are written on the device (k_build_tiles) instead of travelling over PCIe (25 MB at config 2).
     // Counted once per state of the read set, together with a page-locked copy of the per-read arrays (an async copy
@@ -777,9 +809,9 @@ po_status upload_meta(po_handle* h, bool* generate_out) {
         PO_TRY(ensure(h, h->d_exc_off, ((size_t)n + 1) * 4));
         PO_TRY(ensure(h, h->d_exc_pos, n_exc * 4));
         PO_TRY(ensure(h, h->d_exc_byte, n_exc));
-        HIP_TRY(h, hipMemcpyAsync(h->d_exc_off.p, h->exc_off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->d_exc_pos.p, h->exc_pos.data(), n_exc * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->d_exc_byte.p, h->exc_byte.data(), n_exc, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_exc_off.p, staged(h, h->exc_off.data(), ((size_t)n + 1) * 4), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_exc_pos.p, staged(h, h->exc_pos.data(), n_exc * 4), n_exc * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_exc_byte.p, staged(h, h->exc_byte.data(), n_exc), n_exc, hipMemcpyHostToDevice, h->stream));
         h->upload_bytes += ((size_t)n + 1) * 4 + n_exc * 5;
     }
     h->n_exc_uploaded = n_exc;
@@ -809,11 +841,13 @@ po_status upload(po_handle* h) {
             }
         }
     } else if (!h->words[0].empty()) {
-        HIP_TRY(h, hipMemcpyAsync(dw, h->words[0].data(), h->words[0].size() * 8, hipMemcpyHostToDevice, h->stream));
+        const void* src0 = store_is_pinned(h->words[0]) ? h->words[0].data() : staged(h, h->words[0].data(), h->words[0].size() * 8);
+        HIP_TRY(h, hipMemcpyAsync(dw, src0, h->words[0].size() * 8, hipMemcpyHostToDevice, h->stream));
         h->upload_bytes += h->words[0].size() * 8;
     }
     if (!generate && !h->words[1].empty()) {
-        HIP_TRY(h, hipMemcpyAsync(dw + base1, h->words[1].data(), h->words[1].size() * 8, hipMemcpyHostToDevice, h->stream));
+        const void* src1 = store_is_pinned(h->words[1]) ? h->words[1].data() : staged(h, h->words[1].data(), h->words[1].size() * 8);
+        HIP_TRY(h, hipMemcpyAsync(dw + base1, src1, h->words[1].size() * 8, hipMemcpyHostToDevice, h->stream));
         h->upload_bytes += h->words[1].size() * 8;
     }
     if (generate) {
@@ -851,7 +885,7 @@ po_status upload(po_handle* h) {
         if (n_exc) {  // pairs with exception records were compared byte-wise on the host
             h->pair_state.resize(n / 2, 0);
             PO_TRY(ensure(h, h->d_pair_state, n / 2));
-            HIP_TRY(h, hipMemcpyAsync(h->d_pair_state.p, h->pair_state.data(), n / 2, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->d_pair_state.p, staged(h, h->pair_state.data(), n / 2), n / 2, hipMemcpyHostToDevice, h->stream));
             pair_state = h->d_pair_state.as<uint8_t>();
         }
         hipLaunchKernelGGL(po::k_paired_check, dim3(cdiv((uint64_t)(n / 2) * 64, 256)), dim3(256), 0, h->stream,
@@ -2388,6 +2422,7 @@ void po_destroy(po_handle* h) {
         h->d_first.release();
         h->d_defer.release();
         h->meta_host.release();
+        h->stage_host.release();
         for (void* c : h->arena_chunks) (void)hipFree(c);
         h->arena_chunks.clear();
         if (h->up_stream) {
