@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <new>
 #include <string>
 #include <system_error>
@@ -440,6 +441,78 @@ void result_pool_grow(po_handle* h) {
         if (s_ != PO_OK) return s_;     \
     } while (0)
 
+// Streams, events and the small page-locked landing zone of a handle are kept for the NEXT handle of the process instead
+// of being destroyed with this one: a test process (and a server) creates and destroys handles by the hundred, each with
+// four streams and ~70 events -- churn inside the HIP runtime (its completion handlers run on threads of their own) that
+// buys nothing, and ~1 ms of a fresh handle's first call.  A kit is idle when it is put back (every stream synchronised).
+struct DevKit {
+    int device = -1;
+    hipStream_t stream = nullptr, copy_stream = nullptr, up_stream = nullptr, rc_stream = nullptr;
+    hipEvent_t ev_sets[2][EV_N] = {};
+    hipEvent_t ev_up0 = nullptr, ev_up1 = nullptr, ev_meta = nullptr, ev_first = nullptr;
+    hipEvent_t ev_piece[PO_MAX_PIECES] = {}, ev_rc[PO_MAX_PIECES] = {}, ev_lay[4] = {};
+    uint64_t* pinned = nullptr;
+    uint64_t* pinned_dev = nullptr;
+};
+std::mutex g_kit_mu;
+std::vector<DevKit> g_kits;
+constexpr size_t KIT_POOL_MAX = 8;
+
+bool kit_take(po_handle* h) {
+    std::lock_guard<std::mutex> lock(g_kit_mu);
+    for (size_t i = 0; i < g_kits.size(); ++i) {
+        if (g_kits[i].device != h->device) continue;
+        const DevKit k = g_kits[i];
+        g_kits.erase(g_kits.begin() + (long)i);
+        h->stream = k.stream;
+        h->copy_stream = k.copy_stream;
+        h->up_stream = k.up_stream;
+        h->rc_stream = k.rc_stream;
+        std::memcpy(h->ev_sets, k.ev_sets, sizeof(k.ev_sets));
+        h->ev_up0 = k.ev_up0;
+        h->ev_up1 = k.ev_up1;
+        h->ev_meta = k.ev_meta;
+        h->ev_first = k.ev_first;
+        std::memcpy(h->ev_piece, k.ev_piece, sizeof(k.ev_piece));
+        std::memcpy(h->ev_rc, k.ev_rc, sizeof(k.ev_rc));
+        std::memcpy(h->ev_lay, k.ev_lay, sizeof(k.ev_lay));
+        h->pinned = k.pinned;
+        h->pinned_dev = k.pinned_dev;
+        return true;
+    }
+    return false;
+}
+
+// true: the handle's streams / events / landing zone went back to the pool (the caller must not destroy them)
+bool kit_give(po_handle* h) {
+    if (getenv("PHASM_NO_KIT_POOL") || !h->stream || !h->copy_stream || !h->up_stream || !h->rc_stream || !h->pinned) return false;
+    if (hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->copy_stream) != hipSuccess ||
+        hipStreamSynchronize(h->up_stream) != hipSuccess || hipStreamSynchronize(h->rc_stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    DevKit k;
+    k.device = h->device;
+    k.stream = h->stream;
+    k.copy_stream = h->copy_stream;
+    k.up_stream = h->up_stream;
+    k.rc_stream = h->rc_stream;
+    std::memcpy(k.ev_sets, h->ev_sets, sizeof(k.ev_sets));
+    k.ev_up0 = h->ev_up0;
+    k.ev_up1 = h->ev_up1;
+    k.ev_meta = h->ev_meta;
+    k.ev_first = h->ev_first;
+    std::memcpy(k.ev_piece, h->ev_piece, sizeof(k.ev_piece));
+    std::memcpy(k.ev_rc, h->ev_rc, sizeof(k.ev_rc));
+    std::memcpy(k.ev_lay, h->ev_lay, sizeof(k.ev_lay));
+    k.pinned = h->pinned;
+    k.pinned_dev = h->pinned_dev;
+    std::lock_guard<std::mutex> lock(g_kit_mu);
+    if (g_kits.size() >= KIT_POOL_MAX) return false;
+    g_kits.push_back(k);
+    return true;
+}
+
 po_status init_device(po_handle* h) {
     if (h->dev_ready) {
         HIP_TRY(h, hipSetDevice(h->device));
@@ -456,6 +529,15 @@ po_status init_device(po_handle* h) {
     HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->lds_max = prop.sharedMemPerBlock;
+    if (const char* e = getenv("PHASM_POISON")) h->poison = (int)(strtol(e, nullptr, 0) & 0xFF);
+    if (!getenv("PHASM_NO_KIT_POOL") && kit_take(h)) {
+        h->ev = h->ev_sets[0];
+        std::memset(h->pinned, 0, 1024);
+        hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->stream, reinterpret_cast<uint32_t*>(h->pinned_dev + 63), (uint64_t)1, 0u);
+        (void)hipGetLastError();
+        h->dev_ready = true;
+        return PO_OK;
+    }
     HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (int i = 0; i < 2 * EV_N; ++i) HIP_TRY(h, hipEventCreate(&h->ev_sets[i / EV_N][i % EV_N]));
     HIP_TRY(h, hipEventCreate(&h->ev_up0));
@@ -2409,13 +2491,20 @@ void po_destroy(po_handle* h) {
                           &h->d_rowcnt, &h->d_row_off, &h->d_flag, &h->d_pair_key, &h->d_pair_min, &h->spare_rows, &h->spare_cands, &h->spare_edges,
                           &h->d_vlabel, &h->d_vrank, &h->d_vperm, &h->d_end_a, &h->d_end_b, &h->d_dpcnt, &h->d_lay_len, &h->d_lay_cnt, &h->d_rflag, &h->d_removed, &h->d_ekey, &h->d_ecnt,
                           &h->d_ewin, &h->d_eoff, &h->d_chain_state, &h->d_tail_state};
+        // every stream idle before anything the device (or a copy) may still touch is given back
+        if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+        if (h->up_stream) (void)hipStreamSynchronize(h->up_stream);
+        if (h->rc_stream) (void)hipStreamSynchronize(h->rc_stream);
         for (DevBuf* b : bufs) b->release();
+        const bool pooled = kit_give(h);
+        if (!pooled) {
         for (int i = 0; i < 2 * EV_N; ++i) (void)hipEventDestroy(h->ev_sets[i / EV_N][i % EV_N]);
         for (hipEvent_t e : h->ev_lay)
             if (e) (void)hipEventDestroy(e);
         (void)hipEventDestroy(h->ev_up0);
         (void)hipEventDestroy(h->ev_up1);
         if (h->pinned) (void)hipHostFree(h->pinned);
+        }
         h->spare_host.release();
         h->scratch_host.release();
         for (DevBuf& b : h->chunk_rows) b.release();
@@ -2425,6 +2514,7 @@ void po_destroy(po_handle* h) {
         h->stage_host.release();
         for (void* c : h->arena_chunks) (void)hipFree(c);
         h->arena_chunks.clear();
+        if (!pooled) {
         if (h->up_stream) {
             (void)hipStreamSynchronize(h->up_stream);
             (void)hipStreamDestroy(h->up_stream);
@@ -2444,6 +2534,7 @@ void po_destroy(po_handle* h) {
             (void)hipStreamDestroy(h->copy_stream);
         }
         (void)hipStreamDestroy(h->stream);
+        }
     }
     h->spare_host.release();   // (the result pool may exist without the handle ever having made a call)
     delete h;
