@@ -71,6 +71,10 @@ typedef struct {
     uint64_t n_rows;             /* rows emitted (A + B, duplicates included)               */
     uint64_t sum_overlap_bases;  /* sum over emitted rows of the overlap length l           */
     uint64_t verify_bytes_algo;  /* sum over emitted rows of 2*ceil(l*bits/8) (both sides)  */
+                                 /* Stage times come from events recorded between the kernels (~5 us of device time     */
+                                 /* each).  A streamed step (streamed == 1) records only the pairs around its two big   */
+                                 /* kernels: ms_index .. ms_emit are 0 there, ms_total, ms_scan_probe and               */
+                                 /* ms_verify_kernel are sums over the pieces; PHASM_PHASE_EVENTS=1 records them all.   */
     float ms_index;              /* anchor table + chains + Bloom filter build              */
     float ms_scan_count;         /* position scan, counting pass                            */
     float ms_scan_fill;          /* position scan, candidate fill pass                      */
