@@ -601,10 +601,23 @@ struct WideArgs {
 
 // One wave per tile, one word per lane: probe the table with the word itself.  FILL = false: count
 // candidates per tile and remember the slot per lane; FILL = true: write the candidates.
+//
+// The chain entries of a wave's hits are walked by ALL its lanes: about a quarter of the words hit, a quarter of those
+// hits have a chain of several reads, and a lane that walks its own chain does one dependent load after the other while
+// the other 63 wait (the counting pass of config 5 spent its 23 ms there, not on the misses: DESIGN.md 5.1).  Every hit
+// lane contributes its entries (1 for a slot with its one read embedded, w for a chain) to a task list in lane order;
+// the tasks are handed out 64 at a time, one per lane, so that a round of chain loads is ONE round trip for the whole
+// wave.  Task order = lane, then entry = the order the per-lane walk emits, so FILL writes the same array.  A wave with
+// more than WIDE_TASK_CAP entries (tandem repeats) walks per lane as before.
+constexpr uint32_t WIDE_TASK_CAP = 256;
+
 template <int BITS, bool FILL, bool STREAM = false>
 __global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A, const CandGuard G) {
     constexpr uint32_t W = 64 / BITS;
+    __shared__ uint8_t s_owner[256 / WAVE][WIDE_TASK_CAP];
+    __shared__ uint8_t s_kept[256 / WAVE][WAVE];
     const uint32_t lane = lane_id();
+    const uint32_t wv = threadIdx.x / WAVE;
     if (FILL && G.overflow()) return;
     const uint32_t t = __builtin_amdgcn_readfirstlane(A.tile_begin + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     if (t >= A.tile_end) return;
@@ -613,7 +626,7 @@ __global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A, const CandG
     const uint32_t wi = rec.word0 + lane;
     const uint32_t pw = wi * W;
     const size_t li = (size_t)t * WAVE + lane;
-    uint32_t n = 0, z = 0, w = 0, slot1 = 0;
+    uint32_t n = 0, z = 0, w = 0, slot1 = 0, base = 0;
     const bool live = la >= A.m && pw + W <= la;  // the word lies wholly inside the read
     if (!FILL) {
         if (live) {
@@ -622,9 +635,8 @@ __global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A, const CandG
             uint32_t h1, h2;
             kmer_hash(kmer, h1, h2);
             // (sliced index: the key's sub-table; its slots and its chain segment sit in one chunk)
-            const uint32_t base = A.n_slices > 1u ? wide_slice(kmer, h2, A.n_slices) * A.chunk_slots : 0u;
+            base = A.n_slices > 1u ? wide_slice(kmer, h2, A.n_slices) * A.chunk_slots : 0u;
             const Slot* __restrict__ tab = A.table + base;
-            const uint64_t* __restrict__ chain = A.n_slices > 1u ? reinterpret_cast<const uint64_t*>(tab + A.chain_off_slots) : A.chain;
             uint32_t i;
             if (kmer == KEY_EMPTY) {
                 i = tmask + 1u;
@@ -644,27 +656,90 @@ __global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A, const CandG
                     i = (i + 1u) & tmask;
                 }
             }
-            if (w) {
-                for_each_candidate_wide<BITS, STREAM>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
-                                              [&](uint32_t, uint32_t, uint32_t) { ++n; });
-                if (n) slot1 = base + i + 1u;
-            }
+            if (w) slot1 = base + i + 1u;
         }
-        A.lane_slot[li] = slot1;
-        const uint32_t tot = wave_sum(n);
-        if (lane == 0) A.tile_count[t] = tot;
     } else {
         slot1 = A.lane_slot[li];
-        const uint64_t* __restrict__ chain = A.chain;
         if (slot1) {
             const u32x4 s = *reinterpret_cast<const u32x4*>(&A.table[slot1 - 1u]);
             z = s.z;
             w = s.w;
-            if (A.n_slices > 1u)
-                chain = reinterpret_cast<const uint64_t*>(A.table + ((slot1 - 1u) / A.chunk_slots) * A.chunk_slots + A.chain_off_slots);
+            if (A.n_slices > 1u) base = ((slot1 - 1u) / A.chunk_slots) * A.chunk_slots;
+        }
+    }
+    auto chain_of = [&](uint32_t b0) __attribute__((always_inline)) -> const uint64_t* {
+        return A.n_slices > 1u ? reinterpret_cast<const uint64_t*>(A.table + b0 + A.chain_off_slots) : A.chain;
+    };
+    // ---- the wave's task list
+    const uint32_t cnt = !w ? 0u : (w & SLOT_SINGLE) ? 1u : w;
+    const uint32_t incl = wave_incl_scan(cnt), excl = incl - cnt;
+    const uint32_t T = read_last_lane(incl);
+    if (T <= WIDE_TASK_CAP) {
+        for (uint32_t i = 0; i < cnt; ++i) s_owner[wv][excl + i] = (uint8_t)lane;
+        if (!FILL) s_kept[wv][lane] = 0;
+        wave_lds_fence();
+        uint32_t out = FILL ? A.tile_off[t] : 0u;   // FILL: where the next kept candidate goes; COUNT: kept so far
+        for (uint32_t r0 = 0; r0 < T; r0 += WAVE) {
+            const uint32_t task = r0 + lane;
+            bool kept = false;
+            // (the shuffles with every lane active: a task's owner must be, and lanes beyond the list ask for the last task's)
+            const uint32_t o = s_owner[wv][task < T ? task : T - 1u];
+            const uint32_t zo = (uint32_t)__shfl((int)z, (int)o), wo = (uint32_t)__shfl((int)w, (int)o);
+            const uint32_t eo = task - (uint32_t)__shfl((int)excl, (int)o);
+            const uint32_t bo = A.n_slices > 1u ? (uint32_t)__shfl((int)base, (int)o) : 0u;
+            uint32_t cb = 0, cp = 0;
+            if (task < T) {
+                const uint32_t pwo = (rec.word0 + o) * W;
+                uint32_t j, lb;
+                if (wo & SLOT_SINGLE) {
+                    cb = zo;
+                    j = (wo >> WIDE_LEN_BITS) & (W - 1);
+                    lb = wo & ((1u << WIDE_LEN_BITS) - 1u);
+                } else {
+                    const uint64_t e = chain_of(bo)[zo + eo];
+                    cb = wide_chain_read(e);
+                    j = W - 1 - wide_chain_wj(e);
+                    lb = wide_chain_len(e, A.len);
+                }
+                if (j <= pwo) {
+                    cp = pwo - j;
+                    kept = cp + A.m <= la && keep_bits<STREAM>(a, cb, la - cp, lb, A.paired) != 0u;
+                }
+            }
+            const uint64_t bal = __ballot(kept);
+            if (FILL) {
+                if (kept) {
+                    const uint32_t at = out + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    A.cand_a[at] = a;
+                    A.cand_p[at] = cp;
+                    A.cand_b[at] = cb;
+                }
+            } else if (kept) {
+                s_kept[wv][o] = 1;
+            }
+            out += (uint32_t)__popcll(bal);
+        }
+        if (!FILL) {
+            wave_lds_fence();
+            if (!s_kept[wv][lane]) slot1 = 0;   // (a hit none of whose entries is kept: nothing for the fill pass)
+            A.lane_slot[li] = slot1;
+            if (lane == 0) A.tile_count[t] = out;
+        }
+        return;
+    }
+    // ---- more entries than the task list holds: every lane walks its own
+    const uint64_t* __restrict__ chain = chain_of(base);
+    if (!FILL) {
+        if (w) for_each_candidate_wide<BITS, STREAM>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
+                                                     [&](uint32_t, uint32_t, uint32_t) { ++n; });
+        if (!n) slot1 = 0;
+        A.lane_slot[li] = slot1;
+        const uint32_t tot = wave_sum(n);
+        if (lane == 0) A.tile_count[t] = tot;
+    } else {
+        if (slot1)
             for_each_candidate_wide<BITS, STREAM>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
                                           [&](uint32_t, uint32_t, uint32_t) { ++n; });
-        }
         const uint32_t inc = wave_incl_scan(n);
         uint32_t off = A.tile_off[t] + inc - n;
         if (n) {
