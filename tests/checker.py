@@ -114,6 +114,32 @@ def explain_difference(got: np.ndarray, want: np.ndarray, seqs: Optional[Sequenc
     return "\n".join(lines)
 
 
+def snapshot(seqs: Sequence) -> List[bytes]:
+    """Real copies (separate memory) of the reads a test is about to hand to the library."""
+    return [bytes(bytearray(s)) for s in _plain(seqs)]
+
+
+def assert_inputs_unchanged(seqs, snap) -> None:
+    """The reads a test hands to the library are immutable Python objects; the rows are checked against the SAME objects
+    afterwards (checker process + the contract in plain Python).  If one of them reads differently after the call than
+    before it, the comparison that follows would blame whichever side saw the other version -- say so instead, with the
+    bytes that changed (seen once in round 3: the library's rows equalled the oracle's on the regenerated reads, while the
+    test process's own copy of ONE read no longer did)."""
+    for i, (s, c) in enumerate(zip(_plain(seqs), snap)):
+        if s != c:
+            sb, cb = bytes(s), bytes(c)
+            where = [k for k in range(min(len(sb), len(cb))) if sb[k] != cb[k]]
+            dump = os.environ.get("PHASM_MISMATCH_DIR")
+            if dump:
+                os.makedirs(dump, exist_ok=True)
+                np.savez_compressed(os.path.join(dump, "input_changed_%d.npz" % os.getpid()), index=i,
+                                    before=np.frombuffer(cb, dtype=np.uint8), after=np.frombuffer(sb, dtype=np.uint8))
+            raise AssertionError("host memory of the test process changed under the call: read %d (%d bytes) differs from its "
+                                 "copy taken before the call at %d byte offsets, first %s: before %r after %r"
+                                 % (i, len(cb), len(where), where[:8], cb[where[0]:where[0] + 16] if where else b"",
+                                    sb[where[0]:where[0] + 16] if where else b""))
+
+
 def assert_same_rows(got: np.ndarray, want: np.ndarray, seqs: Optional[Sequence] = None, m: int = 1, ctx="") -> None:
     """Sorted-multiset equality of (n, 6) row arrays; a mismatch fails with a per-row verdict."""
     if got.shape == want.shape and np.array_equal(got, want):

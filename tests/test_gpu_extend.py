@@ -37,12 +37,14 @@ def dp_kernel(request, monkeypatch):
 
 
 def ex_rows(seqs, m, max_diff, band):
+    snap = ck.snapshot(seqs)
     ov = ExactOverlapper()
     for i, s in enumerate(seqs):
         ov.add_sequence("r%d" % i, s)
     arr = ov.overlaps_ex_array(m, max_diff, band)
     st = ov.stats()
     ov.close()
+    ck.assert_inputs_unchanged(seqs, snap)
     return oo.sort_rows(oo.struct_to_rows(arr)), st
 
 

@@ -18,30 +18,9 @@ pytestmark = pytest.mark.gpu
 _last = {}
 
 
-def _assert_inputs_unchanged(seqs, snap):
-    """The reads a test hands to the library are immutable Python objects; the rows are checked against the SAME objects
-    afterwards (checker process + the contract in plain Python).  If one of them reads differently after the call than
-    before it, the comparison that follows would blame whichever side saw the other version -- say so instead, with the
-    bytes that changed (seen once in round 3: the library's rows equalled the oracle's on the regenerated reads, while the
-    test process's own copy of ONE read no longer did)."""
-    for i, (s, c) in enumerate(zip(seqs, snap)):
-        if s != c:
-            sb, cb = bytes(s), bytes(c)
-            where = [k for k in range(min(len(sb), len(cb))) if sb[k] != cb[k]]
-            dump = os.environ.get("PHASM_MISMATCH_DIR")
-            if dump:
-                os.makedirs(dump, exist_ok=True)
-                np.savez_compressed(os.path.join(dump, "input_changed_%d.npz" % os.getpid()), index=i,
-                                    before=np.frombuffer(cb, dtype=np.uint8), after=np.frombuffer(sb, dtype=np.uint8))
-            raise AssertionError("host memory of the test process changed under the call: read %d (%d bytes) differs from its "
-                                 "copy taken before the call at %d byte offsets, first %s: before %r after %r"
-                                 % (i, len(cb), len(where), where[:8], cb[where[0]:where[0] + 16] if where else b"",
-                                    sb[where[0]:where[0] + 16] if where else b""))
-
-
 def hip_rows(seqs, m, shard=None):
     _last.update(seqs=seqs, m=m)
-    snap = [bytes(bytearray(s.encode("latin-1") if isinstance(s, str) else s)) for s in seqs]   # (real copies)
+    snap = ck.snapshot(seqs)
     ov = ExactOverlapper()
     for i, s in enumerate(seqs):
         ov.add_sequence("r%d" % i, s)
@@ -51,7 +30,7 @@ def hip_rows(seqs, m, shard=None):
         arr = np.concatenate([ov.overlaps_shard_array(m, k, shard) for k in range(shard)])
     st = ov.stats()
     ov.close()
-    _assert_inputs_unchanged([s.encode("latin-1") if isinstance(s, str) else s for s in seqs], snap)
+    ck.assert_inputs_unchanged(seqs, snap)
     return oo.sort_rows(oo.struct_to_rows(arr)), st
 
 
