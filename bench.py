@@ -242,14 +242,37 @@ def cold_call_leg(dev_idx: int, oriented, m: int, n_handles: int = 3) -> dict:
                                   "then ONE po_overlaps_to_host + po_result_rows timed"}
 
 
+def visible_gpu_count() -> int:
+    """GPUs this process may use, counted WITHOUT the HIP runtime: the KFD topology lists every node (GPUs are the nodes
+    with SIMDs), ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow it down.  The launcher parent
+    must stay a process that has never initialised the GPU (it starts the ranks as children)."""
+    import glob
+    n = 0
+    files = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not files:
+        return -1    # (no topology to read: unknown -- the ranks will say so themselves)
+    for f in files:
+        try:
+            with open(f) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        except (OSError, ValueError):
+            pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU, RCCL) as CHILD processes and pass rank 0's
     JSON line on.  The parent never initialises the GPU (a process that has must not exec or fork GPU work), it only counts
     devices; with --dist-backend gloo the ranks share whatever GPUs there are (a rehearsal, merged on the host)."""
     import socket
     import subprocess
-    n_dev = torch.cuda.device_count()      # (does not initialise the runtime)
-    if args.dist_backend == "nccl" and n_dev < args.gpus:
+    n_dev = visible_gpu_count()      # (from the kernel driver's topology files: no HIP / torch call in this process)
+    if args.dist_backend == "nccl" and 0 <= n_dev < args.gpus:
         print("bench.py --gpus %d: only %d GPU(s) visible (RCCL needs one device per rank; --dist-backend gloo rehearses "
               "the N-rank step on fewer)" % (args.gpus, n_dev), file=sys.stderr)
         return 2

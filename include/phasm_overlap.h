@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PO_ABI_VERSION 3
+#define PO_ABI_VERSION 4
 
 typedef enum {
     PO_OK = 0,
@@ -336,6 +336,24 @@ po_status po_add_gfa(po_handle* h, const char* path, uint64_t* n_segments, po_re
 po_status po_layout_edges(po_handle* h, po_result* rows, const po_layout_params* params,
                           uint8_t* removed_reads_out, po_result** edges_out);
 po_status po_get_layout_stats(const po_handle* h, po_layout_stats* out);
+
+/* Diagnostics for the test suite (no reference counterpart: addSequence copies its argument and
+ * never touches it again, src/overlapper.cpp:22-26 -- these two calls let a test PROVE that of this library).
+ * po_debug_host_ranges: every range of host memory the library has made visible to the GPU in this process, ever
+ * (hipHostMalloc'ed landing zones and result arrays, the hipHostRegister'ed packed read stores): `out` receives up to
+ * cap_entries triplets {base, bytes, kind} (kind & 0xFF: 1 = page-locked allocation, 2 = registered store; bit 8: still
+ * live); returns the number of entries on the list.  Device->host copies and host-mapped stores of the library can
+ * only land inside these ranges.
+ * po_debug_pointer_info: what the HIP runtime (hipPointerGetAttributes -> *hip_type, -1 = unknown to it) and the ROCr
+ * runtime underneath (hsa_amd_pointer_info -> *hsa_type: 0 unknown, 1 runtime allocation, 2 locked / registered host
+ * memory; -1 = not queried) know about address p, and the range they know it as.  Returns 1 if either knows it -- i.e.
+ * the GPU can address that page -- else 0.
+ * po_debug_fault_backtrace: install a SIGSEGV / SIGBUS handler that writes the faulting address and the native stack of
+ * the faulting thread to `fd`, then runs whatever handler was installed before it (a store into a read-only input mapping
+ * by a thread that has no Python frames -- a runtime thread -- is named this way).  Returns 0 on success. */
+uint64_t po_debug_host_ranges(uint64_t* out, uint64_t cap_entries);
+int po_debug_fault_backtrace(int fd);
+int po_debug_pointer_info(const void* p, int32_t* hip_type, int32_t* hsa_type, uint64_t* base, uint64_t* bytes);
 
 po_status po_get_stats(const po_handle* h, po_stats* out);
 const char* po_last_error(const po_handle* h);

@@ -60,9 +60,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             os.remove(LIB)
             raise RuntimeError("k_scan_probe: tools/check_scan_isa.py --strict found a read of an in-flight register; library removed")
         v = hipcc_version(hipcc)
-        if v not in VALIDATED_HIPCC:
-            print("WARNING: hipcc %s is not one of %s: re-validate tools/check_scan_isa.py against this compiler's code "
-                  "for k_scan_probe" % (v, VALIDATED_HIPCC), file=sys.stderr)
+        if v not in VALIDATED_HIPCC and not os.environ.get("PHASM_ALLOW_UNVALIDATED_HIPCC"):
+            os.remove(LIB)
+            raise RuntimeError("hipcc %s is not one of %s: k_scan_probe is hand-scheduled around this compiler's code -- re-validate "
+                               "tools/check_scan_isa.py against the new compiler's output, then add the version to VALIDATED_HIPCC "
+                               "(PHASM_ALLOW_UNVALIDATED_HIPCC=1 builds anyway); library removed" % (v, VALIDATED_HIPCC))
     return LIB
 
 

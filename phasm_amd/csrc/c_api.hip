@@ -5,7 +5,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <execinfo.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -45,6 +48,36 @@ struct DevBuf {
     }
 };
 
+// Every range of HOST memory this library makes visible to the GPU (hipHostMalloc, hipHostRegister) is noted here, for
+// the whole life of the process: po_debug_host_ranges hands the list out, and the tests assert that no page of the reads
+// they handed to po_add_sequence ever lay inside one (the library's device->host copies and
+// host-mapped stores can only reach memory that is on this list).
+struct PinNote {
+    uint64_t base, bytes;
+    uint32_t kind;   // 1 hipHostMalloc, 2 hipHostRegister (packed read store), bit 8: still live
+};
+std::mutex g_pin_mu;
+std::vector<PinNote> g_pins;
+uint64_t g_pins_ever = 0;
+constexpr size_t PIN_LOG_MAX = 1u << 16;
+void pin_note(const void* p, size_t bytes, uint32_t kind) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(g_pin_mu);
+    ++g_pins_ever;
+    for (PinNote& n : g_pins)   // (the same range again: one entry)
+        if (n.base == (uint64_t)(uintptr_t)p && n.bytes == bytes && (n.kind & 0xFFu) == kind) {
+            n.kind |= 0x100u;
+            return;
+        }
+    if (g_pins.size() < PIN_LOG_MAX) g_pins.push_back(PinNote{(uint64_t)(uintptr_t)p, (uint64_t)bytes, kind | 0x100u});
+}
+void pin_drop(const void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(g_pin_mu);
+    for (PinNote& n : g_pins)
+        if (n.base == (uint64_t)(uintptr_t)p && (n.kind & 0x100u)) n.kind &= ~0x100u;
+}
+
 // host-pinned buffer (hipHostMalloc): every device->host copy of this library lands in one of these, never in
 // pageable heap memory -- the HIP runtime then neither stages the copy nor pins (and caches the pin of) a range
 // of the caller's malloc heap
@@ -52,7 +85,10 @@ struct HostBuf {
     void* p = nullptr;
     size_t cap = 0;
     void release() {
-        if (p) (void)hipHostFree(p);
+        if (p) {
+            pin_drop(p);
+            (void)hipHostFree(p);
+        }
         p = nullptr;
         cap = 0;
     }
@@ -95,15 +131,22 @@ struct RegAlloc {
         hd->registered = 0;
         char* data = static_cast<char*>(base) + REG_PAGE;
         if (bytes >= (1u << 20) && !getenv("PHASM_NO_PIN")) {
-            if (hipHostRegister(data, bytes, hipHostRegisterPortable) == hipSuccess) hd->registered = 1;
-            else (void)hipGetLastError();
+            if (hipHostRegister(data, bytes, hipHostRegisterPortable) == hipSuccess) {
+                hd->registered = 1;
+                pin_note(data, bytes, 2u);
+            } else {
+                (void)hipGetLastError();
+            }
         }
         return reinterpret_cast<T*>(data);
     }
     void deallocate(T* p, size_t) {
         char* base = reinterpret_cast<char*>(p) - REG_PAGE;
         RegHeader* hd = reinterpret_cast<RegHeader*>(base);
-        if (hd->registered) (void)hipHostUnregister(p);
+        if (hd->registered) {
+            pin_drop(p);
+            (void)hipHostUnregister(p);
+        }
         free(base);
     }
     template <class U> bool operator==(const RegAlloc<U>&) const { return true; }
@@ -330,7 +373,7 @@ struct AllocTrace {
     }
 };
 
-po_status ensure(po_handle* h, DevBuf& b, size_t bytes, double scale = 1.0) {
+po_status ensure(po_handle* h, DevBuf& b, size_t bytes, double scale = 1.0, bool arena_ok = true) {
     if (bytes <= b.cap) return PO_OK;
     AllocTrace tr("hipMalloc", bytes);
     const bool first = b.p == nullptr;
@@ -339,7 +382,9 @@ po_status ensure(po_handle* h, DevBuf& b, size_t bytes, double scale = 1.0) {
     if (scale > 1.0) want = (size_t)((double)bytes * scale) + 256;   // (a streamed piece: room for the largest piece)
     if (h && h->st_on) want += 8192;   // (... and for the next call's predicted count plus its slack, small inputs included)
     constexpr size_t ARENA_CHUNK = 64u << 20, ARENA_MAX = 8u << 20;
-    if (h && first && want <= ARENA_MAX && !getenv("PHASM_NO_ARENA")) {
+    // (arena_ok = false: buffers that leave the handle with a result -- rows, candidates, edges -- are freed or kept as
+    // spares one by one; carved out of a chunk they would stay behind until the handle dies)
+    if (h && first && arena_ok && want <= ARENA_MAX && !getenv("PHASM_NO_ARENA")) {
         // (only a buffer's FIRST allocation: one that has to grow moves out, so a chunk never fills up with dead pieces)
         want = (want + 255) & ~size_t(255);
         if (h->arena_left < want) {
@@ -389,6 +434,7 @@ po_status ensure_host(po_handle* h, HostBuf& b, size_t bytes) {
         return fail(h, PO_ERR_NOMEM, "hipHostMalloc(" + std::to_string(want) + " bytes): " + hipGetErrorString(e));
     }
     b.cap = want;
+    pin_note(b.p, want, 1u);
     return PO_OK;
 }
 
@@ -428,6 +474,7 @@ void result_pool_grow(po_handle* h) {
     h->spare_host.release();
     if (hipHostMalloc(&h->spare_host.p, want, hipHostMallocPortable) == hipSuccess) {
         h->spare_host.cap = want;
+        pin_note(h->spare_host.p, want, 1u);
     } else {
         (void)hipGetLastError();
         h->spare_host.p = nullptr;
@@ -543,6 +590,7 @@ po_status init_device(po_handle* h) {
     HIP_TRY(h, hipEventCreate(&h->ev_up0));
     HIP_TRY(h, hipEventCreate(&h->ev_up1));
     HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->pinned), 1024, hipHostMallocDefault));   // 128 slots
+    pin_note(h->pinned, 1024, 1u);
     HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pinned_dev), h->pinned, 0));
     if (const char* e = getenv("PHASM_POISON")) h->poison = (int)(strtol(e, nullptr, 0) & 0xFF);
     // the streams and events of the host-to-host call: created here (a few tenths of a millisecond each), not in its first call
@@ -1471,7 +1519,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     const int zone = 64 + 16 * (int)(shard & 1u);   // this piece's slots of the pinned landing area
     uint32_t cap_c = 0;
     bool async_count = false;
-    if (streamed && h->st_harvest && h->st_pred_valid && !dp && !want_cands && !getenv("PHASM_SYNC_COUNT")) {
+    if (streamed && h->st_harvest && h->st_pred_valid && !dp && !want_cands && !getenv("PHASM_SYNC_COUNT") && !getenv("PHASM_TAIL_CLASSIC")) {
         uint64_t pred = h->st_pred_cand[shard];
         uint64_t cap = pred + pred / 50 + 256;
         if (const char* e = getenv("PHASM_PRED_SCALE")) cap = pred = (uint64_t)((double)pred * atof(e));   // (tests: a prediction that is too small)
@@ -1740,6 +1788,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         const bool can_tail = !want_cands && !dpE && h->spare_rows.p && h->spare_rows.cap >= worst_rows * sizeof(po_row) &&
                               (!n_selfrep_reads || ((nshards > 1 || streamed || wide) && n_cand < (4u << 20))) &&
                               cdiv(n_cand, po::TAIL_TILE) <= po::TAIL_MAX_TILES && !getenv("PHASM_TAIL_CLASSIC");
+        // (a piece with a predicted count has nothing but the fused tail: the classic kernels take the real count from the host)
+        if (async_count && !can_tail) return fail(h, PO_ERR_HIP, "internal: a piece with a predicted candidate count needs the fused tail");
         classic_tail = [&]() -> po_status {
         if (n_selfrep_reads) {
             // some read's prefix recurs inside it (or a read was too repetitive for k_select_local): A candidates
@@ -1818,7 +1868,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                         res->d_rows = h->spare_cands;
                         h->spare_cands = DevBuf();
                     }
-                    PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_ver * sizeof(po::Cand), 256)));
+                    PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_ver * sizeof(po::Cand), 256), 1.0, false));
                     dst = res->d_rows.as<po::Cand>();
                 }
                 dst_cap = n_ver;
@@ -1843,7 +1893,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                 const size_t exact = n_rows64 * sizeof(po_row);
                 size_t roomy = worst_rows * sizeof(po_row) <= (2ull << 30) ? (size_t)(worst_rows * sizeof(po_row)) : 0;
                 if (roomy && streamed) roomy += 4096 * sizeof(po_row);   // (room for the next call's predicted count and its slack)
-                PO_TRY(ensure(h, res->d_rows, std::max<size_t>(std::max(exact, roomy), 256)));
+                PO_TRY(ensure(h, res->d_rows, std::max<size_t>(std::max(exact, roomy), 256), 1.0, false));
             }
             if (dpE)
                 hipLaunchKernelGGL(po::k_emit_ex, dim3(std::min<uint32_t>(cdiv(n_cand, 256), (uint32_t)h->n_cu * 16)), dim3(256), 0,
@@ -1941,7 +1991,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         if (n_ver > cands_cap) {
             // the exchange slot was too small for this shard (the caller sizes it from the previous step): once more, into
             // a buffer of the library's own -- the candidate arrays, flags and offsets are all still in place
-            PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_ver * sizeof(po::Cand), 256)));
+            PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_ver * sizeof(po::Cand), 256), 1.0, false));
             hipLaunchKernelGGL(po::k_compact, dim3(cdiv((uint32_t)S.n_candidates, 256)), dim3(256), 0, st, A.cand_a, A.cand_p, A.cand_b,
                                h->d_type.as<uint8_t>(), h->d_flag.as<uint8_t>(), h->d_row_off.as<uint32_t>(), (uint32_t)S.n_candidates,
                                res->d_rows.as<po::Cand>(), (uint32_t)n_ver);
@@ -2013,7 +2063,7 @@ po_status run_expand(po_handle* h, const void* d_cands, uint64_t n, po_result* r
     if (!rows_late) {
         const size_t exact = n_rows * sizeof(po_row);
         const size_t roomy = worst_rows * sizeof(po_row) <= (2ull << 30) ? (size_t)(worst_rows * sizeof(po_row)) : 0;
-        PO_TRY(ensure(h, res->d_rows, std::max<size_t>(std::max(exact, roomy), 256)));
+        PO_TRY(ensure(h, res->d_rows, std::max<size_t>(std::max(exact, roomy), 256), 1.0, false));
     }
     HIP_TRY(h, hipMemsetAsync(h->d_scalars.p, 0, 64, st));
     hipLaunchKernelGGL(po::k_emit_cands, dim3(std::min<uint32_t>(cdiv(nc, 256), (uint32_t)h->n_cu * 16)), dim3(256), 0, st,
@@ -2056,7 +2106,7 @@ bool ids_are_strand_pairs(po_handle* h) {
 po_status rows_to_device(po_handle* h, po_result* r) {
     if (r->count == 0 || r->d_rows.p) return PO_OK;
     if (!r->host) return fail(h, PO_ERR_INVALID, "result holds no rows");
-    PO_TRY(ensure(h, r->d_rows, r->count * r->elem));
+    PO_TRY(ensure(h, r->d_rows, r->count * r->elem, 1.0, false));
     HIP_TRY(h, hipMemcpyAsync(r->d_rows.p, r->host, r->count * r->elem, hipMemcpyHostToDevice, h->stream));
     return PO_OK;
 }
@@ -2132,7 +2182,7 @@ po_status run_layout(po_handle* h, po_result* rows, const po_layout_params& prm,
             res->d_rows = h->spare_edges;
             h->spare_edges = DevBuf();
         }
-        PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_edges * sizeof(po_edge), 256)));
+        PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_edges * sizeof(po_edge), 256), 1.0, false));
         if (n_edges) {
             hipLaunchKernelGGL(po::k_layout_emit, dim3(cdiv(n_rows, 256)), dim3(256), 0, st, d_rows, n_rows, d_len,
                                h->d_rflag.as<uint8_t>(), h->d_ewin.as<uint8_t>(), h->d_eoff.as<uint32_t>(),
@@ -2163,7 +2213,7 @@ po_status run_layout(po_handle* h, po_result* rows, const po_layout_params& prm,
             res->d_rows = h->spare_edges;
             h->spare_edges = DevBuf();
         }
-        PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_edges * sizeof(po_edge), 256)));
+        PO_TRY(ensure(h, res->d_rows, std::max<size_t>(n_edges * sizeof(po_edge), 256), 1.0, false));
         if (n_edges) {
             hipLaunchKernelGGL(po::k_layout_emit, dim3(cdiv(n_rows, 256)), dim3(256), 0, st, d_rows, n_rows, d_len,
                                h->d_rflag.as<uint8_t>(), h->d_ewin.as<uint8_t>(), h->d_eoff.as<uint32_t>(),
@@ -2503,7 +2553,10 @@ void po_destroy(po_handle* h) {
             if (e) (void)hipEventDestroy(e);
         (void)hipEventDestroy(h->ev_up0);
         (void)hipEventDestroy(h->ev_up1);
-        if (h->pinned) (void)hipHostFree(h->pinned);
+        if (h->pinned) {
+            pin_drop(h->pinned);
+            (void)hipHostFree(h->pinned);
+        }
         }
         h->spare_host.release();
         h->scratch_host.release();
@@ -2733,7 +2786,17 @@ po_status po_upload_piece_part(po_handle* h, uint32_t shard, uint32_t nshards, u
     *ok = 1;
     if (!dst_device) return PO_OK;   // (a query: how many words is this part of the shard's piece?)
     if (wc > capacity_words) return fail(h, PO_ERR_INVALID, "po_upload_piece: the piece does not fit the destination");
-    if (wc) HIP_TRY(h, hipMemcpyAsync(dst_device, h->words[0].data() + wb, wc * 8, hipMemcpyHostToDevice, h->stream));
+    if (wc) {
+        // (a store below the registration size is ordinary heap memory: it goes through the page-locked staging block like
+        // every other small source -- handed a pageable pointer the runtime would pin the heap range around it)
+        const void* src = h->words[0].data() + wb;
+        if (!store_is_pinned(h->words[0]) && wc * 8 <= STAGE_MAX) {
+            h->stage_used = 0;   // (no copy is in flight: every path that queued one has synchronised)
+            PO_TRY(ensure_host(h, h->stage_host, wc * 8 + 64));
+            src = staged(h, src, wc * 8);
+        }
+        HIP_TRY(h, hipMemcpyAsync(dst_device, src, wc * 8, hipMemcpyHostToDevice, h->stream));
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->upload_bytes = (part == 0 ? 0 : h->upload_bytes) + wc * 8;
     return PO_OK;
@@ -3970,6 +4033,105 @@ po_status po_get_layout_stats(const po_handle* h, po_layout_stats* out) {
     if (!h || !out) return PO_ERR_INVALID;
     *out = h->lstats;
     return PO_OK;
+}
+
+// ---- diagnostics (tests/checker.py: GuardedReads) ------------------------------------------------------------------
+uint64_t po_debug_host_ranges(uint64_t* out, uint64_t cap_entries) {
+    std::lock_guard<std::mutex> lock(g_pin_mu);
+    const uint64_t n = std::min<uint64_t>(cap_entries, g_pins.size());
+    for (uint64_t i = 0; out && i < n; ++i) {
+        out[3 * i] = g_pins[i].base;
+        out[3 * i + 1] = g_pins[i].bytes;
+        out[3 * i + 2] = g_pins[i].kind;
+    }
+    return g_pins.size();
+}
+
+// SIGSEGV / SIGBUS: the faulting address and the NATIVE stack of the faulting thread to `fd`, then the handler that was
+// installed before (Python's faulthandler prints Python frames only: a store by a runtime thread has none).
+static int g_fault_fd = 2;
+static struct sigaction g_fault_prev[2];
+static void fault_handler(int sig, siginfo_t* si, void* ctx) {
+    char line[128];
+    const int n = std::snprintf(line, sizeof(line), "[phasm] signal %d at address %p (code %d); native stack of the faulting thread:\n", sig,
+                                si ? si->si_addr : nullptr, si ? si->si_code : 0);
+    if (n > 0) (void)!::write(g_fault_fd, line, (size_t)n);
+    void* frames[64];
+    const int k = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, k, g_fault_fd);
+    const struct sigaction& prev = g_fault_prev[sig == SIGBUS ? 1 : 0];
+    if ((prev.sa_flags & SA_SIGINFO) && prev.sa_sigaction) {
+        prev.sa_sigaction(sig, si, ctx);
+        return;
+    }
+    if (prev.sa_handler != SIG_DFL && prev.sa_handler != SIG_IGN && prev.sa_handler) {
+        prev.sa_handler(sig);
+        return;
+    }
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
+int po_debug_fault_backtrace(int fd) {
+    g_fault_fd = fd;
+    struct sigaction sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.sa_sigaction = fault_handler;
+    sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+    sigemptyset(&sa.sa_mask);
+    void* warm[4];
+    (void)backtrace(warm, 4);   // (loads libgcc now, not inside the handler)
+    return (sigaction(SIGSEGV, &sa, &g_fault_prev[0]) == 0 && sigaction(SIGBUS, &sa, &g_fault_prev[1]) == 0) ? 0 : -1;
+}
+
+int po_debug_pointer_info(const void* p, int32_t* hip_type, int32_t* hsa_type, uint64_t* base, uint64_t* bytes) {
+    if (hip_type) *hip_type = -1;
+    if (hsa_type) *hsa_type = -1;
+    if (base) *base = 0;
+    if (bytes) *bytes = 0;
+    if (!p) return 0;
+    int known = 0;
+    {
+        hipPointerAttribute_t at;
+        std::memset(&at, 0, sizeof(at));
+        const hipError_t e = hipPointerGetAttributes(&at, p);
+        if (e == hipSuccess) {
+            if (hip_type) *hip_type = (int32_t)at.type;
+            if (at.type != hipMemoryTypeUnregistered) known = 1;
+        } else {
+            (void)hipGetLastError();   // (an address the runtime has never heard of is an "invalid value" on older runtimes)
+        }
+    }
+    {
+        // the ROCr view: HIP's own pins of pageable copy sources / destinations (hsa_amd_memory_lock) show here too.
+        // Resolved at run time from the HSA runtime the HIP runtime has loaded (this library links to HIP only).
+        struct PtrInfo {   // hsa_amd_pointer_info_t (hsa_ext_amd.h)
+            uint32_t size;
+            uint32_t type;   // 0 unknown, 1 HSA allocation, 2 locked (registered host memory), 3 graphics, 4 IPC
+            void* agentBaseAddress;
+            void* hostBaseAddress;
+            size_t sizeInBytes;
+            void* userData;
+            uint64_t agentOwner;
+            uint32_t global_flags;
+        };
+        using Fn = int (*)(const void*, PtrInfo*, void* (*)(size_t), uint32_t*, void**);
+        static Fn fn = reinterpret_cast<Fn>(dlsym(RTLD_DEFAULT, "hsa_amd_pointer_info"));
+        if (fn) {
+            PtrInfo info;
+            std::memset(&info, 0, sizeof(info));
+            info.size = sizeof(info);
+            if (fn(p, &info, nullptr, nullptr, nullptr) == 0) {
+                if (hsa_type) *hsa_type = (int32_t)info.type;
+                if (info.type != 0) {
+                    known = 1;
+                    if (base) *base = (uint64_t)(uintptr_t)(info.hostBaseAddress ? info.hostBaseAddress : info.agentBaseAddress);
+                    if (bytes) *bytes = info.sizeInBytes;
+                }
+            }
+        }
+    }
+    return known;
 }
 
 po_status po_get_stats(const po_handle* h, po_stats* out) {

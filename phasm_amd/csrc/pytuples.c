@@ -38,6 +38,10 @@ PyObject* po_rows_to_tuples(const void* rows_ptr, uint64_t n, PyObject* ids) {
         PyErr_SetString(PyExc_TypeError, "ids must be a list");
         return NULL;
     }
+    if (!rows && n) {
+        PyErr_SetString(PyExc_ValueError, "null row array with a non-zero row count");
+        return NULL;
+    }
     const Py_ssize_t n_ids = PyList_GET_SIZE(ids);
     PyObject* out = PyList_New((Py_ssize_t)n);
     if (!out) return NULL;

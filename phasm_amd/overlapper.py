@@ -167,6 +167,13 @@ class ExactOverlapper:
         bseq = _to_bytes(seq, "seq")
         _check(self._h, self._lib.po_add_sequence(self._h, bid, len(bid), bseq, len(bseq)))
 
+    def add_sequence_ptr(self, id, address: int, length: int) -> None:
+        """``po_add_sequence`` as the C ABI has it: the sequence is ``length`` bytes at ``address`` (copied, like every
+        sequence: the caller's memory is never written -- the GPU tests hand in a read-only mapping to hold the library
+        to that, tests/checker.py GuardedReads)."""
+        bid = _to_bytes(id, "id")
+        _check(self._h, self._lib.po_add_sequence(self._h, bid, len(bid), ctypes.c_char_p(int(address)), int(length)))
+
     def add_fasta(self, path: str, both_strands: bool = True) -> int:
         """Native FASTA ingest (``po_add_fasta``): every record as ``name+`` / sequence and ``name-`` /
         reverse complement, as ``phasm overlap`` adds them (assembler.py:38-40).  Returns the record count."""
@@ -189,7 +196,10 @@ class ExactOverlapper:
             if fn is not None and len(res):
                 # the list of tuples built natively from the page-locked row array (phasm_amd/csrc/pytuples.c), as
                 # pybind11 builds the reference's from std::vector<OverlapT> (src/phasm.cpp:15)
-                return fn(self._lib.po_result_rows(res._ptr), len(res), ids)
+                p = self._lib.po_result_rows(res._ptr)
+                if not p:   # (a failed device->host copy or page-locked allocation: raise, never hand NULL to the builder)
+                    _check(self._h, _lib.PO_ERR_HIP)
+                return fn(p, len(res), ids)
             arr = res.rows_view()
             a_ids = [ids[i] for i in arr["a_idx"].tolist()]
             b_ids = [ids[i] for i in arr["b_idx"].tolist()]

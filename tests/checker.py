@@ -114,6 +114,146 @@ def explain_difference(got: np.ndarray, want: np.ndarray, seqs: Optional[Sequenc
     return "\n".join(lines)
 
 
+class GuardedReads:
+    """The reads of one GPU parity call, held so that any writer into them is either caught in the act or classified.
+
+    * The bytes live in an anonymous mapping of their own, made READ-ONLY (``mprotect(PROT_READ)``) before the library
+      sees a pointer into it: a CPU store by anything in this process -- the library, the HIP runtime's threads, Python,
+      numpy -- faults AT the store (``faulthandler`` prints every thread's stack, conftest.py).  A change that still
+      appears can only have come from outside the CPU's page protection: a DMA or a device-side store.
+    * ``check_not_gpu_visible``: a DMA or device store needs the page mapped for the GPU.  Every page of the mapping is
+      looked up in the HIP runtime (``hipPointerGetAttributes``) and in ROCr underneath it (``hsa_amd_pointer_info``, which
+      also sees the pins HIP takes by itself for pageable copies) through ``po_debug_pointer_info``; and against the list
+      of every host range the library has EVER pinned or registered in this process (``po_debug_host_ranges``).
+    * ``verify``: the mapping, a heap copy and a digest taken when the reads were made are compared after the call; the
+      message names which of the three changed (mapping changed = DMA / device store; heap copy changed = a stray store
+      into this process's heap).
+    """
+
+    def __init__(self, seqs: Sequence):
+        import ctypes
+        import hashlib
+        import mmap
+        self._plain = _plain(seqs)
+        self._digest = [hashlib.blake2b(s, digest_size=16).digest() for s in self._plain]
+        self._copy = [bytes(bytearray(s)) for s in self._plain]   # (separate heap objects)
+        self._off = []
+        off = 0
+        for s in self._plain:
+            self._off.append(off)
+            off += (len(s) + 7) & ~7   # (8-byte alignment only: reads start anywhere inside their pages, like heap objects)
+        self._size = max(mmap.PAGESIZE, (off + mmap.PAGESIZE - 1) // mmap.PAGESIZE * mmap.PAGESIZE)
+        self._mm = mmap.mmap(-1, self._size, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS, prot=mmap.PROT_READ | mmap.PROT_WRITE)
+        for o, s in zip(self._off, self._plain):
+            self._mm[o:o + len(s)] = s
+        self._anchor = ctypes.c_char.from_buffer(self._mm)
+        self.base = ctypes.addressof(self._anchor)
+        self._libc = ctypes.CDLL(None, use_errno=True)
+        self._libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        if self._libc.mprotect(self.base, self._size, mmap.PROT_READ) != 0:
+            raise OSError(ctypes.get_errno(), "mprotect(PROT_READ)")
+        self._visible_log = []
+
+    def __len__(self) -> int:
+        return len(self._plain)
+
+    def address(self, i: int) -> int:
+        return self.base + self._off[i]
+
+    def length(self, i: int) -> int:
+        return len(self._plain[i])
+
+    def add_all(self, ov, fmt: str = "r%d") -> None:
+        """``po_add_sequence`` for every read, with pointers into the read-only mapping."""
+        for i in range(len(self)):
+            ov.add_sequence_ptr(fmt % i, self.address(i), self.length(i))
+        self.check_not_gpu_visible("after po_add_sequence")
+
+    def check_not_gpu_visible(self, when: str) -> None:
+        import ctypes
+        import mmap
+        from phasm_amd import _lib
+        lib = _lib.load()
+        ht, st = ctypes.c_int32(), ctypes.c_int32()
+        b, n = ctypes.c_uint64(), ctypes.c_uint64()
+        for page in range(self.base, self.base + self._size, mmap.PAGESIZE):
+            if lib.po_debug_pointer_info(ctypes.c_void_p(page), ctypes.byref(ht), ctypes.byref(st), ctypes.byref(b), ctypes.byref(n)):
+                self._visible_log.append((when, page, ht.value, st.value, b.value, n.value))
+        cap = 1 << 16
+        buf = (ctypes.c_uint64 * (3 * cap))()
+        k = min(int(lib.po_debug_host_ranges(buf, cap)), cap)
+        lo, hi = self.base, self.base + self._size
+        for i in range(k):
+            rb, rn, kind = buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]
+            if rb < hi and lo < rb + rn:
+                self._visible_log.append((when, rb, -2, int(kind), rb, rn))
+        if self._visible_log:
+            _evidence("gpu_visible_inputs_%d.txt" % os.getpid(),
+                      "\n".join("%s: page 0x%x hip_type %d hsa_type %d range 0x%x + %d" % e for e in self._visible_log) + "\n")
+            raise AssertionError("pages of the reads handed to po_add_sequence are known to the GPU runtime %s: %r"
+                                 % (when, self._visible_log[:4]))
+
+    def verify(self) -> None:
+        import hashlib
+        self.check_not_gpu_visible("after the call")
+        for i, (o, s) in enumerate(zip(self._off, self._plain)):
+            now = bytes(self._mm[o:o + len(s)])
+            d = self._digest[i]
+            sides = {"read-only mapping (only a DMA / device store gets past PROT_READ)": now,
+                     "heap copy (a stray store into this process's heap)": self._copy[i],
+                     "the test's own object": s}
+            bad = [name for name, v in sides.items() if hashlib.blake2b(v, digest_size=16).digest() != d]
+            if bad:
+                ref = next((v for v in sides.values() if hashlib.blake2b(v, digest_size=16).digest() == d), None)
+                detail = []
+                for name in bad:
+                    v = sides[name]
+                    where = [k for k in range(len(v)) if ref is not None and v[k] != ref[k]]
+                    detail.append("%s: %d byte offsets differ, first %s" % (name, len(where), where[:8]))
+                dump = os.environ.get("PHASM_MISMATCH_DIR")
+                if dump:
+                    os.makedirs(dump, exist_ok=True)
+                    np.savez_compressed(os.path.join(dump, "input_changed_%d.npz" % os.getpid()), index=i,
+                                        mapping=np.frombuffer(now, dtype=np.uint8), heap_copy=np.frombuffer(self._copy[i], dtype=np.uint8),
+                                        original=np.frombuffer(s, dtype=np.uint8))
+                raise AssertionError("host memory of the test process changed under the call: read %d (%d bytes): %s"
+                                     % (i, len(s), "; ".join(detail)))
+
+    def close(self) -> None:
+        if self._mm is not None:
+            self._anchor = None
+            try:
+                self._mm.close()
+            except BufferError:
+                pass
+            self._mm = None
+
+    def verify_and_close(self) -> None:
+        try:
+            self.verify()
+        finally:
+            self.close()
+
+
+def _evidence(name: str, text: str) -> None:
+    dump = os.environ.get("PHASM_MISMATCH_DIR")
+    if dump:
+        os.makedirs(dump, exist_ok=True)
+        with open(os.path.join(dump, name), "a") as fh:
+            fh.write(text)
+
+
+def host_ranges() -> List[tuple]:
+    """Every host range the library has made visible to the GPU in this process: (base, bytes, kind, live)."""
+    import ctypes
+    from phasm_amd import _lib
+    lib = _lib.load()
+    cap = 1 << 16
+    buf = (ctypes.c_uint64 * (3 * cap))()
+    k = min(int(lib.po_debug_host_ranges(buf, cap)), cap)
+    return [(int(buf[3 * i]), int(buf[3 * i + 1]), int(buf[3 * i + 2]) & 0xFF, bool(buf[3 * i + 2] & 0x100)) for i in range(k)]
+
+
 def snapshot(seqs: Sequence) -> List[bytes]:
     """Real copies (separate memory) of the reads a test is about to hand to the library."""
     return [bytes(bytearray(s)) for s in _plain(seqs)]

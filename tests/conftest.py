@@ -19,11 +19,41 @@ def pytest_configure(config):
         # a mismatch of a GPU run leaves its evidence behind (rows of both sides and the reads: tests/checker.py;
         # a read that changed under a call: tests/test_gpu_parity.py) -- gpurun_out/ travels back from the GPU box
         os.environ.setdefault("PHASM_MISMATCH_DIR", os.path.join(ROOT, "gpurun_out", "mismatch"))
+        # a CPU store into a read-only input mapping (tests/checker.py GuardedReads) -- or any other fault -- ends the run with
+        # every thread's Python stack: on stderr, and in a file that travels back from the GPU box
+        import faulthandler
+        global _fault_log
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out", "faults"), exist_ok=True)
+            _fault_log = open(os.path.join(ROOT, "gpurun_out", "faults", "fault_%d.log" % os.getpid()), "w")
+            faulthandler.enable(file=_fault_log, all_threads=True)
+        except OSError:
+            faulthandler.enable(all_threads=True)
+        try:   # ... and the NATIVE stack of the faulting thread (a runtime thread has no Python frames), same file, first
+            from phasm_amd import _lib
+            _lib.load().po_debug_fault_backtrace(_fault_log.fileno() if _fault_log is not None else 2)
+        except Exception:  # noqa: BLE001 -- the library may not be built in a CPU-only session that never loads it
+            pass
+
+
+_fault_log = None
 
 
 def pytest_unconfigure(config):
     import checker
     checker.stop()
+    global _fault_log
+    if _fault_log is not None:   # (no fault: no file)
+        import faulthandler
+        faulthandler.disable()
+        name = _fault_log.name
+        _fault_log.close()
+        _fault_log = None
+        try:
+            if os.path.getsize(name) == 0:
+                os.remove(name)
+        except OSError:
+            pass
 
 
 def _have_gpu() -> bool:

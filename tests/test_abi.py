@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(s[0] for s in _lib.SYMBOLS) == names  # the ctypes table binds exactly the header
-    assert lib.po_abi_version() == 3
+    assert lib.po_abi_version() == 4
 
 
 def test_row_struct_is_24_bytes():

@@ -37,14 +37,13 @@ def dp_kernel(request, monkeypatch):
 
 
 def ex_rows(seqs, m, max_diff, band):
-    snap = ck.snapshot(seqs)
+    guard = ck.GuardedReads(seqs)
     ov = ExactOverlapper()
-    for i, s in enumerate(seqs):
-        ov.add_sequence("r%d" % i, s)
+    guard.add_all(ov)
     arr = ov.overlaps_ex_array(m, max_diff, band)
     st = ov.stats()
     ov.close()
-    ck.assert_inputs_unchanged(seqs, snap)
+    guard.verify_and_close()
     return oo.sort_rows(oo.struct_to_rows(arr)), st
 
 

@@ -20,17 +20,16 @@ _last = {}
 
 def hip_rows(seqs, m, shard=None):
     _last.update(seqs=seqs, m=m)
-    snap = ck.snapshot(seqs)
+    guard = ck.GuardedReads(seqs)   # (the reads in a read-only mapping; pointers into it go to po_add_sequence)
     ov = ExactOverlapper()
-    for i, s in enumerate(seqs):
-        ov.add_sequence("r%d" % i, s)
+    guard.add_all(ov)
     if shard is None:
         arr = ov.overlaps_array(m)
     else:
         arr = np.concatenate([ov.overlaps_shard_array(m, k, shard) for k in range(shard)])
     st = ov.stats()
     ov.close()
-    ck.assert_inputs_unchanged(seqs, snap)
+    guard.verify_and_close()
     return oo.sort_rows(oo.struct_to_rows(arr)), st
 
 

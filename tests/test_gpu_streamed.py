@@ -17,10 +17,9 @@ CUTS = ["", "500", "250,500,750", "100,200,300,400,500,600,700,800,900", "30,60,
 
 
 def streamed_rows(seqs, m, calls=1):
-    snap = ck.snapshot(seqs)
+    guard = ck.GuardedReads(seqs)
     ov = ExactOverlapper()
-    for i, s in enumerate(seqs):
-        ov.add_sequence("r%d" % i, s)
+    guard.add_all(ov)
     out = []
     for _ in range(calls):
         ov.invalidate()
@@ -28,7 +27,7 @@ def streamed_rows(seqs, m, calls=1):
         out.append((oo.sort_rows(oo.struct_to_rows(res.rows_view())), ov.stats()))
         res.free()
     ov.close()
-    ck.assert_inputs_unchanged(seqs, snap)
+    guard.verify_and_close()
     return out
 
 

@@ -129,6 +129,34 @@ def test_streamed_pieces_with_a_predicted_candidate_count(scale, monkeypatch):
         ov.close()
 
 
+def test_classic_tail_switch_on_a_call_that_would_predict(monkeypatch):
+    """PHASM_TAIL_CLASSIC=1 on the SECOND streamed call of a handle: the first call left candidate counts to predict from,
+    but a predicted piece has nothing but the fused tail -- with the switch set no piece may predict, and the classic
+    kernels must see the real count (they once ran unguarded over the predicted capacity)."""
+    monkeypatch.setenv("PHASM_STREAM", "1")
+    monkeypatch.setenv("PHASM_STREAM_CUTS", "250,500,750")
+    monkeypatch.setenv("PHASM_VERIFY_ORDER", "1")
+    for name in ("cfg2_1k", "ladder_varlen"):
+        _, seqs, m, want = gu.ladder_case(name)
+        ov = ExactOverlapper()
+        for i, s in enumerate(seqs):
+            ov.add_sequence("r%d" % i, s)
+        for call_no in range(4):
+            if call_no in (1, 2):
+                monkeypatch.setenv("PHASM_TAIL_CLASSIC", "1")
+            else:
+                monkeypatch.delenv("PHASM_TAIL_CLASSIC", raising=False)
+            rows = oo.sort_rows(oo.struct_to_rows(to_host(ov, m)))
+            st = ov.stats()
+            ck.assert_same_rows(rows, want, seqs, m, "%s call %d" % (name, call_no))
+            assert st["streamed"] == 1 and st["n_rows"] == len(want)
+            if call_no in (1, 2):
+                assert st["n_predicted"] == 0 and st["fused_tail"] == 0, (name, call_no, st)
+            elif call_no == 3:
+                assert st["n_predicted"] > 0 and st["fused_tail"] > 0, (name, call_no, st)
+        ov.close()
+
+
 def test_predicted_pieces_fuzz(monkeypatch):
     """Several streamed calls per handle with the cuts, min_length and the read set changing in between: a prediction
     must be used only for the same reads, cuts and min_length, and a wrong one must never show in the rows."""

@@ -8,6 +8,8 @@
 # (MI355X_MICROARCH.md, rocprofv3 PMC slots); SQ counters go four at a time.
 set -uo pipefail
 OUT="${1:?output directory}"
+CFG="${2:-cfg2}"     # cfg3: the wide index's kernels (k_wide_scan both passes, k_wide_insert, k_wide_chain_fill); the DP and
+                     # layout passes are config-2 / config-4 only
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -19,13 +21,14 @@ run_pass() {   # name, program args..., then counters after '--pmc--'
 }
 P="$ROOT/tools/perf_probe.py"
 L="$ROOT/tools/layout_probe.py"
-run_pass fetch  "$P" --config cfg2 --iters 3 --pmc-- FETCH_SIZE
-run_pass write  "$P" --config cfg2 --iters 3 --pmc-- WRITE_SIZE
-run_pass sq1    "$P" --config cfg2 --iters 3 --pmc-- SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CU_CYCLES
-run_pass sq2    "$P" --config cfg2 --iters 3 --pmc-- SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES
-run_pass sq3    "$P" --config cfg2 --iters 3 --pmc-- SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY
-run_pass sq4    "$P" --config cfg2 --iters 3 --pmc-- SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH
-run_pass tcc    "$P" --config cfg2 --iters 3 --pmc-- TCC_HIT_sum TCC_MISS_sum
+run_pass fetch  "$P" --config "$CFG" --iters 3 --pmc-- FETCH_SIZE
+run_pass write  "$P" --config "$CFG" --iters 3 --pmc-- WRITE_SIZE
+run_pass sq1    "$P" --config "$CFG" --iters 3 --pmc-- SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CU_CYCLES
+run_pass sq2    "$P" --config "$CFG" --iters 3 --pmc-- SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES
+run_pass sq3    "$P" --config "$CFG" --iters 3 --pmc-- SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY
+run_pass sq4    "$P" --config "$CFG" --iters 3 --pmc-- SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH
+run_pass tcc    "$P" --config "$CFG" --iters 3 --pmc-- TCC_HIT_sum TCC_MISS_sum
+if [ "$CFG" != cfg2 ]; then echo done >&2; exit 0; fi
 # config 4 through the banded DP (po_overlaps_ex): where does k_extend_dp spend its cycles?
 # (both mappings: the lane-per-candidate kernel is the default, PHASM_DP_KERNEL=wave selects the wave-per-candidate one)
 run_pass dp_sq1 "$P" --config cfg4 --iters 1 --max-diff 400 --band 8 --pmc-- SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CU_CYCLES

@@ -6,6 +6,9 @@
 //          per SIMD, i.e. cycles per wave64 instruction at the clock the chip holds under that load
 //   lds    ds_read_b64 at random 8-byte-aligned addresses of a 128 KB region (the scan's filter lookups)
 //   l2     global_load_dwordx4 over a footprint that stays in the XCD's L2 (the verify's b side)
+//   lines  global_load_dwordx4 at RANDOM 64-byte lines of a table of 4 MB .. 2 GB, one line per lane (the wide index's
+//          probe: one slot per word of a) or one line per four lanes (the narrow table's group probe) -> lines per second
+//   stream a plain 16-byte-per-lane sweep (the byte count FETCH_SIZE is calibrated against, tools/fetch_calib.sh)
 //
 // Occupancy is pinned with dynamic LDS: a 256-thread workgroup (one wave per SIMD) that asks for 160 KB / w of LDS
 // can only share its CU with w - 1 others.
@@ -106,6 +109,43 @@ __global__ __launch_bounds__(256) void k_l2(const u32x4* __restrict__ buf, uint3
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
 }
 
+
+// ---- random 64-byte lines (VERDICT r3 #3a / #4) ---------------------------------------------------------------------
+// Every lane draws line numbers from its own xorshift stream and loads 16 bytes of the line; LPL lanes share a line
+// (LPL = 1: 64 lines per wave-instruction, what k_wide_scan's table probe issues; LPL = 4: 16 lines per
+// wave-instruction, the four slots of a group in k_scan_probe).  DEPTH independent loads are in flight per lane.
+template <int LPL, int DEPTH>
+__global__ __launch_bounds__(256) void k_rand_lines(const u32x4* __restrict__ table, uint64_t n_lines, uint32_t* out, int iters) {
+    const uint32_t gl = (blockIdx.x * 256u + threadIdx.x) / LPL;   // lanes of one group draw the same numbers
+    uint64_t x = 0x9E3779B97F4A7C15ull * (gl + 1);
+    const uint32_t sub = threadIdx.x % LPL;
+    u32x4 acc = {0, 0, 0, 0};
+    if (threadIdx.x == 1023) dyn_lds[0] = 0;
+    for (int i = 0; i < iters; ++i) {
+        u32x4 v[DEPTH];
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) {
+            x ^= x << 13;
+            x ^= x >> 7;
+            x ^= x << 17;
+            const uint64_t line = (uint64_t)(((__uint128_t)(x & 0xFFFFFFFFFFFFull) * n_lines) >> 48);
+            v[k] = table[line * 4 + sub];
+        }
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) acc ^= v[k];
+    }
+    out[blockIdx.x * 256u + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+}
+
+// 16 bytes per lane, grid-stride, `passes` sweeps over n_vecs vectors
+__global__ __launch_bounds__(256) void k_stream(const u32x4* __restrict__ buf, uint64_t n_vecs, uint32_t* out, int passes) {
+    u32x4 acc = {0, 0, 0, 0};
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (int p = 0; p < passes; ++p)
+        for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n_vecs; i += stride) acc ^= buf[i];
+    out[blockIdx.x * 256u + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+}
+
 static double time_ms(hipEvent_t e0, hipEvent_t e1) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
@@ -195,4 +235,126 @@ double ub_l2(int waves_per_simd, int iters, uint32_t per_xcd_bytes) {
     return (double)grid * 256.0 * (double)iters * 8.0 * 16.0 / (ms * 1e-3);
 }
 
+
+// random 64-byte lines per second, whole chip: table_bytes of table, lanes_per_line 1 or 4, depth 4 or 8 loads in flight
+double ub_rand_lines(uint64_t table_bytes, int waves_per_simd, int iters, int lanes_per_line, int depth) {
+    const int n_cu = 256, rounds = 4;
+    const int grid = n_cu * waves_per_simd * rounds;
+    const size_t lds = (size_t)(160 * 1024) / waves_per_simd - 1024;
+    u32x4* buf = nullptr;
+    uint32_t* out = nullptr;
+    CHECK(hipMalloc(&buf, table_bytes));
+    CHECK(hipMemset(buf, 1, table_bytes));
+    CHECK(hipMalloc(&out, (size_t)grid * 256 * 4));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    void (*kern)(const u32x4*, uint64_t, uint32_t*, int) =
+        lanes_per_line == 4 ? (depth == 4 ? k_rand_lines<4, 4> : k_rand_lines<4, 8>) : (depth == 4 ? k_rand_lines<1, 4> : k_rand_lines<1, 8>);
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t n_lines = table_bytes / 64;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, buf, n_lines, out, iters / 4 + 1);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, buf, n_lines, out, iters);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipDeviceSynchronize());
+    const double ms = time_ms(e0, e1);
+    (void)hipFree(buf);
+    (void)hipFree(out);
+    const int dd = depth == 4 ? 4 : 8;
+    return (double)grid * 256.0 / (lanes_per_line == 4 ? 4.0 : 1.0) * (double)iters * dd / (ms * 1e-3);
+}
+
 }  // extern "C"
+
+#ifdef UBENCH_MAIN
+// FETCH_SIZE calibration (tools/fetch_calib.sh): every pattern once, each its own kernel NAME, with the byte count the
+// pattern requests printed beside it -- `rocprofv3 --pmc FETCH_SIZE` of this program gives the counter per kernel.
+template <int TAG>
+__global__ __launch_bounds__(256) void k_cal_stream(const u32x4* __restrict__ buf, uint64_t n_vecs, uint32_t* out, int passes) {
+    u32x4 acc = {0, 0, 0, 0};
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (int p = 0; p < passes; ++p)
+        for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n_vecs; i += stride) acc ^= buf[i];
+    out[blockIdx.x * 256u + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+}
+template <int TAG, int LPL>
+__global__ __launch_bounds__(256) void k_cal_lines(const u32x4* __restrict__ table, uint64_t n_lines, uint32_t* out, int iters) {
+    const uint32_t gl = (blockIdx.x * 256u + threadIdx.x) / LPL;
+    uint64_t x = 0x9E3779B97F4A7C15ull * (gl + 1);
+    const uint32_t sub = threadIdx.x % LPL;
+    u32x4 acc = {0, 0, 0, 0};
+    for (int i = 0; i < iters; ++i) {
+        u32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            x ^= x << 13;
+            x ^= x >> 7;
+            x ^= x << 17;
+            const uint64_t line = (uint64_t)(((__uint128_t)(x & 0xFFFFFFFFFFFFull) * n_lines) >> 48);
+            v[k] = table[line * 4 + sub];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc ^= v[k];
+    }
+    out[blockIdx.x * 256u + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+}
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+int main() {
+    const uint64_t big = 2ull << 30;
+    u32x4* buf = nullptr;
+    uint32_t* out = nullptr;
+    const int grid = 256 * 8;
+    CK(hipMalloc(&buf, big));
+    CK(hipMemset(buf, 1, big));
+    CK(hipMalloc(&out, (size_t)grid * 256 * 4));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    printf("{\n");
+    auto report = [&](const char* kernel, const char* what, double requests, double bytes_per_request, bool last) {
+        CK(hipEventRecord(e1, 0));
+        CK(hipDeviceSynchronize());
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        printf(" \"%s\": {\"pattern\": \"%s\", \"requests\": %.0f, \"bytes_requested\": %.0f, \"ms\": %.4f, \"requests_per_s\": %.4g, \"GBps\": %.1f}%s\n",
+               kernel, what, requests, requests * bytes_per_request, ms, requests / (ms * 1e-3), requests * bytes_per_request / (ms * 1e-3) / 1e9, last ? "" : ",");
+        return 0;
+    };
+    // (a) streaming 16 B per lane over 2 GiB, once: 2 GiB, nothing resident
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_cal_stream<0>, dim3(grid), dim3(256), 0, 0, buf, big / 16, out, 1);
+    if (report("k_cal_stream<0>", "stream 16 B/lane, 2 GiB once (HBM)", (double)(big / 64), 64.0, false)) return 1;
+    // (b) streaming over 64 MiB, 32 passes: the Infinity Cache holds it after the first pass, the L2s (32 MiB) do not
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_cal_stream<1>, dim3(grid), dim3(256), 0, 0, buf, (64ull << 20) / 16, out, 32);
+    if (report("k_cal_stream<1>", "stream 16 B/lane, 64 MiB x 32 passes (Infinity Cache)", 32.0 * (64ull << 20) / 64, 64.0, false)) return 1;
+    // (c..f) random 64-byte lines, one lane per line (16 B of it loaded), tables of 2 GiB / 512 MiB / 64 MiB / 8 MiB
+    const int iters = 64;
+    const double n_req = (double)grid * 256.0 * iters * 8.0;
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_cal_lines<0, 1>), dim3(grid), dim3(256), 0, 0, buf, big / 64, out, iters);
+    if (report("k_cal_lines<0, 1>", "random 64-B lines, 1 lane per line, 2 GiB table (HBM)", n_req, 64.0, false)) return 1;
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_cal_lines<1, 1>), dim3(grid), dim3(256), 0, 0, buf, (512ull << 20) / 64, out, iters);
+    if (report("k_cal_lines<1, 1>", "random 64-B lines, 1 lane per line, 512 MiB table", n_req, 64.0, false)) return 1;
+    // (warm the 64 MiB table into the Infinity Cache first: the warm-up has its own kernel name)
+    hipLaunchKernelGGL(k_cal_stream<2>, dim3(grid), dim3(256), 0, 0, buf, (64ull << 20) / 16, out, 2);
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_cal_lines<2, 1>), dim3(grid), dim3(256), 0, 0, buf, (64ull << 20) / 64, out, iters);
+    if (report("k_cal_lines<2, 1>", "random 64-B lines, 1 lane per line, 64 MiB table (Infinity Cache)", n_req, 64.0, false)) return 1;
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_cal_lines<3, 1>), dim3(grid), dim3(256), 0, 0, buf, (8ull << 20) / 64, out, iters);
+    if (report("k_cal_lines<3, 1>", "random 64-B lines, 1 lane per line, 8 MiB table (half of it in each XCD's L2)", n_req, 64.0, false)) return 1;
+    // (g, h) four lanes per line (the narrow scan's group probe): 8 MiB and 64 MiB
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_cal_lines<4, 4>), dim3(grid), dim3(256), 0, 0, buf, (8ull << 20) / 64, out, iters);
+    if (report("k_cal_lines<4, 4>", "random 64-B lines, 4 lanes per line, 8 MiB table", n_req / 4, 64.0, false)) return 1;
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_cal_lines<5, 4>), dim3(grid), dim3(256), 0, 0, buf, (64ull << 20) / 64, out, iters);
+    if (report("k_cal_lines<5, 4>", "random 64-B lines, 4 lanes per line, 64 MiB table", n_req / 4, 64.0, true)) return 1;
+    printf("}\n");
+    return 0;
+}
+#endif

@@ -32,7 +32,28 @@ def load():
     lib.ub_lds.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.ub_l2.restype = ctypes.c_double
     lib.ub_l2.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
+    lib.ub_rand_lines.restype = ctypes.c_double
+    lib.ub_rand_lines.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     return lib
+
+
+def measure_lines(quick=False):
+    """Random 64-byte lines per second (whole chip) by table size, lanes per line, loads in flight per lane and waves per
+    SIMD: what a hash-table probe costs on this memory system wherever the table lives (VERDICT r3 #3a)."""
+    lib = load()
+    it = 200 if quick else 1000
+    out = {}
+    for mb in (4, 64, 512, 2048):
+        row = {}
+        for lpl in (1, 4):
+            for depth in (4, 8):
+                for w in ((8,) if quick else (2, 4, 8)):
+                    r = lib.ub_rand_lines(mb << 20, w, it, lpl, depth)
+                    row["lanes_per_line_%d_depth_%d_waves_%d" % (lpl, depth, w)] = round(r / 1e9, 2)
+        row["best_G_lines_per_s_1_lane_per_line"] = max(v for k, v in row.items() if k.startswith("lanes_per_line_1"))
+        row["best_G_lines_per_s_4_lanes_per_line"] = max(v for k, v in row.items() if k.startswith("lanes_per_line_4"))
+        out["%d_MB" % mb] = row
+    return out
 
 
 def measure(quick=False):
@@ -56,15 +77,19 @@ def measure(quick=False):
         out["l2_hit_dwordx4_TBps"]["%d_waves_per_simd" % w] = lib.ub_l2(w, it // 20, 2 << 20) / 1e12
     out["l2_miss_64MB_per_xcd_TBps"] = lib.ub_l2(8, it // 40, 64 << 20) / 1e12
     best = max(v["wave_insts_per_sec_per_simd"] for d in out["valu"].values() for v in d.values())
+    out["random_64B_lines_G_per_s"] = measure_lines(quick)
     out["peaks"] = {"valu_wave_insts_per_sec_per_simd": best,
                     "valu_wave_insts_per_sec_chip": best * 1024,
                     "lds_random_b64_TBps": max(out["lds_random_b64_TBps"].values()),
-                    "l2_hit_TBps": max(out["l2_hit_dwordx4_TBps"].values())}
+                    "l2_hit_TBps": max(out["l2_hit_dwordx4_TBps"].values()),
+                    "random_lines_G_per_s": {k: v["best_G_lines_per_s_1_lane_per_line"] for k, v in out["random_64B_lines_G_per_s"].items()}}
     return out
 
 
 if __name__ == "__main__":
     if "--build" in sys.argv:
         print(build(force=True))
+    elif "--lines" in sys.argv:
+        print(json.dumps(measure_lines("--quick" in sys.argv), indent=1))
     else:
         print(json.dumps(measure("--quick" in sys.argv), indent=1))
