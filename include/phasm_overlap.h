@@ -352,6 +352,13 @@ po_status po_get_layout_stats(const po_handle* h, po_layout_stats* out);
  * the faulting thread to `fd`, then runs whatever handler was installed before it (a store into a read-only input mapping
  * by a thread that has no Python frames -- a runtime thread -- is named this way).  Returns 0 on success. */
 uint64_t po_debug_host_ranges(uint64_t* out, uint64_t cap_entries);
+/* The host half of po_overlaps_to_host's compact row transfer on its own, for tests without a GPU: the rows of `n`
+ * verified-candidate records (po_cand; one per strand-mirror pair when paired != 0), written by the library's helper
+ * threads in the order po_overlaps emits them -- A row, [its mirror], B row, [its mirror] per record (row fields:
+ * src/overlapper.cpp:77-82,104-110; mirror rules: SURVEY.md section 8c).  0 = ok; 1 = the rows differ in number from
+ * n_rows_expected (nothing reliable was written); 2 = a record names a read >= n_reads; -1 = no helper thread. */
+int po_debug_expand_records(const po_cand* records, uint64_t n, const uint32_t* lengths, uint32_t n_reads, uint32_t paired,
+                            po_row* rows_out, uint64_t n_rows_expected);
 int po_debug_fault_backtrace(int fd);
 int po_debug_pointer_info(const void* p, int32_t* hip_type, int32_t* hsa_type, uint64_t* base, uint64_t* bytes);
 

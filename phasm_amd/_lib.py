@@ -126,6 +126,8 @@ SYMBOLS = [
     ("po_get_stats", ctypes.c_int, [_P, ctypes.POINTER(PoStats)]),
     ("po_last_error", ctypes.c_char_p, [_P]),
     ("po_debug_fault_backtrace", ctypes.c_int, [ctypes.c_int]),
+    ("po_debug_expand_records", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                               ctypes.c_void_p, ctypes.c_uint64]),
     ("po_debug_host_ranges", ctypes.c_uint64, [ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64]),
     ("po_debug_pointer_info", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
                                              ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),

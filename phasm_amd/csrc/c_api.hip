@@ -17,9 +17,11 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <mutex>
 #include <new>
@@ -235,6 +237,16 @@ struct po_handle {
     // po_overlaps_to_host: a second stream copies chunk k's rows to the host while chunk k + 1 is computed
     hipStream_t copy_stream = nullptr;
     DevBuf chunk_rows[PO_MAX_PIECES + 1];
+    // rows home in compact form (namespace home): chunk_compact[k] = chunk_rows[k] holds 16-byte records, not rows; the
+    // records land in home_stage (page-locked; a bump allocator that starts over whenever the helper threads have caught up),
+    // ev_home[] are the events behind their copies
+    bool chunk_compact[PO_MAX_PIECES + 1] = {};
+    bool home_on = false;          // this po_overlaps_to_host call hands its rows home as records where the fused tail runs
+    HostBuf home_stage;
+    size_t home_used = 0;
+    uint64_t home_seq = 0;         // pieces submitted to the helper threads by this call
+    uint64_t home_last_bytes = 0;  // record bytes of the previous call (sizes home_stage)
+    hipEvent_t ev_home[PO_MAX_PIECES + 2] = {};
     // streamed step (po_overlaps_to_host on a changed read set): the packed reads cross PCIe piece by piece on
     // up_stream while the pieces that have arrived go through the kernels and their rows travel back
     hipStream_t up_stream = nullptr;
@@ -272,6 +284,7 @@ struct po_handle {
         bool ver_timed = false;
         bool full_events = true;
         bool tail = false;         // the piece's tail ran as k_tail: counts in pinned[zone..], fallback flag in pinned[zone + 7]
+        bool compact = false;      // ... as k_tail_cands: the piece's buffer holds records
         int zone = 48;
         uint32_t cap_c = 0;        // > 0: the candidate count was predicted (real count in pinned[zone + 8])
         hipEvent_t* ev = nullptr;
@@ -338,6 +351,7 @@ struct po_result {
     void* ext_dst = nullptr;
     uint64_t ext_cap = 0;
     bool wrote_ext = false;
+    bool compact = false;   // (inside po_overlaps_to_host only) d_rows holds the verified-candidate records of `count` ROWS
 };
 
 namespace {
@@ -456,6 +470,11 @@ void quiesce_store(po_handle* h) {
 // whenever the read set has grown by half, capped at 4 GB.  A call that needs more grows the array as before.
 po_status init_device(po_handle* h);
 
+inline bool home_enabled() {
+    const char* e = getenv("PHASM_HOME");
+    return !(e && atoi(e) == 0);
+}
+
 void result_pool_grow(po_handle* h) {
     h->pool_bases = h->total_bases + h->total_bases / 2;   // next look when the set has grown by half
     if (getenv("PHASM_NO_POOL")) return;
@@ -475,6 +494,8 @@ void result_pool_grow(po_handle* h) {
     if (hipHostMalloc(&h->spare_host.p, want, hipHostMallocPortable) == hipSuccess) {
         h->spare_host.cap = want;
         pin_note(h->spare_host.p, want, 1u);
+        // the landing block of the compact records (a third of the row bytes), sized with it -- not inside the first call
+        if (home_enabled() && h->home_stage.cap < want / 3) (void)ensure_host(h, h->home_stage, want / 3);
     } else {
         (void)hipGetLastError();
         h->spare_host.p = nullptr;
@@ -498,6 +519,7 @@ struct DevKit {
     hipEvent_t ev_sets[2][EV_N] = {};
     hipEvent_t ev_up0 = nullptr, ev_up1 = nullptr, ev_meta = nullptr, ev_first = nullptr;
     hipEvent_t ev_piece[PO_MAX_PIECES] = {}, ev_rc[PO_MAX_PIECES] = {}, ev_lay[4] = {};
+    hipEvent_t ev_home[PO_MAX_PIECES + 2] = {};
     uint64_t* pinned = nullptr;
     uint64_t* pinned_dev = nullptr;
 };
@@ -523,6 +545,7 @@ bool kit_take(po_handle* h) {
         std::memcpy(h->ev_piece, k.ev_piece, sizeof(k.ev_piece));
         std::memcpy(h->ev_rc, k.ev_rc, sizeof(k.ev_rc));
         std::memcpy(h->ev_lay, k.ev_lay, sizeof(k.ev_lay));
+        std::memcpy(h->ev_home, k.ev_home, sizeof(k.ev_home));
         h->pinned = k.pinned;
         h->pinned_dev = k.pinned_dev;
         return true;
@@ -552,6 +575,7 @@ bool kit_give(po_handle* h) {
     std::memcpy(k.ev_piece, h->ev_piece, sizeof(k.ev_piece));
     std::memcpy(k.ev_rc, h->ev_rc, sizeof(k.ev_rc));
     std::memcpy(k.ev_lay, h->ev_lay, sizeof(k.ev_lay));
+    std::memcpy(k.ev_home, h->ev_home, sizeof(k.ev_home));
     k.pinned = h->pinned;
     k.pinned_dev = h->pinned_dev;
     std::lock_guard<std::mutex> lock(g_kit_mu);
@@ -559,6 +583,228 @@ bool kit_give(po_handle* h) {
     g_kits.push_back(k);
     return true;
 }
+
+
+// ---- rows home in compact form -------------------------------------------------------------------------------------------
+// po_overlaps_to_host used to bring every 24-byte row across PCIe: 168 MB at BASELINE config 2, and the step ended when that
+// copy ended.  Half of those rows are strand mirrors of the other half, and every exact row is a function of {a, p, b, type}
+// and the two read lengths -- the 16-byte verified-candidate record the multi-GPU exchange already uses (po_cand).  So the
+// device hands out one record per strand-mirror pair (k_tail_cands), the records cross PCIe (56 MB at config 2), and host
+// threads write the rows into the page-locked result array while later pieces are still on the device: the same array, byte
+// for byte, that k_tail / k_emit write on the device (rows per record in write_rows' order: A row, [its mirror], B row,
+// [its mirror]; records in candidate order).  SURVEY.md section 8c has the mirror rules; the row fields are those of
+// src/overlapper.cpp:77-82,104-110.
+//
+// One pool per process, threads started at the first use (PHASM_HOME_THREADS, default min(cores, 16); they sleep between
+// calls and spin while a call is active -- a call lasts milliseconds).  Thread 0 takes the pieces in order: it waits for the
+// event behind the piece's device->host copy, then all threads count the rows of the piece's chunks (8192 records each),
+// thread 0 turns the counts into offsets -- and checks the total against what the device counted --, and all threads write.
+namespace home {
+
+constexpr uint32_t CHUNK = 8192;
+
+struct Job {
+    const po::Cand* rec = nullptr;   // page-locked staging memory
+    uint64_t n_rec = 0;
+    po_row* out = nullptr;           // where this piece's rows start in the result array
+    uint64_t n_rows = 0;             // what the device counted for the piece
+    hipEvent_t ready = nullptr;      // recorded behind the device->host copy of rec
+};
+
+struct Pool {
+    std::vector<std::thread> thr;
+    std::mutex mu;                   // queue, sleep / wake
+    std::condition_variable cv;
+    std::mutex call_mu;              // one call at a time uses the pool
+    std::deque<Job> queue;
+    std::atomic<int> active{0};
+    std::atomic<uint64_t> submitted{0}, finished{0};
+    std::atomic<int> error{0};       // 1: counts disagree, 2: a record names an unknown read, 3: the copy's event failed
+    // the call's read set
+    const uint32_t* len = nullptr;
+    uint32_t n_reads = 0, paired = 0;
+    int device = 0;
+    // the piece being expanded
+    Job cur;
+    uint32_t n_chunks = 0;
+    std::vector<uint64_t> chunk_off;
+    std::atomic<uint32_t> next_count{0}, done_count{0}, next_write{0}, done_write{0};
+    std::atomic<int> phase{0};       // 0: none, 1: count, 2: write
+    std::atomic<int> inside{0};      // helper threads inside the current piece's loops
+};
+
+Pool* g_pool = nullptr;
+std::once_flag g_pool_once;
+
+inline void cpu_pause() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+
+inline uint32_t rows_of_rec(const po::Cand& c, uint32_t paired) {
+    if (!paired) return (c.type & 1u) + ((c.type >> 1) & 1u);
+    return ((c.type & 1u) ? (c.a == (c.b ^ 1u) ? 1u : 2u) : 0u) + ((c.type & 2u) ? 2u : 0u);
+}
+
+inline void put_row(uint64_t*& o, uint32_t a, uint32_t b, uint32_t astart, uint32_t aend, uint32_t bend) {
+    // (a row is three 8-byte words; non-temporal stores: the array is written once and read by the caller much later)
+    __builtin_nontemporal_store((uint64_t)a | ((uint64_t)b << 32), o);
+    __builtin_nontemporal_store((uint64_t)astart | ((uint64_t)aend << 32), o + 1);
+    __builtin_nontemporal_store((uint64_t)bend << 32, o + 2);
+    o += 3;
+}
+
+// rows of records [lo, hi) -> out; returns false when a record names a read the handle does not hold
+bool expand_records(const Pool& P, uint64_t lo, uint64_t hi, po_row* out) {
+    uint64_t* o = reinterpret_cast<uint64_t*>(out);
+    const po::Cand* rec = P.cur.rec;
+    const uint32_t* len = P.len;
+    const uint32_t paired = P.paired, n_reads = P.n_reads;
+    for (uint64_t i = lo; i < hi; ++i) {
+        const po::Cand c = rec[i];
+        if (c.a >= n_reads || c.b >= n_reads) return false;
+        const uint32_t la = len[c.a], lb = len[c.b];
+        if (c.type & 1u) {
+            const uint32_t l = la - c.p;
+            put_row(o, c.a, c.b, c.p, la, l);
+            if (paired && c.a != (c.b ^ 1u)) put_row(o, c.b ^ 1u, c.a ^ 1u, lb - l, lb, l);
+        }
+        if (c.type & 2u) {
+            put_row(o, c.a, c.b, c.p, c.p + lb, lb);
+            if (paired) put_row(o, c.a ^ 1u, c.b ^ 1u, la - c.p - lb, la - c.p, lb);
+        }
+    }
+    return true;
+}
+
+void run_phases(Pool& P, bool lead) {
+    const uint32_t nc = P.n_chunks;
+    for (;;) {   // count
+        const uint32_t c = P.next_count.fetch_add(1, std::memory_order_relaxed);
+        if (c >= nc) break;
+        const uint64_t lo = (uint64_t)c * CHUNK, hi = std::min<uint64_t>(P.cur.n_rec, lo + CHUNK);
+        uint64_t n = 0;
+        for (uint64_t i = lo; i < hi; ++i) n += rows_of_rec(P.cur.rec[i], P.paired);
+        P.chunk_off[c + 1] = n;
+        P.done_count.fetch_add(1, std::memory_order_release);
+    }
+    if (lead) {
+        while (P.done_count.load(std::memory_order_acquire) < nc) cpu_pause();
+        P.chunk_off[0] = 0;
+        for (uint32_t c = 0; c < nc; ++c) P.chunk_off[c + 1] += P.chunk_off[c];
+        if (P.chunk_off[nc] != P.cur.n_rows) P.error.store(1);   // (the device counted differently: nothing is written)
+        P.phase.store(P.error.load() ? 0 : 2, std::memory_order_release);
+    } else {
+        while (P.phase.load(std::memory_order_acquire) == 1) cpu_pause();
+    }
+    if (P.phase.load(std::memory_order_acquire) != 2) return;
+    for (;;) {   // write
+        const uint32_t c = P.next_write.fetch_add(1, std::memory_order_relaxed);
+        if (c >= nc) break;
+        const uint64_t lo = (uint64_t)c * CHUNK, hi = std::min<uint64_t>(P.cur.n_rec, lo + CHUNK);
+        if (!expand_records(P, lo, hi, P.cur.out + P.chunk_off[c])) P.error.store(2);
+#if defined(__x86_64__)
+        __builtin_ia32_sfence();   // (non-temporal stores are ordered by sfence only: before the chunk counts as written)
+#endif
+        P.done_write.fetch_add(1, std::memory_order_release);
+    }
+}
+
+void worker(Pool* Pp, unsigned id) {
+    Pool& P = *Pp;
+    bool dev_set = false;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lock(P.mu);
+            P.cv.wait(lock, [&] { return P.active.load() != 0; });
+        }
+        dev_set = false;
+        while (P.active.load(std::memory_order_acquire)) {
+            if (id != 0) {
+                P.inside.fetch_add(1, std::memory_order_acq_rel);
+                if (P.phase.load(std::memory_order_acquire) != 0) run_phases(P, false);
+                P.inside.fetch_sub(1, std::memory_order_release);
+                cpu_pause();
+                continue;
+            }
+            Job j;
+            {
+                std::lock_guard<std::mutex> lock(P.mu);
+                if (P.queue.empty()) {
+                    j.rec = nullptr;
+                } else {
+                    j = P.queue.front();
+                    P.queue.pop_front();
+                }
+            }
+            if (!j.rec) {
+                cpu_pause();
+                continue;
+            }
+            if (!dev_set && j.ready) {
+                (void)hipSetDevice(P.device);
+                dev_set = true;
+            }
+            while (j.ready) {   // the piece's records are home when the event behind their copy has completed
+                const hipError_t e = hipEventQuery(j.ready);
+                if (e == hipSuccess) break;
+                if (e != hipErrorNotReady) {
+                    (void)hipGetLastError();
+                    P.error.store(3);
+                    break;
+                }
+                cpu_pause();
+            }
+            if (P.error.load() == 0 && j.n_rec) {
+                // (no helper is inside the previous piece's loops any more: the counters may be reset)
+                while (P.inside.load(std::memory_order_acquire) != 0) cpu_pause();
+                P.cur = j;
+                P.n_chunks = (uint32_t)((j.n_rec + CHUNK - 1) / CHUNK);
+                if (P.chunk_off.size() < (size_t)P.n_chunks + 1) P.chunk_off.resize((size_t)P.n_chunks + 1);
+                P.next_count.store(0);
+                P.done_count.store(0);
+                P.next_write.store(0);
+                P.done_write.store(0);
+                P.phase.store(1, std::memory_order_release);
+                run_phases(P, true);
+                if (P.phase.load() == 2)
+                    while (P.done_write.load(std::memory_order_acquire) < P.n_chunks) cpu_pause();
+                P.phase.store(0, std::memory_order_release);
+                // (the rows were written with non-temporal stores: make them visible before the piece counts as finished)
+                std::atomic_thread_fence(std::memory_order_seq_cst);
+#if defined(__x86_64__)
+                __builtin_ia32_sfence();
+#endif
+            }
+            P.finished.fetch_add(1, std::memory_order_release);
+        }
+    }
+}
+
+Pool* pool() {
+    std::call_once(g_pool_once, [] {
+        Pool* P = new Pool();
+        unsigned n = std::thread::hardware_concurrency();
+        n = std::max(1u, std::min(n ? n : 4u, 16u));
+        if (const char* e = getenv("PHASM_HOME_THREADS")) n = (unsigned)std::max(1, std::min(64, atoi(e)));
+        try {
+            for (unsigned i = 0; i < n; ++i) {
+                P->thr.emplace_back(worker, P, i);
+                P->thr.back().detach();   // (they sleep until the process ends)
+            }
+        } catch (const std::system_error&) {
+        }
+        if (P->thr.empty()) {
+            delete P;
+            P = nullptr;
+        }
+        g_pool = P;
+    });
+    return g_pool;
+}
+
+}  // namespace home
 
 po_status init_device(po_handle* h) {
     if (h->dev_ready) {
@@ -1529,7 +1775,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         auto fits = [](const DevBuf& b, uint64_t bytes) { return b.p && b.cap >= bytes; };
         async_count = pred > 0 && order && cap < (4u << 20) && cdiv(cap, po::TAIL_TILE) <= po::TAIL_MAX_TILES &&
                       fits(h->d_cand_a, cap * 4) && fits(h->d_cand_p, cap * 4) && fits(h->d_cand_b, cap * 4) && fits(h->d_type, cap) &&
-                      fits(h->d_rowcnt, cap) && fits(h->d_row_off, (cap + 1) * 4) && fits(h->spare_rows, worst * sizeof(po_row)) &&
+                      fits(h->d_rowcnt, cap) && fits(h->d_row_off, (cap + 1) * 4) &&
+                      fits(h->spare_rows, h->home_on ? cap * sizeof(po::Cand) : worst * sizeof(po_row)) &&
                       fits(h->d_vlabel, (uint64_t)(r_end - r_begin) * 4) && fits(h->d_vperm, (uint64_t)(r_end - r_begin) * 4) &&
                       fits(h->d_vrank, (uint64_t)(r_end - r_begin) * 4) && h->dev_words < 0xFFFFFFF0ull;
         cap_c = (uint32_t)cap;
@@ -1785,9 +2032,19 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         // ---- the tail in ONE launch (k_tail: rows per candidate, their prefix sum, the rows, the counters) when the kept
         // row buffer holds the worst case and no global (a, b) table is needed -- or only a gated one: if k_select_local
         // hands a read over after all, k_tail writes nothing but a flag and the classic tail below runs instead
-        const bool can_tail = !want_cands && !dpE && h->spare_rows.p && h->spare_rows.cap >= worst_rows * sizeof(po_row) &&
-                              (!n_selfrep_reads || ((nshards > 1 || streamed || wide) && n_cand < (4u << 20))) &&
-                              cdiv(n_cand, po::TAIL_TILE) <= po::TAIL_MAX_TILES && !getenv("PHASM_TAIL_CLASSIC");
+        // (rows home in compact form -- h->home_on, po_overlaps_to_host -- : the tail writes one 16-byte record per verified
+        // candidate, so its buffer needs n_cand records, not the worst case of rows; a call whose kept buffer is too small
+        // makes one here -- never a piece with a predicted count, whose buffers were checked before anything was launched)
+        const bool home_tail_ok = h->home_on && !want_cands && !dpE && !getenv("PHASM_TAIL_CLASSIC") &&
+                                  (!n_selfrep_reads || ((nshards > 1 || streamed || wide) && n_cand < (4u << 20))) &&
+                                  cdiv(n_cand, po::TAIL_TILE) <= po::TAIL_MAX_TILES;
+        if (home_tail_ok && !async_count && h->spare_rows.cap < (size_t)n_cand * sizeof(po::Cand))
+            PO_TRY(ensure(h, h->spare_rows, (size_t)n_cand * sizeof(po::Cand) + (streamed ? 65536 : 0), 1.0, false));
+        const bool compact_tail = home_tail_ok && h->spare_rows.p && h->spare_rows.cap >= (size_t)n_cand * sizeof(po::Cand);
+        const bool can_tail = compact_tail ||
+                              (!want_cands && !dpE && h->spare_rows.p && h->spare_rows.cap >= worst_rows * sizeof(po_row) &&
+                               (!n_selfrep_reads || ((nshards > 1 || streamed || wide) && n_cand < (4u << 20))) &&
+                               cdiv(n_cand, po::TAIL_TILE) <= po::TAIL_MAX_TILES && !getenv("PHASM_TAIL_CLASSIC"));
         // (a piece with a predicted count has nothing but the fused tail: the classic kernels take the real count from the host)
         if (async_count && !can_tail) return fail(h, PO_ERR_HIP, "internal: a piece with a predicted candidate count needs the fused tail");
         classic_tail = [&]() -> po_status {
@@ -1918,8 +2175,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             uint32_t* tile_rows = h->d_tail_state.as<uint32_t>();
             uint32_t* tail_done = tile_rows + po::TAIL_MAX_TILES;
             const uint32_t* tgate = n_selfrep_reads ? n_deferred : nullptr;
-            hipLaunchKernelGGL(po::k_tile_rows, dim3(n_tt), dim3(po::TAIL_BLOCK), 0, st, A.cand_a, A.cand_b, h->d_type.as<uint8_t>(), n_cand,
-                               paired, tgate, tile_rows, G);
+            hipLaunchKernelGGL(compact_tail ? po::k_tile_rows<true> : po::k_tile_rows<false>, dim3(n_tt), dim3(po::TAIL_BLOCK), 0, st, A.cand_a,
+                               A.cand_b, h->d_type.as<uint8_t>(), n_cand, paired, tgate, tile_rows, G);
             if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
             rows_late = true;
             used_tail = true;
@@ -1929,6 +2186,12 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             tail_zone = async_count ? zone : 48;
             h->pinned[tail_zone] = 0;
             h->pinned[tail_zone + 7] = 0;
+            if (compact_tail) {
+                res->compact = true;
+                hipLaunchKernelGGL(po::k_tail_cands, dim3(n_tt), dim3(po::TAIL_BLOCK), 0, st, A.cand_a, A.cand_p, A.cand_b, h->d_type.as<uint8_t>(),
+                                   n_cand, len, res->d_rows.as<po::Cand>(), (uint32_t)BITS, paired, tgate, tile_rows, n_tt, tail_done,
+                                   scalars + 4, scalars + 3, h->pinned_dev + tail_zone, G);
+            } else
             hipLaunchKernelGGL(po::k_tail, dim3(n_tt), dim3(po::TAIL_BLOCK), 0, st, A.cand_a, A.cand_p, A.cand_b, h->d_type.as<uint8_t>(),
                                n_cand, len, res->d_rows.as<po::Row>(), (uint32_t)BITS, paired, tgate, tile_rows, n_tt, tail_done,
                                scalars + 4, h->pinned_dev + tail_zone, G);
@@ -1940,6 +2203,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             // k_tail found reads handed to the global table: nothing was written -- the classic tail, now
             h->spare_rows = res->d_rows;
             res->d_rows = DevBuf();
+            res->compact = false;
             rows_late = false;
             used_tail = false;
             S.fused_tail = 0;
@@ -1964,6 +2228,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     }
     if (streamed && rows_late && h->st_harvest && !h->st_pend.valid) {
         h->st_pend.tail = used_tail;
+        h->st_pend.compact = res->compact;
         h->st_pend.zone = tail_zone;
         h->st_pend.cap_c = async_count ? cap_c : 0u;
         // a piece of a streamed step with its rows in a buffer known to be large enough: nothing here needs the host
@@ -2551,6 +2816,8 @@ void po_destroy(po_handle* h) {
         for (int i = 0; i < 2 * EV_N; ++i) (void)hipEventDestroy(h->ev_sets[i / EV_N][i % EV_N]);
         for (hipEvent_t e : h->ev_lay)
             if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : h->ev_home)
+            if (e) (void)hipEventDestroy(e);
         (void)hipEventDestroy(h->ev_up0);
         (void)hipEventDestroy(h->ev_up1);
         if (h->pinned) {
@@ -2560,6 +2827,7 @@ void po_destroy(po_handle* h) {
         }
         h->spare_host.release();
         h->scratch_host.release();
+        h->home_stage.release();
         for (DevBuf& b : h->chunk_rows) b.release();
         h->d_first.release();
         h->d_defer.release();
@@ -2590,6 +2858,7 @@ void po_destroy(po_handle* h) {
         }
     }
     h->spare_host.release();   // (the result pool may exist without the handle ever having made a call)
+    h->home_stage.release();
     delete h;
 }
 
@@ -2941,27 +3210,118 @@ struct HostRows {
     uint64_t total = 0;
 };
 
+// ---- the helper threads of a po_overlaps_to_host call (namespace home) ----
+bool home_begin(po_handle* h) {
+    h->home_on = false;
+    if (!home_enabled()) return false;
+    home::Pool* P = home::pool();
+    if (!P) return false;
+    P->call_mu.lock();
+    P->len = h->len.data();
+    P->n_reads = (uint32_t)h->len.size();
+    P->paired = 0;   // (known after the upload: set with the first piece)
+    P->device = h->device;
+    P->error.store(0);
+    P->submitted.store(0);
+    P->finished.store(0);
+    {
+        std::lock_guard<std::mutex> lock(P->mu);
+        P->queue.clear();
+        P->active.store(1);
+    }
+    P->cv.notify_all();
+    h->home_on = true;
+    h->home_used = 0;
+    h->home_seq = 0;
+    return true;
+}
+
+// every piece submitted so far has been expanded (or the pool has stopped on an error)
+void home_wait(po_handle* h) {
+    if (!h->home_on) return;
+    home::Pool* P = home::g_pool;
+    while (P->finished.load(std::memory_order_acquire) < P->submitted.load(std::memory_order_acquire)) home::cpu_pause();
+}
+
+// returns the pool's error code (0 = fine)
+int home_end(po_handle* h) {
+    if (!h->home_on) return 0;
+    home::Pool* P = home::g_pool;
+    home_wait(h);
+    const int err = P->error.load();
+    P->active.store(0, std::memory_order_release);
+    h->home_on = false;
+    P->call_mu.unlock();
+    return err;
+}
+
+// room for `nk` more rows in the page-locked array (first call, or more rows than last time: guess the whole from what has
+// been seen, move what is there).  seen_share (streamed step): the share of all (a, b) index pairs the pieces so far
+// cover -- rows grow with the SQUARE of the reads that have arrived, a linear guess from the first piece is 6 x short
+po_status rows_room(po_handle* h, HostRows& R, uint64_t nk, uint32_t k, uint32_t n_chunks, double seen_share) {
+    const size_t need = (size_t)(R.total + nk) * sizeof(po_row);
+    if (need <= R.hb.cap) return PO_OK;
+    uint64_t guess = std::max<uint64_t>(h->last_host_rows, (R.total + nk) * n_chunks / (k + 1));
+    if (seen_share > 0.0) guess = std::max<uint64_t>(guess, (uint64_t)((double)(R.total + nk) / seen_share * 1.05));
+    HostBuf bigger;
+    PO_TRY(ensure_host(h, bigger, std::max<size_t>(need, (size_t)(guess + guess / 8) * sizeof(po_row))));
+    home_wait(h);   // (helper threads may be writing rows into the old array)
+    if (hipStreamSynchronize(h->copy_stream) != hipSuccess) {
+        bigger.release();
+        return fail(h, PO_ERR_HIP, "copy stream");
+    }
+    if (R.total) std::memcpy(bigger.p, R.hb.p, (size_t)R.total * sizeof(po_row));
+    R.hb.release();
+    R.hb = bigger;
+    return PO_OK;
+}
+
+// the rows of one chunk as RECORDS: their copy on the copy stream into the staging block, an event behind it, and the piece
+// goes to the helper threads, which write its nk rows at R.total
+po_status append_home(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t n_rec, uint64_t nk, uint32_t k, uint32_t n_chunks,
+                      double seen_share = 0.0) {
+    if (nk == 0) return PO_OK;
+    home::Pool* P = home::g_pool;
+    PO_TRY(rows_room(h, R, nk, k, n_chunks, seen_share));
+    const size_t bytes = (size_t)n_rec * sizeof(po::Cand);
+    constexpr uint64_t N_EV = PO_MAX_PIECES + 2;
+    if (h->home_used + bytes > h->home_stage.cap || (h->home_seq && h->home_seq % N_EV == 0)) {
+        // the block is full (or every event has been used once): wait for the helper threads, start over at its beginning
+        home_wait(h);
+        if (hipStreamSynchronize(h->copy_stream) != hipSuccess) return fail(h, PO_ERR_HIP, "copy stream");
+        h->home_used = 0;
+        if (bytes > h->home_stage.cap)
+            PO_TRY(ensure_host(h, h->home_stage, std::max<size_t>({bytes * 2, (size_t)(h->home_last_bytes + h->home_last_bytes / 8), (size_t)8 << 20})));
+    }
+    hipEvent_t& ev = h->ev_home[h->home_seq % N_EV];
+    if (!ev) HIP_TRY(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    char* dst = static_cast<char*>(h->home_stage.p) + h->home_used;
+    HIP_TRY(h, hipMemcpyAsync(dst, dev.p, bytes, hipMemcpyDeviceToHost, h->copy_stream));
+    HIP_TRY(h, hipEventRecord(ev, h->copy_stream));
+    home::Job j;
+    j.rec = reinterpret_cast<const po::Cand*>(dst);
+    j.n_rec = n_rec;
+    j.out = static_cast<po_row*>(R.hb.p) + R.total;
+    j.n_rows = nk;
+    j.ready = ev;
+    P->paired = (h->bits == 2 && h->paired) ? 1u : 0u;
+    {
+        std::lock_guard<std::mutex> lock(P->mu);
+        P->queue.push_back(j);
+    }
+    P->submitted.fetch_add(1, std::memory_order_release);
+    h->home_used += (bytes + 255) & ~size_t(255);
+    h->home_last_bytes += bytes;
+    ++h->home_seq;
+    R.total += nk;
+    return PO_OK;
+}
+
 // rows of one chunk: room in the page-locked array, then the copy on the copy stream (dev must stay untouched
 // until that stream has been synchronised)
 po_status append_rows(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t nk, uint32_t k, uint32_t n_chunks, double seen_share = 0.0) {
     if (nk == 0) return PO_OK;
-    const size_t need = (size_t)(R.total + nk) * sizeof(po_row);
-    if (need > R.hb.cap) {
-        // first call, or more rows than last time: guess the whole from what has been seen, move what is there.
-        // seen_share (streamed step): the share of all (a, b) index pairs the pieces so far cover -- rows grow with the
-        // SQUARE of the reads that have arrived, a linear guess from the first piece is 6 x short
-        uint64_t guess = std::max<uint64_t>(h->last_host_rows, (R.total + nk) * n_chunks / (k + 1));
-        if (seen_share > 0.0) guess = std::max<uint64_t>(guess, (uint64_t)((double)(R.total + nk) / seen_share * 1.05));
-        HostBuf bigger;
-        PO_TRY(ensure_host(h, bigger, std::max<size_t>(need, (size_t)(guess + guess / 8) * sizeof(po_row))));
-        if (hipStreamSynchronize(h->copy_stream) != hipSuccess) {
-            bigger.release();
-            return fail(h, PO_ERR_HIP, "copy stream");
-        }
-        if (R.total) std::memcpy(bigger.p, R.hb.p, (size_t)R.total * sizeof(po_row));
-        R.hb.release();
-        R.hb = bigger;
-    }
+    PO_TRY(rows_room(h, R, nk, k, n_chunks, seen_share));
     HIP_TRY(h, hipMemcpyAsync(static_cast<char*>(R.hb.p) + (size_t)R.total * sizeof(po_row), dev.p, (size_t)nk * sizeof(po_row),
                               hipMemcpyDeviceToHost, h->copy_stream));
     R.total += nk;
@@ -3003,6 +3363,7 @@ po_status run_chunk(po_handle* h, uint32_t min_length, uint32_t k, uint32_t n_ch
     const po_status st = h->bits == 2 ? run_overlaps<2>(h, min_length, k, n_chunks, false, &part)
                                       : run_overlaps<8>(h, min_length, k, n_chunks, false, &part);
     h->chunk_rows[k] = part.d_rows;   // (run_overlaps returned: this chunk's rows are complete on the device)
+    h->chunk_compact[k] = part.compact;
     part.d_rows = DevBuf();
     *nk = part.count;
     return st;
@@ -3195,7 +3556,8 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
         add_stats(sum, S);
         new_pred[k] = S.n_candidates;
         const double seen = (double)bounds[k + 1] / (double)n;
-        PO_TRY(append_rows(h, R, h->chunk_rows[k], nk, k, P, seen * seen));
+        if (h->chunk_compact[k]) PO_TRY(append_home(h, R, h->chunk_rows[k], S.n_verified, nk, k, P, seen * seen));
+        else PO_TRY(append_rows(h, R, h->chunk_rows[k], nk, k, P, seen * seen));
         if (trace) {
             float up = 0;
             (void)hipEventElapsedTime(&up, h->ev_up0, h->ev_piece[k]);
@@ -3362,6 +3724,10 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
             R.hb = h->spare_host;
             h->spare_host = HostBuf();
         }
+        if (st == PO_OK) {
+            (void)home_begin(h);   // rows home as records + helper threads (PHASM_HOME=0: every row crosses PCIe as before)
+            h->home_last_bytes = 0;
+        }
         if (st == PO_OK && stream_eligible(h, min_length)) {
             bool overflow = false;
             st = overlaps_streamed(h, min_length, R, sum, &overflow);
@@ -3371,6 +3737,7 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
             } else if (st == PO_OK) {
                 // (rare: more containments of later reads than the list holds -- the reads are resident now)
                 overflowed = true;
+                home_wait(h);
                 if (hipStreamSynchronize(h->copy_stream) != hipSuccess) st = fail(h, PO_ERR_HIP, "copy stream");
                 R.total = 0;
                 sum = po_stats();
@@ -3382,7 +3749,8 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
             st = run_chunk(h, min_length, k, n_chunks, &nk);
             if (st != PO_OK) break;
             add_stats(sum, h->stats);
-            st = append_rows(h, R, h->chunk_rows[k], nk, k, n_chunks);
+            st = h->chunk_compact[k] ? append_home(h, R, h->chunk_rows[k], h->stats.n_verified, nk, k, n_chunks)
+                                     : append_rows(h, R, h->chunk_rows[k], nk, k, n_chunks);
         }
     } catch (const std::bad_alloc&) {
         st = fail(h, PO_ERR_NOMEM, "out of host memory in po_overlaps_to_host");
@@ -3395,6 +3763,14 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
     if (h->up_stream) (void)hipStreamSynchronize(h->up_stream);
     if (h->rc_stream) (void)hipStreamSynchronize(h->rc_stream);
     if (h->copy_stream && hipStreamSynchronize(h->copy_stream) != hipSuccess && st == PO_OK) st = fail(h, PO_ERR_HIP, "row copy device->host");
+    {
+        // the helper threads have written every piece's rows before the array is handed out (or released)
+        const int herr = home_end(h);
+        if (herr && st == PO_OK)
+            st = fail(h, PO_ERR_HIP, herr == 1 ? "internal: the host's row count of a piece differs from the device's"
+                                     : herr == 2 ? "internal: a verified-candidate record names a read the handle does not hold"
+                                                 : "the event behind a device->host copy of records failed");
+    }
     if (st != PO_OK) {
         R.hb.release();
         delete r;
@@ -4045,6 +4421,54 @@ uint64_t po_debug_host_ranges(uint64_t* out, uint64_t cap_entries) {
         out[3 * i + 2] = g_pins[i].kind;
     }
     return g_pins.size();
+}
+
+// The host half of "rows home in compact form" on its own (no GPU): `n` records -> rows through the helper threads, exactly
+// as po_overlaps_to_host runs them.  Returns 0, or the pool's error code (1 = the rows counted differ from n_rows_expected,
+// 2 = a record names a read >= n_reads), -1 = no helper thread could be started.
+int po_debug_expand_records(const po_cand* records, uint64_t n, const uint32_t* lengths, uint32_t n_reads, uint32_t paired,
+                            po_row* rows_out, uint64_t n_rows_expected) {
+    home::Pool* P = home::pool();
+    if (!P) return -1;
+    std::lock_guard<std::mutex> call(P->call_mu);
+    P->len = lengths;
+    P->n_reads = n_reads;
+    P->paired = paired ? 1u : 0u;
+    P->device = 0;
+    P->error.store(0);
+    P->submitted.store(0);
+    P->finished.store(0);
+    {
+        std::lock_guard<std::mutex> lock(P->mu);
+        P->queue.clear();
+        P->active.store(1);
+    }
+    P->cv.notify_all();
+    // (several pieces, like a streamed step: the records cut into up to five jobs)
+    const uint64_t n_jobs = n ? std::min<uint64_t>(5, (n + 2999) / 3000) : 0;
+    uint64_t row0 = 0;
+    int err = 0;
+    for (uint64_t jn = 0; jn < n_jobs && !err; ++jn) {
+        const uint64_t lo = n * jn / n_jobs, hi = n * (jn + 1) / n_jobs;
+        uint64_t rows = 0;
+        for (uint64_t i = lo; i < hi; ++i) rows += home::rows_of_rec(reinterpret_cast<const po::Cand*>(records)[i], P->paired);
+        if (jn + 1 == n_jobs && row0 + rows != n_rows_expected) rows = n_rows_expected - row0;   // (a wrong expectation must be noticed)
+        home::Job j;
+        j.rec = reinterpret_cast<const po::Cand*>(records) + lo;
+        j.n_rec = hi - lo;
+        j.out = rows_out + row0;
+        j.n_rows = rows;
+        {
+            std::lock_guard<std::mutex> lock(P->mu);
+            P->queue.push_back(j);
+        }
+        P->submitted.fetch_add(1, std::memory_order_release);
+        row0 += rows;
+    }
+    while (P->finished.load(std::memory_order_acquire) < P->submitted.load(std::memory_order_acquire)) home::cpu_pause();
+    err = P->error.load();
+    P->active.store(0, std::memory_order_release);
+    return err;
 }
 
 // SIGSEGV / SIGBUS: the faulting address and the NATIVE stack of the faulting thread to `fd`, then the handler that was

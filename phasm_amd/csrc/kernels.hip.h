@@ -2664,6 +2664,8 @@ constexpr int TAIL_TILE = TAIL_BLOCK * TAIL_ITEMS;
 constexpr uint32_t TAIL_MAX_TILES = 1u << 12;   // (a workgroup sums the tiles before its own: 2 M candidates at most -- a piece
                                                 //  of a streamed step, a shard; a whole-set call of 6.5 M candidates is faster classic)
 
+// COMPACT: the tail hands out verified candidates instead of rows (k_tail_cands): tile_rows[] = verified candidates per tile
+template <bool COMPACT = false>
 __global__ __launch_bounds__(TAIL_BLOCK) void k_tile_rows(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_b,
                                                           const uint8_t* __restrict__ type, uint32_t n_cand, uint32_t paired,
                                                           const uint32_t* __restrict__ gate, uint32_t* __restrict__ tile_rows,
@@ -2681,7 +2683,8 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tile_rows(const uint32_t* __rest
     for (int r = 0; r < TAIL_ITEMS; ++r) {
         const uint32_t i = base + r * TAIL_BLOCK + threadIdx.x;
         const uint32_t t = i < n_cand ? type[i] : 0u;
-        if (t) n += rows_of(t, cand_a[i], cand_b[i], paired);
+        if (COMPACT) n += t != 0u;
+        else if (t) n += rows_of(t, cand_a[i], cand_b[i], paired);
     }
     n = wave_sum(n);
     if (lane_id() == 0) s_part[threadIdx.x >> 6] = n;
@@ -2812,6 +2815,156 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail(const uint32_t* __restrict_
         s_last = atomicAdd(done, 1u) == n_tiles - 1u ? 1u : 0u;
         if (s_last) {
             *done = 0;
+            for (int k = 0; k < 4; ++k) host_out[1 + k] = __hip_atomic_load(&counters[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_out[7] = 0;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// The tail for rows that go home in COMPACT form (po_overlaps_to_host; c_api.hip "rows home"): the verified candidates of
+// the call, compacted in candidate order as 16-byte records {a, p, b, type} -- one per strand-mirror pair in paired mode --
+// instead of their rows (24 bytes each, two to four per record).  Host threads expand them into the page-locked row array
+// as the pieces land (expand_records), bit for bit what write_rows writes: PCIe carries a third of the bytes.
+// tile_recs[] = verified candidates per tile (k_tile_rows<true>).  The row total and the byte counters are summed here
+// exactly as k_tail sums them.
+// host_out: [0] rows, [1] verified candidates = records written, [2] sum l, [3] algorithmic bytes, [4] compared bytes,
+// [7] fallback flag.  rows_ctr: a device counter, zero at launch (scalars[3]).
+// ----------------------------------------------------------------------------------------
+__device__ inline uint32_t row_sums(uint32_t t, uint32_t a, uint32_t p, uint32_t b, uint32_t la, uint32_t lb, uint32_t bits,
+                                    uint32_t paired, uint64_t& suml, uint64_t& sumb, uint64_t& sume) {
+    // (the counter arithmetic of write_rows without the stores)
+    uint32_t n = 0;
+    sume += 2ull * packed_bytes((t & 1u) ? la - p : lb, bits);
+    if (t & 1u) {
+        const uint32_t l = la - p;
+        const uint32_t k = (paired && a != (b ^ 1u)) ? 2u : 1u;
+        suml += (uint64_t)k * l;
+        sumb += (uint64_t)k * 2ull * packed_bytes(l, bits);
+        n += k;
+    }
+    if (t & 2u) {
+        const uint32_t k = paired ? 2u : 1u;
+        suml += (uint64_t)k * lb;
+        sumb += (uint64_t)k * 2ull * packed_bytes(lb, bits);
+        n += k;
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(TAIL_BLOCK) void k_tail_cands(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
+                                                           const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,
+                                                           uint32_t n_cand, const uint32_t* __restrict__ len, Cand* __restrict__ out,
+                                                           uint32_t bits, uint32_t paired, const uint32_t* __restrict__ gate,
+                                                           const uint32_t* __restrict__ tile_recs, uint32_t n_tiles, uint32_t* __restrict__ done,
+                                                           unsigned long long* __restrict__ counters, unsigned long long* __restrict__ rows_ctr,
+                                                           uint64_t* __restrict__ host_out, const CandGuard G) {
+    __shared__ uint32_t s_cnt[TAIL_ITEMS][TAIL_BLOCK / WAVE];
+    __shared__ uint32_t s_pre[TAIL_BLOCK / WAVE];
+    __shared__ uint32_t s_last;
+    if ((gate && *gate != 0u) || G.overflow()) {   // (grid-uniform)
+        if (blockIdx.x == 0 && threadIdx.x == 0) host_out[7] = G.overflow() ? 2 : 1;
+        return;
+    }
+    if (G.n_dev) {   // (predicted count: the grid covers G.cap candidates)
+        n_cand = (uint32_t)*G.n_dev;
+        n_tiles = (n_cand + TAIL_TILE - 1) / TAIL_TILE;
+        if (n_tiles == 0) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                for (int k = 0; k < 5; ++k) host_out[k] = 0;
+                host_out[7] = 0;
+            }
+            return;
+        }
+        if (blockIdx.x >= n_tiles) return;
+    }
+    const uint32_t tile = blockIdx.x;
+    const uint32_t base = tile * TAIL_TILE;
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    uint32_t pre = 0;   // records of the tiles before this one
+    {
+        uint32_t k = threadIdx.x;
+        for (; k + 3 * TAIL_BLOCK < tile; k += 4 * TAIL_BLOCK)
+            pre += tile_recs[k] + tile_recs[k + TAIL_BLOCK] + tile_recs[k + 2 * TAIL_BLOCK] + tile_recs[k + 3 * TAIL_BLOCK];
+        for (; k < tile; k += TAIL_BLOCK) pre += tile_recs[k];
+    }
+    uint32_t t[TAIL_ITEMS], a[TAIL_ITEMS], b[TAIL_ITEMS], pp[TAIL_ITEMS], excl[TAIL_ITEMS];
+#pragma unroll
+    for (int r = 0; r < TAIL_ITEMS; ++r) {
+        const uint32_t i = base + r * TAIL_BLOCK + threadIdx.x;
+        t[r] = i < n_cand ? type[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < TAIL_ITEMS; ++r) {
+        const uint32_t i = base + r * TAIL_BLOCK + threadIdx.x;
+        a[r] = b[r] = pp[r] = 0;
+        if (t[r]) {
+            a[r] = cand_a[i];
+            b[r] = cand_b[i];
+            pp[r] = cand_p[i];
+        }
+    }
+    uint64_t nver = 0, suml = 0, sumb = 0, sume = 0;
+    uint32_t nrows = 0;
+#pragma unroll
+    for (int r = 0; r < TAIL_ITEMS; ++r) {
+        const uint32_t cnt = t[r] ? 1u : 0u;
+        const uint32_t inc = wave_incl_scan(cnt);
+        excl[r] = inc - cnt;
+        if (lane == WAVE - 1) s_cnt[r][wave] = inc;
+        if (t[r]) {
+            nver += 1;
+            nrows += row_sums(t[r], a[r], pp[r], b[r], len[a[r]], len[b[r]], bits, paired, suml, sumb, sume);
+        }
+    }
+    pre = wave_sum(pre);
+    if (lane == 0) s_pre[wave] = pre;
+    __syncthreads();
+    uint32_t pfx = 0, block_total = 0;
+#pragma unroll
+    for (int w = 0; w < TAIL_BLOCK / WAVE; ++w) pfx += s_pre[w];
+#pragma unroll
+    for (int r = 0; r < TAIL_ITEMS; ++r) {
+        uint32_t before = block_total;
+#pragma unroll
+        for (int w = 0; w < TAIL_BLOCK / WAVE; ++w) {
+            if ((uint32_t)w < wave) before += s_cnt[r][w];
+            block_total += s_cnt[r][w];
+        }
+        excl[r] += before;
+    }
+#pragma unroll
+    for (int r = 0; r < TAIL_ITEMS; ++r)
+        if (t[r]) out[pfx + excl[r]] = Cand{a[r], pp[r], b[r], t[r]};
+    {
+        __shared__ uint64_t s_red[5][TAIL_BLOCK / WAVE];
+        nver = wave_sum64(nver);
+        suml = wave_sum64(suml);
+        sumb = wave_sum64(sumb);
+        sume = wave_sum64(sume);
+        const uint64_t nr = wave_sum64((uint64_t)nrows);
+        if (lane == 0) {
+            s_red[0][wave] = nver;
+            s_red[1][wave] = suml;
+            s_red[2][wave] = sumb;
+            s_red[3][wave] = sume;
+            s_red[4][wave] = nr;
+        }
+        __syncthreads();
+        if (threadIdx.x < 5) {
+            uint64_t v = 0;
+            for (int w = 0; w < TAIL_BLOCK / WAVE; ++w) v += s_red[threadIdx.x][w];
+            unsigned long long old = 0;   // (a RETURNING atomic: performed at the coherence point before the done count below, see k_tail)
+            if (v) old = atomicAdd(threadIdx.x < 4 ? &counters[threadIdx.x] : rows_ctr, (unsigned long long)v);
+            asm volatile("" :: "v"((uint32_t)old));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_last = atomicAdd(done, 1u) == n_tiles - 1u ? 1u : 0u;
+        if (s_last) {
+            *done = 0;
+            host_out[0] = __hip_atomic_load(rows_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int k = 0; k < 4; ++k) host_out[1 + k] = __hip_atomic_load(&counters[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             host_out[7] = 0;
         }

@@ -114,6 +114,10 @@ def explain_difference(got: np.ndarray, want: np.ndarray, seqs: Optional[Sequenc
     return "\n".join(lines)
 
 
+# what the guards of a session saw (conftest.py writes it to gpurun_out/guard_summary.json at the end of a GPU session)
+GUARD_TALLY = {"guards": 0, "pages_checked": 0, "reused_addresses_of_freed_pinned_memory": 0, "verified_unchanged": 0}
+
+
 class GuardedReads:
     """The reads of one GPU parity call, held so that any writer into them is either caught in the act or classified.
 
@@ -183,10 +187,18 @@ class GuardedReads:
         buf = (ctypes.c_uint64 * (3 * cap))()
         k = min(int(lib.po_debug_host_ranges(buf, cap)), cap)
         lo, hi = self.base, self.base + self._size
+        reused = False
         for i in range(k):
             rb, rn, kind = buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]
             if rb < hi and lo < rb + rn:
-                self._visible_log.append((when, rb, -2, int(kind), rb, rn))
+                if kind & 0x100:     # a LIVE pinned / registered range of the library covers an input page
+                    self._visible_log.append((when, rb, -2, int(kind), rb, rn))
+                else:                # a range the library has given back: this mapping reuses its addresses (tallied, not an error)
+                    reused = True
+        if when == "after po_add_sequence":
+            GUARD_TALLY["guards"] += 1
+            GUARD_TALLY["pages_checked"] += self._size // mmap.PAGESIZE
+            GUARD_TALLY["reused_addresses_of_freed_pinned_memory"] += int(reused)
         if self._visible_log:
             _evidence("gpu_visible_inputs_%d.txt" % os.getpid(),
                       "\n".join("%s: page 0x%x hip_type %d hsa_type %d range 0x%x + %d" % e for e in self._visible_log) + "\n")
@@ -218,6 +230,7 @@ class GuardedReads:
                                         original=np.frombuffer(s, dtype=np.uint8))
                 raise AssertionError("host memory of the test process changed under the call: read %d (%d bytes): %s"
                                      % (i, len(s), "; ".join(detail)))
+        GUARD_TALLY["verified_unchanged"] += 1
 
     def close(self) -> None:
         if self._mm is not None:

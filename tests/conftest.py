@@ -42,6 +42,17 @@ _fault_log = None
 def pytest_unconfigure(config):
     import checker
     checker.stop()
+    if checker.GUARD_TALLY["guards"]:
+        import json
+        try:
+            ranges = checker.host_ranges()
+            checker.GUARD_TALLY["host_ranges_ever_pinned_by_the_library"] = len(ranges)
+            checker.GUARD_TALLY["host_ranges_live_at_the_end"] = sum(1 for r in ranges if r[3])
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "guard_summary.json"), "w") as fh:
+                json.dump(checker.GUARD_TALLY, fh, indent=1)
+        except Exception:  # noqa: BLE001
+            pass
     global _fault_log
     if _fault_log is not None:   # (no fault: no file)
         import faulthandler
