@@ -201,20 +201,74 @@ def cli_overlap_leg(reads, m: int) -> dict:
         synth.write_fasta(fa, reads)
         env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         t0 = time.perf_counter()
-        p = subprocess.run([sys.executable, "-m", "phasm_amd.cli", "overlap", fa, "-l", str(m), "-o", out],
+        p = subprocess.run([sys.executable, "-m", "phasm_amd.cli", "overlap", "--timing", fa, "-l", str(m), "-o", out],
                            stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, text=True)
         dt = time.perf_counter() - t0
         if p.returncode != 0:
             return {"error": p.stderr[-500:]}
+        stages = None
+        for ln in p.stderr.splitlines():
+            if ln.startswith("PHASM_CLI_TIMING "):
+                stages = json.loads(ln[len("PHASM_CLI_TIMING "):])
+        if stages is not None:
+            stages["process exit + launch overhead (wall - the stages above)"] = round(dt - sum(stages.values()), 4)
         n_e = 0
         with open(out, "rb") as f:
             for chunk in iter(lambda: f.read(1 << 24), b""):
                 n_e += chunk.count(b"\nE\t")
-        return {"cli_overlap_seconds": dt, "fasta_bytes": os.path.getsize(fa), "gfa_bytes": os.path.getsize(out), "e_lines": n_e,
+        return {"cli_overlap_seconds": dt, "stages_seconds": stages, "fasta_bytes": os.path.getsize(fa), "gfa_bytes": os.path.getsize(out), "e_lines": n_e,
                 "note": "wall time of the child process `python -m phasm_amd.cli overlap` (files in /dev/shm): interpreter + GPU runtime start, "
                         "FASTA ingest, one cold po_overlaps call, S and E lines written"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def other_config_leg(dev_idx: int, name: str, m: int, steps: int = 3) -> dict:
+    """Another BASELINE config on ONE GPU, outside the headline's timed region: the host-to-host step (a changed
+    read set: streamed upload, kernels, rows home -- what `value` measures at config 2) and the kernels alone (reads resident,
+    rows left in HBM).  BASELINE.json names configs 3 and 5 for 8 GPUs; this is their single-GPU number."""
+    cfg = synth.CONFIGS[name]
+    t0 = time.time()
+    ov = ExactOverlapper(device=dev_idx)
+    for rname, seq in synth.oriented(synth.generate_reads(cfg)):
+        ov.add_sequence(rname, seq)
+    t_load = time.time() - t0
+    h2h, rows, st = [], 0, {}
+    for it in range(steps + 1):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ov.invalidate()
+        res = ov.overlaps_to_host_result(m)
+        rows = len(res.rows_view())
+        dt = (time.perf_counter() - t1) * 1e3
+        res.free()
+        if it:
+            h2h.append(dt)
+            st = ov.stats()
+    resident = []
+    res_st = {}
+    for it in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        res = ov.overlaps_result(m)
+        n2 = len(res)
+        dt = (time.perf_counter() - t1) * 1e3
+        res.free()
+        if it:
+            resident.append(dt)
+            res_st = ov.stats()
+    assert n2 == rows
+    ov.close()
+    keys = ("ms_index", "ms_scan_count", "ms_scan_fill", "ms_verify", "ms_select", "ms_emit", "ms_total", "ms_scan_probe", "ms_verify_kernel")
+    return {"workload": "%s: %d x %d b error-free reads, %d b %d-ploid genome, both strands, min_overlap %d, ONE GPU"
+                        % (name, cfg.n_reads, cfg.read_len, cfg.genome_len, cfg.ploidy, m),
+            "rows": int(rows), "host_to_host_ms": min(h2h), "host_to_host_ms_all": [round(x, 3) for x in h2h],
+            "overlaps_per_sec": rows / (min(h2h) * 1e-3), "streamed": int(st.get("streamed", 0)), "wide_index": int(st.get("wide_index", 0)),
+            "upload_bytes": int(st.get("upload_bytes", 0)), "upload_ms": st.get("ms_upload"),
+            "resident_ms": min(resident), "resident_overlaps_per_sec": rows / (min(resident) * 1e-3),
+            "resident_stage_ms": {k: round(res_st.get(k, 0.0), 4) for k in keys},
+            "index_reused_in_resident_calls": int(res_st.get("index_reused", 0)),
+            "load_seconds": round(t_load, 1)}
 
 
 def cold_call_leg(dev_idx: int, oriented, m: int, n_handles: int = 3) -> dict:
@@ -310,6 +364,8 @@ def main() -> int:
     ap.add_argument("--no-tuples", action="store_true", help="skip the Python tuple materialisation leg")
     ap.add_argument("--no-stream", action="store_true", help="N=1: upload the whole read set first (po_upload), then call po_overlaps_to_host (the unstreamed form of the step)")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the config-4 leg (exact path + banded DP)")
+    ap.add_argument("--other-configs", default="cfg3", help="comma-separated BASELINE configs run after the headline legs on one GPU "
+                                                           "(host-to-host step and kernels alone; '' = none; cfg5 needs ~60 GB of host memory and ~4 minutes)")
     ap.add_argument("--no-cli", action="store_true", help="skip the `overlap` command leg (a child process: FASTA file in, GFA2 file out)")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-call leg (first call on fresh handles)")
     ap.add_argument("--dist-path", action="store_true",
@@ -678,6 +734,16 @@ def main() -> int:
                 out["cfg4_extension"] = cfg4_leg(dev_idx, m, 400, 8)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(m, args.cpu_sample_reads)
+            if args.other_configs and not args.reads:
+                # (last: the headline's handle is closed first so that the big configs have the GPU's memory to themselves)
+                ov.close()
+                del oriented_once
+                out["other_configs"] = {}
+                for name in [x.strip() for x in args.other_configs.split(",") if x.strip()]:
+                    try:
+                        out["other_configs"][name] = other_config_leg(dev_idx, name, m)
+                    except Exception as e:  # noqa: BLE001 -- the headline line must come out
+                        out["other_configs"][name] = {"error": repr(e)}
     if world > 1 or args.dist_path:
         dist.barrier()
         dist.destroy_process_group()

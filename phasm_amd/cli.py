@@ -38,7 +38,29 @@ from . import layout as layout_mod
 logger = logging.getLogger("phasm_amd")
 
 
+def _seconds_since_process_start() -> float:
+    """Wall time since the kernel started this process (interpreter start and imports included), from /proc."""
+    import os
+    try:
+        with open("/proc/self/stat") as f:
+            start_ticks = int(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as f:
+            up = float(f.read().split()[0])
+        return up - start_ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, IndexError):
+        return float("nan")
+
+
 def overlap(args) -> int:
+    import time
+    marks = [("process start -> overlap() entered (interpreter, imports)", _seconds_since_process_start())]
+    t_prev = [time.perf_counter()]
+
+    def mark(what):
+        now = time.perf_counter()
+        marks.append((what, now - t_prev[0]))
+        t_prev[0] = now
+
     args.output.write(gfa.gfa_header())
     overlapper = ExactOverlapper(device=getattr(args, "device", None))
     logger.info("Packing reads and searching for pairwise overlaps on the GPU...")
@@ -57,12 +79,14 @@ def overlap(args) -> int:
             args.output.write(gfa.gfa_line("S", name, len(seq), "*"))
             overlapper.add_sequence(name + "+", seq)
             overlapper.add_sequence(name + "-", reverse_complement(seq))
+    mark("FASTA ingest + S lines")
     max_diff = int(getattr(args, "max_diff", 0) or 0)
     if max_diff > 0:
         # beyond the reference (which is exact, assembler.py:436-439): banded seed-extension DP, po_overlaps_ex
         res = overlapper.overlaps_ex_result(args.min_length, max_diff, int(getattr(args, "band", 0) or 0))
     else:
         res = overlapper.overlaps_to_host_result(args.min_length)   # rows travel to the host while later chunks are computed
+    mark("the overlap call (upload, kernels, rows home)")
     logger.info("Writing %d overlaps to GFA2...", len(res))
     try:
         try:
@@ -76,6 +100,13 @@ def overlap(args) -> int:
             n = gfa.write_edges(args.output, res.rows(), overlapper.ids())
     finally:
         res.free()
+    mark("E lines formatted and written")
+    args.output.flush()
+    overlapper.close()
+    mark("flush + handle closed")
+    if getattr(args, "timing", False):
+        import json
+        sys.stderr.write("PHASM_CLI_TIMING " + json.dumps({k: round(v, 4) for k, v in marks}) + "\n")
     logger.info("Done.")
     return n
 
@@ -172,6 +203,7 @@ def main(argv=None) -> int:
                    help="Output file (default: stdout)")
     p.add_argument("--device", type=int, default=None, help="HIP device ordinal (default 0)")
     p.add_argument("--python-ingest", action="store_true", help="parse the FASTA in Python instead of po_add_fasta")
+    p.add_argument("--timing", action="store_true", help="print the command's stage times as one JSON line on stderr")
     p.add_argument("--max-diff", type=int, default=0,
                    help="(extension beyond the exact reference) accept overlaps with up to this many differences: banded "
                         "seed-extension DP on the GPU; 0 = exact, the reference's behaviour (default)")

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -4056,86 +4057,145 @@ po_status po_write_gfa_edges(po_result* r, int fd, uint64_t* lines_out) {
     if (r->count == 0) return PO_OK;
     const po_row* rows = po_result_rows(r);
     if (!rows) return PO_ERR_HIP;
-    // Formatting 7 M lines is the long part (0.45 s on one core at config 2): chunks of rows are formatted by a few
-    // threads at a time and written out in order.
-    auto format_chunk = [&](uint64_t lo, uint64_t hi, std::string& buf) -> bool {
-        buf.clear();
-        buf.reserve((size_t)(hi - lo) * 48);
-        auto put_int = [&](long long v) {
-            char tmp[24];
-            int n = 0;
-            bool neg = v < 0;
-            unsigned long long u = neg ? 0ull - (unsigned long long)v : (unsigned long long)v;
-            do {
-                tmp[n++] = (char)('0' + u % 10);
-                u /= 10;
-            } while (u);
-            if (neg) buf.push_back('-');
-            while (n) buf.push_back(tmp[--n]);
-        };
+    // Formatting 7 M lines and copying 324 MB into the file are the long parts of the `overlap` command after the call
+    // itself (0.3-0.4 s at config 2 with a dozen threads appending to std::string and ONE thread writing).  Now: chunks of
+    // 32 k rows are handed out dynamically to up to 16 threads; a thread formats its chunk straight into a buffer sized for
+    // the worst case (two ids + four integers per line, digits from a two-digit table), learns its file offset from the
+    // chunk before it (offsets are published along the chain as the sizes become known) and writes its own bytes with
+    // pwrite -- formatting and the copy into the page cache both run in parallel, the file's bytes are the same.  A
+    // descriptor that cannot seek (a pipe) keeps the ordered write() of whole chunks.
+    size_t max_id = 0;
+    for (const std::string& id : h->ids) max_id = std::max(max_id, id.size());
+    const uint64_t chunk = 1u << 15;
+    const uint64_t n_chunks = (r->count + chunk - 1) / chunk;
+    const size_t line_max = 2 * max_id + 4 * 11 + 16;
+    const off_t base_off = ::lseek(fd, 0, SEEK_CUR);
+    const bool seekable = base_off >= 0;
+    static const char digits2[201] =
+        "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+    auto put_int = [&](char* q, long long v) -> char* {
+        if (v < 0) {
+            *q++ = '-';
+            v = -v;
+        }
+        unsigned long long u = (unsigned long long)v;
+        char tmp[24];
+        int n = 0;
+        while (u >= 100) {
+            const unsigned d = (unsigned)(u % 100) * 2;
+            u /= 100;
+            tmp[n++] = digits2[d + 1];
+            tmp[n++] = digits2[d];
+        }
+        if (u >= 10) {
+            tmp[n++] = digits2[u * 2 + 1];
+            tmp[n++] = digits2[u * 2];
+        } else {
+            tmp[n++] = (char)('0' + u);
+        }
+        while (n) *q++ = tmp[--n];
+        return q;
+    };
+    // one chunk -> buf; returns the bytes written, or -1 when a row names an unknown read
+    auto format_chunk = [&](uint64_t lo, uint64_t hi, char* buf) -> long long {
+        char* q = buf;
+        const size_t n_ids = h->ids.size();
         for (uint64_t i = lo; i < hi; ++i) {
             po_row x;
             if (graph_edges) {
                 // E * u v weight len(u) 0 overlap_len *   (gfa2_write_graph, phasm/io/gfa.py:315-327)
                 const po_edge& e = reinterpret_cast<const po_edge*>(rows)[i];
-                if (e.u >= h->ids.size() || e.v >= h->ids.size()) return false;
+                if (e.u >= n_ids || e.v >= n_ids) return -1;
                 x = po_row{e.u, e.v, e.weight, (int32_t)h->len[e.u], 0, e.overlap_len};
             } else {
                 x = rows[i];
             }
-            if (x.a_idx >= h->ids.size() || x.b_idx >= h->ids.size()) return false;
-            buf.append("E\t*\t");
-            buf.append(h->ids[x.a_idx]);
-            buf.push_back('\t');
-            buf.append(h->ids[x.b_idx]);
-            buf.push_back('\t');
-            put_int(x.astart);
-            buf.push_back('\t');
-            put_int(x.aend);
-            buf.push_back('\t');
-            put_int(x.bstart);
-            buf.push_back('\t');
-            put_int(x.bend);
-            buf.append("\t*\n");
+            if (x.a_idx >= n_ids || x.b_idx >= n_ids) return -1;
+            const std::string &ia = h->ids[x.a_idx], &ib = h->ids[x.b_idx];
+            std::memcpy(q, "E\t*\t", 4);
+            q += 4;
+            std::memcpy(q, ia.data(), ia.size());
+            q += ia.size();
+            *q++ = '\t';
+            std::memcpy(q, ib.data(), ib.size());
+            q += ib.size();
+            *q++ = '\t';
+            q = put_int(q, x.astart);
+            *q++ = '\t';
+            q = put_int(q, x.aend);
+            *q++ = '\t';
+            q = put_int(q, x.bstart);
+            *q++ = '\t';
+            q = put_int(q, x.bend);
+            std::memcpy(q, "\t*\n", 3);
+            q += 3;
         }
-        return true;
+        return (long long)(q - buf);
     };
     try {
-        const uint64_t chunk = 1u << 17;
-        const uint64_t n_chunks = (r->count + chunk - 1) / chunk;
         unsigned hw = std::thread::hardware_concurrency();
-        const unsigned n_thr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw ? hw : 4, 12), n_chunks));
-        std::vector<std::string> bufs(n_thr);
-        std::vector<char> ok(n_thr, 1);
-        for (uint64_t c0 = 0; c0 < n_chunks; c0 += n_thr) {
-            const unsigned live = (unsigned)std::min<uint64_t>(n_thr, n_chunks - c0);
-            std::vector<std::thread> thr;
-            for (unsigned t = 1; t < live; ++t)
-                thr.emplace_back([&, t] {
-                    try {
-                        ok[t] = format_chunk((c0 + t) * chunk, std::min<uint64_t>(r->count, (c0 + t + 1) * chunk), bufs[t]) ? 1 : 0;
-                    } catch (...) {
-                        ok[t] = 0;
-                    }
-                });
-            ok[0] = format_chunk(c0 * chunk, std::min<uint64_t>(r->count, (c0 + 1) * chunk), bufs[0]) ? 1 : 0;
-            for (auto& th : thr) th.join();
-            for (unsigned t = 0; t < live; ++t) {
-                if (!ok[t]) return fail(h, PO_ERR_INVALID, "a row names an unknown read (or out of memory while formatting)");
-                const char* p = bufs[t].data();
-                size_t left = bufs[t].size();
-                while (left) {
-                    ssize_t w = ::write(fd, p, left);
-                    if (w < 0) return fail(h, PO_ERR_INVALID, "write failed");
-                    p += w;
-                    left -= (size_t)w;
-                }
+        const unsigned n_thr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw ? hw : 4, 16), n_chunks));
+        // off[c] = file offset of chunk c (-1 until chunk c - 1 has been formatted); off[n_chunks] = the end
+        std::unique_ptr<std::atomic<long long>[]> off(new std::atomic<long long>[n_chunks + 1]);
+        for (uint64_t c = 0; c <= n_chunks; ++c) off[c].store(-1, std::memory_order_relaxed);
+        off[0].store(seekable ? (long long)base_off : 0);
+        std::atomic<uint64_t> next{0};
+        std::atomic<int> failed{0};   // 1 unknown read, 2 write error, 3 out of memory
+        // a pipe: chunk c may only be written once chunk c - 1 has been (written[c] = done)
+        std::unique_ptr<std::atomic<int>[]> written(new std::atomic<int>[n_chunks + 1]);
+        for (uint64_t c = 0; c <= n_chunks; ++c) written[c].store(c == 0 ? 1 : 0, std::memory_order_relaxed);
+        auto work = [&]() {
+            std::unique_ptr<char[]> buf;
+            try {
+                buf.reset(new char[(size_t)chunk * line_max]);
+            } catch (const std::bad_alloc&) {
+                failed.store(3);
             }
+            for (;;) {
+                const uint64_t c = next.fetch_add(1);
+                if (c >= n_chunks) return;
+                long long n = -1;
+                if (!failed.load()) {
+                    n = format_chunk(c * chunk, std::min<uint64_t>(r->count, (c + 1) * chunk), buf.get());
+                    if (n < 0) failed.store(1);
+                }
+                // (the chain of offsets goes on even after a failure: nobody may wait for ever)
+                long long at;
+                while ((at = off[c].load(std::memory_order_acquire)) < 0) home::cpu_pause();
+                off[c + 1].store(at + std::max<long long>(n, 0), std::memory_order_release);
+                if (!seekable)
+                    while (!written[c].load(std::memory_order_acquire)) home::cpu_pause();
+                if (n > 0 && !failed.load()) {
+                    const char* p = buf.get();
+                    long long left = n, pos = at;
+                    while (left) {
+                        const ssize_t w = seekable ? ::pwrite(fd, p, (size_t)left, (off_t)pos) : ::write(fd, p, (size_t)left);
+                        if (w < 0) {
+                            failed.store(2);
+                            break;
+                        }
+                        p += w;
+                        pos += w;
+                        left -= w;
+                    }
+                }
+                if (!seekable) written[c + 1].store(1, std::memory_order_release);
+            }
+        };
+        std::vector<std::thread> thr;
+        try {
+            for (unsigned t = 1; t < n_thr; ++t) thr.emplace_back(work);
+        } catch (const std::system_error&) {
+            // fewer threads than asked for: carry on with those that started
         }
+        work();
+        for (auto& th : thr) th.join();
+        if (failed.load() == 1) return fail(h, PO_ERR_INVALID, "a row names an unknown read");
+        if (failed.load() == 2) return fail(h, PO_ERR_INVALID, "write failed");
+        if (failed.load() == 3) return fail(h, PO_ERR_NOMEM, "out of host memory");
+        if (seekable && ::lseek(fd, (off_t)off[n_chunks].load(), SEEK_SET) < 0) return fail(h, PO_ERR_INVALID, "lseek failed");
     } catch (const std::bad_alloc&) {
         return fail(h, PO_ERR_NOMEM, "out of host memory");
-    } catch (const std::system_error&) {
-        return fail(h, PO_ERR_NOMEM, "cannot start formatting threads");
     }
     if (lines_out) *lines_out = r->count;
     return PO_OK;

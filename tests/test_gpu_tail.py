@@ -62,22 +62,36 @@ def test_fused_tail_gives_the_golden_rows(form, monkeypatch):
         assert n_fallback > 0                            # ... and the tandem-repeat reads of repeats.npz sent it back
 
 
-def test_classic_and_fused_tails_emit_the_same_array(monkeypatch):
-    """Same emission order, not just the same multiset: the prefix sums are exact either way."""
+@pytest.mark.parametrize("home", ["1", "0"])
+def test_classic_and_fused_tails_emit_the_same_array(home, monkeypatch):
+    """Same emission order, not just the same multiset: the prefix sums are exact either way -- and so is the host's
+    expansion of the compact records (home = 1: po_overlaps_to_host brings one 16-byte record per verified candidate home
+    and helper threads write the rows; home = 0: the device writes the rows and every one of them crosses PCIe).  The
+    row array is the same bytes in all forms."""
+    monkeypatch.setenv("PHASM_HOME", home)
     _, seqs, m, want = gu.ladder_case("cfg2_1k")
     ov = ExactOverlapper()
     for i, s in enumerate(seqs):
         ov.add_sequence("r%d" % i, s)
     first = ov.overlaps_array(m)
-    assert ov.stats()["fused_tail"] == 0
+    # (the record tail needs no kept worst-case row buffer: it runs from the first call on; the row tail from the second)
+    assert ov.stats()["fused_tail"] == (1 if home == "1" else 0)
     second = ov.overlaps_array(m)
     assert ov.stats()["fused_tail"] == 1 and ov.stats()["tail_fallback"] == 0
     monkeypatch.setenv("PHASM_TAIL_CLASSIC", "1")
     monkeypatch.setenv("PHASM_PS_CLASSIC", "1")
     third = ov.overlaps_array(m)
     assert ov.stats()["fused_tail"] == 0
+    monkeypatch.delenv("PHASM_TAIL_CLASSIC")
+    monkeypatch.delenv("PHASM_PS_CLASSIC")
+    monkeypatch.setenv("PHASM_HOME", "0" if home == "1" else "1")     # ... and the other transfer form on the same handle
+    fourth = ov.overlaps_array(m)
+    dev = ov.overlaps_result(m)                                       # the device-resident form (po_overlaps + po_result_rows)
+    fifth = dev.rows()
+    dev.free()
     ov.close()
-    assert np.array_equal(first, second) and np.array_equal(first, third)
+    assert np.array_equal(first, second) and np.array_equal(first, third) and np.array_equal(first, fourth)
+    assert np.array_equal(first, fifth)
     assert np.array_equal(oo.sort_rows(oo.struct_to_rows(first)), want)
 
 
