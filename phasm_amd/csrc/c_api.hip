@@ -476,8 +476,9 @@ inline bool home_enabled() {
     return !(e && atoi(e) == 0);
 }
 
-void result_pool_grow(po_handle* h) {
-    h->pool_bases = h->total_bases + h->total_bases / 2;   // next look when the set has grown by half
+void result_pool_grow(po_handle* h, uint64_t bases = 0) {
+    if (!bases) bases = h->total_bases;   // (bases > 0: an estimate made before the reads are in -- po_add_fasta's warm-up thread)
+    h->pool_bases = bases + bases / 2;   // next look when the set has grown by half
     if (getenv("PHASM_NO_POOL")) return;
     // a read set this size is headed for the GPU: bring the device up now (runtime start, stream, events: 130 ms in a
     // fresh process) rather than inside the first call.  No GPU: the call itself will say so.
@@ -2632,26 +2633,57 @@ inline void trim_seq_line(const char*& p, size_t& n) {
 bool add_fasta_parallel(po_handle* h, const char* data, size_t size, uint64_t* n_records) {
     if (h->bits != 2 || !h->exc_pos.empty()) return false;
     std::vector<FastaRec> recs;
-    {   // pass A: records, in file order
-        size_t pos = 0;
-        bool have = false;
-        while (pos < size) {
-            const char* nl = static_cast<const char*>(std::memchr(data + pos, '\n', size - pos));
-            const size_t len = nl ? (size_t)(nl - (data + pos)) + 1 : size - pos;
-            const char* p = data + pos;
-            size_t n = len;
-            while (n && (p[n - 1] == '\r' || p[n - 1] == '\n')) --n;
-            if (n && p[0] == '>') {
-                if (have) recs.back().seq_end = data + pos;
-                recs.push_back(FastaRec{p + 1, n - 1, data + pos + len, data + size, 0});
-                have = true;
-            } else if (n && have) {
-                size_t m = len;
-                trim_seq_line(p, m);
-                recs.back().seq_len += m;
+    {   // pass A: records, in file order.  The file is cut into ranges; a range's thread takes the records whose header
+        // line STARTS inside the range and follows its last record to the next header (or the end of the file) -- one
+        // thread over the 715 MB of config 2 was 0.15 s of the command's 0.19 s of ingest
+        unsigned hw = std::thread::hardware_concurrency();
+        unsigned n_rng = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(hw ? hw : 4u, 16u), size >> 22));
+        if (const char* e = getenv("PHASM_FASTA_RANGES")) n_rng = (unsigned)std::max(1, std::min(64, atoi(e)));   // (tests: many ranges on small files)
+        if ((size_t)n_rng > size) n_rng = 1;
+        std::vector<std::vector<FastaRec>> part(n_rng);
+        auto scan = [&](unsigned k) {
+            const size_t lo = size / n_rng * k, hi = k + 1 == n_rng ? size : size / n_rng * (k + 1);
+            size_t pos = lo;
+            if (lo) {   // first line start at or after lo
+                const char* nl = static_cast<const char*>(std::memchr(data + lo - 1, '\n', size - (lo - 1)));
+                pos = nl ? (size_t)(nl - data) + 1 : size;
             }
-            pos += len;
+            std::vector<FastaRec>& out = part[k];
+            bool have = false;
+            while (pos < size) {
+                const char* nl = static_cast<const char*>(std::memchr(data + pos, '\n', size - pos));
+                const size_t len = nl ? (size_t)(nl - (data + pos)) + 1 : size - pos;
+                const char* p = data + pos;
+                size_t n = len;
+                while (n && (p[n - 1] == '\r' || p[n - 1] == '\n')) --n;
+                if (n && p[0] == '>') {
+                    if (have) out.back().seq_end = data + pos;
+                    if (pos >= hi) return;   // the next range's first record
+                    out.push_back(FastaRec{p + 1, n - 1, data + pos + len, data + size, 0});
+                    have = true;
+                } else if (n && have) {
+                    size_t m = len;
+                    trim_seq_line(p, m);
+                    out.back().seq_len += m;
+                } else if (!have && pos >= hi) {
+                    return;                  // (no header started in this range)
+                }
+                pos += len;
+            }
+        };
+        std::vector<std::thread> thr;
+        try {
+            for (unsigned k = 1; k < n_rng; ++k) thr.emplace_back(scan, k);
+        } catch (const std::system_error&) {
         }
+        const unsigned started = (unsigned)thr.size() + 1;
+        scan(0);
+        for (auto& th : thr) th.join();
+        for (unsigned k = started; k < n_rng; ++k) scan(k);   // (threads that could not be started)
+        size_t total = 0;
+        for (const auto& v : part) total += v.size();
+        recs.reserve(total);
+        for (auto& v : part) recs.insert(recs.end(), v.begin(), v.end());
     }
     if (recs.empty()) {
         if (n_records) *n_records = 0;
@@ -2924,6 +2956,26 @@ po_status po_add_fasta(po_handle* h, const char* path, int both_strands, uint64_
         if (::fstat(fd, &sb) == 0 && sb.st_size > 0) {
             void* m = ::mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
             if (m != MAP_FAILED) {
+                // A file this size is headed for the GPU: the device comes up (runtime start, streams, events, the first code
+                // object: ~0.15 s in a fresh process) and the page-locked result pool is made WHILE the file is parsed and
+                // packed, not after it -- the `overlap` command is one process and one call (assembler.py:42).  The pool is
+                // sized from the file's size (both strands: at most two oriented bases per byte).
+                std::thread warm;
+                if ((uint64_t)sb.st_size >= (32ull << 20) && !h->dev_ready && !getenv("PHASM_NO_POOL") && !getenv("PHASM_NO_WARM")) {
+                    const uint64_t est_bases = 2ull * (uint64_t)sb.st_size;
+                    try {
+                        warm = std::thread([h, est_bases] {
+                            if (h->total_bases + est_bases >= h->pool_bases) result_pool_grow(h, h->total_bases + est_bases);
+                        });
+                    } catch (const std::system_error&) {
+                    }
+                }
+                struct Joiner {
+                    std::thread& t;
+                    ~Joiner() {
+                        if (t.joinable()) t.join();
+                    }
+                } joiner{warm};
                 try {
                     done = add_fasta_parallel(h, static_cast<const char*>(m), (size_t)sb.st_size, n_records);
                 } catch (const std::bad_alloc&) {

@@ -106,16 +106,20 @@ def test_parallel_and_sequential_fasta_ingest_agree(tmp_path, monkeypatch):
         p = tmp_path / ("r_%d_%d.fa" % (min(width, 999), crlf))
         write(str(p), recs, width, crlf, blanks)
         got = {}
-        for mode in ("parallel", "sequential"):
+        # (the record scan of the parallel path cuts the file into ranges: 1, a few, and more ranges than records per range)
+        for mode in ("parallel", "ranges3", "ranges7", "ranges64", "sequential"):
+            monkeypatch.delenv("PHASM_FASTA_RANGES", raising=False)
             if mode == "sequential":
                 monkeypatch.setenv("PHASM_FASTA_SEQUENTIAL", "1")
             else:
                 monkeypatch.delenv("PHASM_FASTA_SEQUENTIAL", raising=False)
+                if mode.startswith("ranges"):
+                    monkeypatch.setenv("PHASM_FASTA_RANGES", mode[6:])
             ov = ExactOverlapper()
             assert ov.add_fasta(str(p)) == len(recs)
             got[mode] = (ov.ids(), ov.lengths().tolist())
             ov.close()
-        assert got["parallel"] == got["sequential"]
+        assert got["parallel"] == got["sequential"] == got["ranges3"] == got["ranges7"] == got["ranges64"]
         assert got["parallel"][0] == [n + s for n, _ in recs for s in "+-"]
         assert got["parallel"][1] == [len(q) for _, q in recs for _ in "+-"]
     # a file with one N: the parallel path steps aside, the result is the sequential one
@@ -127,4 +131,48 @@ def test_parallel_and_sequential_fasta_ingest_agree(tmp_path, monkeypatch):
     assert ov.add_fasta(str(p)) == len(recs2)
     assert ov.ids() == [n + s for n, _ in recs2 for s in "+-"]
     assert ov.lengths().tolist() == [len(q) for _, q in recs2 for _ in "+-"]
+    ov.close()
+
+
+def test_native_edge_writer_many_chunks_file_and_pipe(tmp_path):
+    """po_write_gfa_edges formats chunks of rows on several threads; into a file every thread writes its own bytes at its
+    own offset (pwrite), into a pipe the chunks go out in order.  Both must be the bytes of the per-row reference format
+    (gfa_line, /root/reference/phasm/io/gfa.py:230-231) -- here on 200 k rows, i.e. several chunks, without a GPU."""
+    import os
+    import threading
+    from phasm_amd.overlapper import ExactOverlapper
+    rng = np.random.default_rng(12)
+    ov = ExactOverlapper()
+    names = ["read %d|x" % i if i % 3 else "r%d" % i for i in range(60)]
+    for i, n in enumerate(names):
+        ov.add_segment(n, 1000 + 17 * i)
+    ids = ov.ids()
+    n = 200_000
+    rows = np.zeros(n, dtype=ROW_DTYPE)
+    rows["a_idx"] = rng.integers(0, len(ids), n)
+    rows["b_idx"] = rng.integers(0, len(ids), n)
+    rows["astart"] = rng.integers(0, 2_000_000_000, n)
+    rows["aend"] = rng.integers(0, 20_000, n)
+    rows["bstart"] = rng.integers(-5, 5, n)           # (negative numbers never occur in overlap rows; the writer takes any int32)
+    rows["bend"] = rng.integers(0, 120, n)
+    res = ov.result_from_rows(rows)
+    py = io.StringIO()
+    gfa.write_edges(py, rows, ids)
+    want = py.getvalue().encode()
+    path = tmp_path / "edges.gfa"
+    with open(path, "w") as f:
+        f.write("H\tVN:z:2.0\n")
+        assert res.write_gfa_edges(f) == n
+        f.write("S\tafter\t1\t*\n")                  # the descriptor's offset stands behind the edges
+    assert path.read_bytes() == b"H\tVN:z:2.0\n" + want + b"S\tafter\t1\t*\n"
+    rd, wr = os.pipe()
+    got = []
+    t = threading.Thread(target=lambda: got.append(b"".join(iter(lambda: os.read(rd, 1 << 20), b""))))
+    t.start()
+    with os.fdopen(wr, "w") as f:
+        assert res.write_gfa_edges(f) == n
+    t.join()
+    os.close(rd)
+    assert got[0] == want
+    res.free()
     ov.close()
