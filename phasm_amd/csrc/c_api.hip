@@ -14,6 +14,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -212,6 +213,7 @@ struct po_handle {
 
     // per-call workspace (grow-only)
     DevBuf d_table, d_slot_cnt, d_slot_cur, d_slot_start, d_read_slot, d_chain, d_chain_tmp, d_long_list;
+    DevBuf d_entry_off;   // wide index: offset o of every (read, phase) entry inside its read (k_wide_insert -> k_wide_chain_fill)
     DevBuf d_bloom, d_selfrep, d_tile_count, d_tile_off, d_truemask, d_ps_blocks, d_scalars, d_left, d_left_cnt, d_tile_extra;
     DevBuf d_cand_a, d_cand_p, d_cand_b, d_type, d_rowcnt, d_row_off, d_flag, d_pair_key, d_pair_min;
     DevBuf d_vlabel, d_vrank, d_vperm;  // verify order (k_read_label, k_read_sort, k_read_invert)
@@ -239,15 +241,15 @@ struct po_handle {
     hipStream_t copy_stream = nullptr;
     DevBuf chunk_rows[PO_MAX_PIECES + 1];
     // rows home in compact form (namespace home): chunk_compact[k] = chunk_rows[k] holds 16-byte records, not rows; the
-    // records land in home_stage (page-locked; a bump allocator that starts over whenever the helper threads have caught up),
-    // ev_home[] are the events behind their copies
+    // records land in home_stage (page-locked; a bump allocator that starts over whenever the helper threads have caught up)
     bool chunk_compact[PO_MAX_PIECES + 1] = {};
     bool home_on = false;          // this po_overlaps_to_host call hands its rows home as records where the fused tail runs
     HostBuf home_stage;
     size_t home_used = 0;
     uint64_t home_seq = 0;         // pieces submitted to the helper threads by this call
+    uint32_t home_gen = 0;         // number written behind a piece's copy (never repeats on a handle's landing zone)
     uint64_t home_last_bytes = 0;  // record bytes of the previous call (sizes home_stage)
-    hipEvent_t ev_home[PO_MAX_PIECES + 2] = {};
+
     // streamed step (po_overlaps_to_host on a changed read set): the packed reads cross PCIe piece by piece on
     // up_stream while the pieces that have arrived go through the kernels and their rows travel back
     hipStream_t up_stream = nullptr;
@@ -307,7 +309,7 @@ struct po_handle {
     uint64_t upload_gen = 0;
     bool idx_valid = false;
     uint64_t idx_gen = 0;
-    uint32_t idx_m = 0, idx_tbits = 0, idx_bits = 0;
+    uint32_t idx_m = 0, idx_tbits = 0, idx_bits = 0, idx_ww = 0;
     bool idx_wide = false;
     // sliced wide index (multi-GPU, phasm_amd/dist.py IndexExchange): sl_build_n > 1 makes run_overlaps stop after it has
     // built sub-table sl_build_slice; ext_index makes it probe a gathered sliced index instead of building one
@@ -521,7 +523,7 @@ struct DevKit {
     hipEvent_t ev_sets[2][EV_N] = {};
     hipEvent_t ev_up0 = nullptr, ev_up1 = nullptr, ev_meta = nullptr, ev_first = nullptr;
     hipEvent_t ev_piece[PO_MAX_PIECES] = {}, ev_rc[PO_MAX_PIECES] = {}, ev_lay[4] = {};
-    hipEvent_t ev_home[PO_MAX_PIECES + 2] = {};
+
     uint64_t* pinned = nullptr;
     uint64_t* pinned_dev = nullptr;
 };
@@ -547,7 +549,6 @@ bool kit_take(po_handle* h) {
         std::memcpy(h->ev_piece, k.ev_piece, sizeof(k.ev_piece));
         std::memcpy(h->ev_rc, k.ev_rc, sizeof(k.ev_rc));
         std::memcpy(h->ev_lay, k.ev_lay, sizeof(k.ev_lay));
-        std::memcpy(h->ev_home, k.ev_home, sizeof(k.ev_home));
         h->pinned = k.pinned;
         h->pinned_dev = k.pinned_dev;
         return true;
@@ -577,7 +578,6 @@ bool kit_give(po_handle* h) {
     std::memcpy(k.ev_piece, h->ev_piece, sizeof(k.ev_piece));
     std::memcpy(k.ev_rc, h->ev_rc, sizeof(k.ev_rc));
     std::memcpy(k.ev_lay, h->ev_lay, sizeof(k.ev_lay));
-    std::memcpy(k.ev_home, h->ev_home, sizeof(k.ev_home));
     k.pinned = h->pinned;
     k.pinned_dev = h->pinned_dev;
     std::lock_guard<std::mutex> lock(g_kit_mu);
@@ -603,36 +603,44 @@ bool kit_give(po_handle* h) {
 // thread 0 turns the counts into offsets -- and checks the total against what the device counted --, and all threads write.
 namespace home {
 
-constexpr uint32_t CHUNK = 8192;
+constexpr uint32_t CHUNK = 4096;
 
 struct Job {
     const po::Cand* rec = nullptr;   // page-locked staging memory
     uint64_t n_rec = 0;
     po_row* out = nullptr;           // where this piece's rows start in the result array
     uint64_t n_rows = 0;             // what the device counted for the piece
-    hipEvent_t ready = nullptr;      // recorded behind the device->host copy of rec
+    // the piece's records are home when *flag == want: a one-thread kernel queued behind their device->host copy on the
+    // copy stream writes `want` into page-locked memory (polling a word costs the caller's launches nothing; polling
+    // hipEventQuery takes the runtime's locks on every call).  flag == nullptr: the records are there already.
+    const volatile uint32_t* flag = nullptr;
+    uint32_t want = 0;
 };
 
 struct Pool {
     std::vector<std::thread> thr;
-    std::mutex mu;                   // queue, sleep / wake
-    std::condition_variable cv;
+    std::mutex mu;                   // queue, job hand-over, sleep / wake
+    std::condition_variable cv_queue;   // thread 0: a piece was submitted
+    std::condition_variable cv_job;     // helpers: a piece was published
     std::mutex call_mu;              // one call at a time uses the pool
     std::deque<Job> queue;
-    std::atomic<int> active{0};
     std::atomic<uint64_t> submitted{0}, finished{0};
-    std::atomic<int> error{0};       // 1: counts disagree, 2: a record names an unknown read, 3: the copy's event failed
+    std::atomic<int> error{0};       // 1: counts disagree, 2: a record names an unknown read
     // the call's read set
     const uint32_t* len = nullptr;
     uint32_t n_reads = 0, paired = 0;
-    int device = 0;
     // the piece being expanded
     Job cur;
+    uint64_t job_seq = 0;            // (under mu) pieces published so far
     uint32_t n_chunks = 0;
     std::vector<uint64_t> chunk_off;
     std::atomic<uint32_t> next_count{0}, done_count{0}, next_write{0}, done_write{0};
     std::atomic<int> phase{0};       // 0: none, 1: count, 2: write
     std::atomic<int> inside{0};      // helper threads inside the current piece's loops
+    // PHASM_STREAM_TRACE: per piece, microseconds since the call began -- records home / rows written
+    std::chrono::steady_clock::time_point t0;
+    std::vector<std::array<double, 3>> trace;   // {ready, done, rows}
+    bool tracing = false;
 };
 
 Pool* g_pool = nullptr;
@@ -680,6 +688,8 @@ bool expand_records(const Pool& P, uint64_t lo, uint64_t hi, po_row* out) {
     return true;
 }
 
+// the two passes over the current piece; `lead` (thread 0) turns the counts into offsets between them.  A piece is
+// 50-400 us of work for the pool: inside it the threads spin, between pieces they sleep.
 void run_phases(Pool& P, bool lead) {
     const uint32_t nc = P.n_chunks;
     for (;;) {   // count
@@ -713,87 +723,77 @@ void run_phases(Pool& P, bool lead) {
     }
 }
 
-void worker(Pool* Pp, unsigned id) {
+void helper(Pool* Pp) {
     Pool& P = *Pp;
-    bool dev_set = false;
+    uint64_t seen = 0;
     for (;;) {
         {
             std::unique_lock<std::mutex> lock(P.mu);
-            P.cv.wait(lock, [&] { return P.active.load() != 0; });
+            P.cv_job.wait(lock, [&] { return P.job_seq != seen; });
+            seen = P.job_seq;
         }
-        dev_set = false;
-        while (P.active.load(std::memory_order_acquire)) {
-            if (id != 0) {
-                P.inside.fetch_add(1, std::memory_order_acq_rel);
-                if (P.phase.load(std::memory_order_acquire) != 0) run_phases(P, false);
-                P.inside.fetch_sub(1, std::memory_order_release);
-                cpu_pause();
-                continue;
-            }
-            Job j;
+        P.inside.fetch_add(1, std::memory_order_acq_rel);
+        if (P.phase.load(std::memory_order_acquire) != 0) run_phases(P, false);
+        P.inside.fetch_sub(1, std::memory_order_release);
+    }
+}
+
+void leader(Pool* Pp) {
+    Pool& P = *Pp;
+    for (;;) {
+        Job j;
+        {
+            std::unique_lock<std::mutex> lock(P.mu);
+            P.cv_queue.wait(lock, [&] { return !P.queue.empty(); });
+            j = P.queue.front();
+            P.queue.pop_front();
+        }
+        if (j.flag)   // the records are home when the word behind their copy has arrived
+            while (*j.flag != j.want) cpu_pause();
+        std::atomic_thread_fence(std::memory_order_acquire);
+        const double t_ready = P.tracing ? std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - P.t0).count() : 0.0;
+        if (P.error.load() == 0 && j.n_rec) {
+            // (no helper is inside the previous piece's loops any more: the counters may be reset)
+            while (P.inside.load(std::memory_order_acquire) != 0) cpu_pause();
+            P.cur = j;
+            P.n_chunks = (uint32_t)((j.n_rec + CHUNK - 1) / CHUNK);
+            if (P.chunk_off.size() < (size_t)P.n_chunks + 1) P.chunk_off.resize((size_t)P.n_chunks + 1);
+            P.next_count.store(0);
+            P.done_count.store(0);
+            P.next_write.store(0);
+            P.done_write.store(0);
+            P.phase.store(1, std::memory_order_release);
             {
                 std::lock_guard<std::mutex> lock(P.mu);
-                if (P.queue.empty()) {
-                    j.rec = nullptr;
-                } else {
-                    j = P.queue.front();
-                    P.queue.pop_front();
-                }
+                ++P.job_seq;
             }
-            if (!j.rec) {
-                cpu_pause();
-                continue;
-            }
-            if (!dev_set && j.ready) {
-                (void)hipSetDevice(P.device);
-                dev_set = true;
-            }
-            while (j.ready) {   // the piece's records are home when the event behind their copy has completed
-                const hipError_t e = hipEventQuery(j.ready);
-                if (e == hipSuccess) break;
-                if (e != hipErrorNotReady) {
-                    (void)hipGetLastError();
-                    P.error.store(3);
-                    break;
-                }
-                cpu_pause();
-            }
-            if (P.error.load() == 0 && j.n_rec) {
-                // (no helper is inside the previous piece's loops any more: the counters may be reset)
-                while (P.inside.load(std::memory_order_acquire) != 0) cpu_pause();
-                P.cur = j;
-                P.n_chunks = (uint32_t)((j.n_rec + CHUNK - 1) / CHUNK);
-                if (P.chunk_off.size() < (size_t)P.n_chunks + 1) P.chunk_off.resize((size_t)P.n_chunks + 1);
-                P.next_count.store(0);
-                P.done_count.store(0);
-                P.next_write.store(0);
-                P.done_write.store(0);
-                P.phase.store(1, std::memory_order_release);
-                run_phases(P, true);
-                if (P.phase.load() == 2)
-                    while (P.done_write.load(std::memory_order_acquire) < P.n_chunks) cpu_pause();
-                P.phase.store(0, std::memory_order_release);
-                // (the rows were written with non-temporal stores: make them visible before the piece counts as finished)
-                std::atomic_thread_fence(std::memory_order_seq_cst);
-#if defined(__x86_64__)
-                __builtin_ia32_sfence();
-#endif
-            }
-            P.finished.fetch_add(1, std::memory_order_release);
+            P.cv_job.notify_all();
+            run_phases(P, true);
+            if (P.phase.load() == 2)
+                while (P.done_write.load(std::memory_order_acquire) < P.n_chunks) cpu_pause();
+            P.phase.store(0, std::memory_order_release);
+            std::atomic_thread_fence(std::memory_order_seq_cst);
         }
+        if (P.tracing)
+            P.trace.push_back({t_ready, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - P.t0).count(), (double)j.n_rows});
+        P.finished.fetch_add(1, std::memory_order_release);
     }
 }
 
 Pool* pool() {
     std::call_once(g_pool_once, [] {
         Pool* P = new Pool();
+        // (a GPU box gives one GPU's process a share of the host's cores: the pool stays well inside it -- the caller's
+        // thread and the HIP runtime's own threads need cores too, and threads beyond the share would stall everyone)
         unsigned n = std::thread::hardware_concurrency();
-        n = std::max(1u, std::min(n ? n : 4u, 16u));
+        n = std::max(1u, std::min(n ? n / 2 : 4u, 10u));
         if (const char* e = getenv("PHASM_HOME_THREADS")) n = (unsigned)std::max(1, std::min(64, atoi(e)));
         try {
-            for (unsigned i = 0; i < n; ++i) {
-                P->thr.emplace_back(worker, P, i);
-                P->thr.back().detach();   // (they sleep until the process ends)
+            P->thr.emplace_back(leader, P);
+            P->thr.back().detach();   // (they sleep until the process ends)
+            for (unsigned i = 1; i < n; ++i) {
+                P->thr.emplace_back(helper, P);
+                P->thr.back().detach();
             }
         } catch (const std::system_error&) {
         }
@@ -804,6 +804,32 @@ Pool* pool() {
         g_pool = P;
     });
     return g_pool;
+}
+
+void begin(Pool* P, const uint32_t* len, uint32_t n_reads, bool tracing) {
+    P->len = len;
+    P->n_reads = n_reads;
+    P->paired = 0;
+    P->error.store(0);
+    P->submitted.store(0);
+    P->finished.store(0);
+    P->tracing = tracing;
+    P->trace.clear();
+    P->t0 = std::chrono::steady_clock::now();
+}
+
+void submit(Pool* P, const Job& j) {
+    {
+        std::lock_guard<std::mutex> lock(P->mu);
+        P->queue.push_back(j);
+    }
+    P->submitted.fetch_add(1, std::memory_order_release);
+    P->cv_queue.notify_one();
+}
+
+void wait_all(Pool* P) {
+    // (the caller has nothing else to do: it spins -- the last piece's rows are what the call is waiting for)
+    while (P->finished.load(std::memory_order_acquire) < P->submitted.load(std::memory_order_acquire)) cpu_pause();
 }
 
 }  // namespace home
@@ -1477,6 +1503,17 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         if (!strcmp(e, "narrow")) wide = false;
     }
     S.wide_index = wide ? 1u : 0u;
+    // wide index: window of the minimiser scheme (kernels.hip.h WideEnc) -- the largest of 16 / 4 / 1 words with
+    // W ww + W - 1 <= min_length.  The streamed step keeps 1: its index is built from the first two words of every read,
+    // which travel ahead of the pieces.  PHASM_WIDE_WINDOW=1|4|16 forces a smaller one (tests, A/B).
+    uint32_t ww = 1;
+    if (wide && BITS == 2 && !streamed) {
+        ww = m >= W * 16 + W - 1 ? 16u : m >= W * 4 + W - 1 ? 4u : 1u;
+        if (const char* e = getenv("PHASM_WIDE_WINDOW")) {
+            const uint32_t v = (uint32_t)atoi(e);
+            if ((v == 1 || v == 4 || v == 16) && v <= ww) ww = v;
+        }
+    }
     bool WA_ext = false;
     const bool slice_build = h->sl_build_n > 1;     // build one sub-table of the sliced wide index, then stop
     const bool ext_idx = h->ext_index != nullptr;   // probe a gathered sliced index
@@ -1525,6 +1562,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         PO_TRY(ensure(h, h->d_chain, std::min(chain_entries, n_entries) * chain_elem));
         PO_TRY(ensure(h, h->d_chain_tmp, std::min(chain_entries, n_entries) * chain_elem));
         PO_TRY(ensure(h, h->d_long_list, (size_t)nslots * 4));
+        if (wide) PO_TRY(ensure(h, h->d_entry_off, n_entries * 2));
     }
     PO_TRY(ensure(h, h->d_bloom, bloom_bytes));
     PO_TRY(ensure(h, h->d_selfrep, (size_t)n * 4));
@@ -1566,7 +1604,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     }
     HIP_TRY(h, hipEventRecord(h->ev[EV_START], st));
     const bool reuse_index = !slice_build && !ext_idx && h->idx_valid && h->idx_gen == h->upload_gen && h->idx_m == m &&
-                             h->idx_wide == wide && h->idx_tbits == tbits && h->idx_bits == (uint32_t)BITS && h->poison < 0 &&
+                             h->idx_wide == wide && h->idx_tbits == tbits && h->idx_bits == (uint32_t)BITS && h->idx_ww == ww && h->poison < 0 &&
                              !getenv("PHASM_NO_INDEX_REUSE");
     S.index_reused = reuse_index ? 1u : 0u;
     h->idx_valid = false;
@@ -1596,8 +1634,12 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         hipLaunchKernelGGL(po::k_table_finalize, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt,
                            slot_start, chain, len);
     } else {
-        hipLaunchKernelGGL(po::k_wide_insert<BITS>, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, words, woff, len, n, m,
-                           table, tbits, slot_cnt, read_slot, slice_build ? h->sl_build_n : 1u, h->sl_build_slice);
+        uint16_t* entry_off = h->d_entry_off.as<uint16_t>();
+        auto k_ins = ww == 16 ? po::k_wide_insert<BITS, 16> : ww == 4 ? po::k_wide_insert<BITS, 4> : po::k_wide_insert<BITS, 1>;
+        auto k_cfill = ww == 16 ? po::k_wide_chain_fill<BITS, 16> : ww == 4 ? po::k_wide_chain_fill<BITS, 4> : po::k_wide_chain_fill<BITS, 1>;
+        auto k_fin = ww == 16 ? po::k_wide_finalize<BITS, 16> : ww == 4 ? po::k_wide_finalize<BITS, 4> : po::k_wide_finalize<BITS, 1>;
+        hipLaunchKernelGGL(k_ins, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, words, woff, len, n, m,
+                           table, tbits, slot_cnt, read_slot, entry_off, slice_build ? h->sl_build_n : 1u, h->sl_build_slice);
         PO_TRY(prefix_sum<uint32_t>(h, slot_cnt, nslots, slot_start, &h->pinned[0]));
         if (slice_build) {
             // a sub-table's chain segment was sized for its expected share: learn the real number before anything is
@@ -1607,13 +1649,13 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             PO_TRY(ensure(h, h->d_chain_tmp, (size_t)h->pinned[0] * chain_elem));
         }
         uint64_t* chain64 = h->d_chain.as<uint64_t>();
-        hipLaunchKernelGGL(po::k_wide_chain_fill<BITS>, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, read_slot,
+        hipLaunchKernelGGL(k_cfill, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, read_slot, entry_off,
                            (uint64_t)n_entries, slot_start, slot_cur, chain64, len);
         hipLaunchKernelGGL(po::k_chain_sort_short<uint64_t>, dim3(cdiv(nslots, 256)), dim3(256), 0, st, slot_cnt, slot_start,
                            nslots, chain64, h->d_long_list.as<uint32_t>(), n_long);
         hipLaunchKernelGGL(po::k_chain_sort_long<uint64_t>, dim3(64), dim3(256), 0, st, slot_cnt, slot_start,
                            h->d_long_list.as<uint32_t>(), n_long, chain64, h->d_chain_tmp.as<uint64_t>());
-        hipLaunchKernelGGL(po::k_wide_finalize<BITS>, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt,
+        hipLaunchKernelGGL(k_fin, dim3(cdiv(nslots, 256)), dim3(256), 0, st, table, nslots, slot_cnt,
                            slot_start, chain64, len);
     }
     // Which reads repeat their own prefix K-mer (selfrep: only their A candidates can be non-longest duplicates)?
@@ -1642,6 +1684,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         h->idx_wide = wide;
         h->idx_tbits = tbits;
         h->idx_bits = (uint32_t)BITS;
+        h->idx_ww = ww;
         return PO_OK;
     }
     h->idx_valid = !ext_idx;
@@ -1650,6 +1693,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     h->idx_wide = wide;
     h->idx_tbits = tbits;
     h->idx_bits = (uint32_t)BITS;
+    h->idx_ww = ww;
 
     // ---- scan, counting pass
     po::ScanArgs A = {};
@@ -1703,7 +1747,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     WA.tile_off = A.tile_off;
     if (wide) {
         HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE0], st));
-        auto wscan = streamed ? po::k_wide_scan<BITS, false, BITS == 2> : po::k_wide_scan<BITS, false, false>;
+        auto wscan = streamed ? po::k_wide_scan<BITS, false, BITS == 2, 1>
+                     : ww == 16 ? po::k_wide_scan<BITS, false, false, 16> : ww == 4 ? po::k_wide_scan<BITS, false, false, 4> : po::k_wide_scan<BITS, false, false, 1>;
         hipLaunchKernelGGL(wscan, dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA, po::CandGuard{nullptr, 0u});
         HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
     } else {
@@ -1846,7 +1891,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             WA.cand_a = A.cand_a;
             WA.cand_p = A.cand_p;
             WA.cand_b = A.cand_b;
-            auto wfill = streamed ? po::k_wide_scan<BITS, true, BITS == 2> : po::k_wide_scan<BITS, true, false>;
+            auto wfill = streamed ? po::k_wide_scan<BITS, true, BITS == 2, 1>
+                         : ww == 16 ? po::k_wide_scan<BITS, true, false, 16> : ww == 4 ? po::k_wide_scan<BITS, true, false, 4> : po::k_wide_scan<BITS, true, false, 1>;
             hipLaunchKernelGGL(wfill, dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA, G);
         } else {
             auto fill = streamed ? po::k_scan_fill<BITS, BITS == 2> : po::k_scan_fill<BITS, false>;
@@ -2026,7 +2072,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         if (nshards > 1 || streamed || wide || dpE) {
             static_assert(po::SEL_CAP == 512, "k_select_local hashes to 9 bits");
             hipLaunchKernelGGL(po::k_select_local, dim3(cdiv(r_end - r_begin, 256 / po::WAVE)), dim3(256), 0, st,
-                               h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_b, h->d_type.as<uint8_t>(),
+                               h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_p, A.cand_b, h->d_type.as<uint8_t>(),
                                r_begin, r_end - r_begin, selfrep, n_deferred, G);
         }
         // A candidate gives at most 2 rows (4 with their mirrors: worst_rows).  When the row buffer kept from an earlier
@@ -2072,12 +2118,12 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                 hipLaunchKernelGGL(po::k_fill_gated, dim3((uint32_t)h->n_cu * 8), dim3(256), 0, st, h->d_pair_key.as<uint4>(),
                                    (uint64_t)((size_t)1 << pbits) * sizeof(po::PairSlot) / 16, 0xFFFFFFFFu, gate);
                 ptab = h->d_pair_key.as<po::PairSlot>();
-                hipLaunchKernelGGL(po::k_select_mark, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_b,
+                hipLaunchKernelGGL(po::k_select_mark, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_p, A.cand_b,
                                    h->d_type.as<uint8_t>(), n_cand, selfrep, ptab, pbits, gate);
             }
         }
         if (want_cands) PO_TRY(ensure(h, h->d_flag, (size_t)n_cand));
-        hipLaunchKernelGGL(po::k_select, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_b,
+        hipLaunchKernelGGL(po::k_select, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_p, A.cand_b,
                            h->d_type.as<uint8_t>(), n_cand, selfrep, ptab, pbits, paired, h->d_rowcnt.as<uint8_t>(),
                            want_cands ? h->d_flag.as<uint8_t>() : nullptr, gate);
         HIP_TRY(h, hipGetLastError());
@@ -2834,7 +2880,7 @@ void po_destroy(po_handle* h) {
         (void)hipStreamSynchronize(h->stream);
         DevBuf* bufs[] = {&h->d_words, &h->d_woff, &h->d_len, &h->d_tiles, &h->d_read_tile0, &h->d_left, &h->d_left_cnt, &h->d_tile_extra, &h->d_exc_off, &h->d_exc_pos, &h->d_exc_byte, &h->d_pair_state, &h->d_truemask,
                           &h->d_table, &h->d_slot_cnt, &h->d_slot_cur, &h->d_slot_start, &h->d_read_slot, &h->d_chain,
-                          &h->d_chain_tmp, &h->d_long_list, &h->d_bloom, &h->d_selfrep, &h->d_tile_count, &h->d_tile_off,
+                          &h->d_chain_tmp, &h->d_long_list, &h->d_entry_off, &h->d_bloom, &h->d_selfrep, &h->d_tile_count, &h->d_tile_off,
                           &h->d_ps_blocks, &h->d_scalars, &h->d_cand_a, &h->d_cand_p, &h->d_cand_b, &h->d_type,
                           &h->d_rowcnt, &h->d_row_off, &h->d_flag, &h->d_pair_key, &h->d_pair_min, &h->spare_rows, &h->spare_cands, &h->spare_edges,
                           &h->d_vlabel, &h->d_vrank, &h->d_vperm, &h->d_end_a, &h->d_end_b, &h->d_dpcnt, &h->d_lay_len, &h->d_lay_cnt, &h->d_rflag, &h->d_removed, &h->d_ekey, &h->d_ecnt,
@@ -2848,8 +2894,6 @@ void po_destroy(po_handle* h) {
         if (!pooled) {
         for (int i = 0; i < 2 * EV_N; ++i) (void)hipEventDestroy(h->ev_sets[i / EV_N][i % EV_N]);
         for (hipEvent_t e : h->ev_lay)
-            if (e) (void)hipEventDestroy(e);
-        for (hipEvent_t e : h->ev_home)
             if (e) (void)hipEventDestroy(e);
         (void)hipEventDestroy(h->ev_up0);
         (void)hipEventDestroy(h->ev_up1);
@@ -3270,19 +3314,7 @@ bool home_begin(po_handle* h) {
     home::Pool* P = home::pool();
     if (!P) return false;
     P->call_mu.lock();
-    P->len = h->len.data();
-    P->n_reads = (uint32_t)h->len.size();
-    P->paired = 0;   // (known after the upload: set with the first piece)
-    P->device = h->device;
-    P->error.store(0);
-    P->submitted.store(0);
-    P->finished.store(0);
-    {
-        std::lock_guard<std::mutex> lock(P->mu);
-        P->queue.clear();
-        P->active.store(1);
-    }
-    P->cv.notify_all();
+    home::begin(P, h->len.data(), (uint32_t)h->len.size(), getenv("PHASM_STREAM_TRACE") != nullptr);
     h->home_on = true;
     h->home_used = 0;
     h->home_seq = 0;
@@ -3291,18 +3323,19 @@ bool home_begin(po_handle* h) {
 
 // every piece submitted so far has been expanded (or the pool has stopped on an error)
 void home_wait(po_handle* h) {
-    if (!h->home_on) return;
-    home::Pool* P = home::g_pool;
-    while (P->finished.load(std::memory_order_acquire) < P->submitted.load(std::memory_order_acquire)) home::cpu_pause();
+    if (h->home_on) home::wait_all(home::g_pool);
 }
 
 // returns the pool's error code (0 = fine)
 int home_end(po_handle* h) {
     if (!h->home_on) return 0;
     home::Pool* P = home::g_pool;
-    home_wait(h);
+    home::wait_all(P);
     const int err = P->error.load();
-    P->active.store(0, std::memory_order_release);
+    if (P->tracing)
+        for (size_t i = 0; i < P->trace.size(); ++i)
+            std::fprintf(stderr, "[home] piece %zu: records home at %.3f ms, %.0f rows written at %.3f ms (since the call set the pool up)\n", i,
+                         P->trace[i][0] * 1e-3, P->trace[i][2], P->trace[i][1] * 1e-3);
     h->home_on = false;
     P->call_mu.unlock();
     return err;
@@ -3339,30 +3372,30 @@ po_status append_home(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t n_r
     const size_t bytes = (size_t)n_rec * sizeof(po::Cand);
     constexpr uint64_t N_EV = PO_MAX_PIECES + 2;
     if (h->home_used + bytes > h->home_stage.cap || (h->home_seq && h->home_seq % N_EV == 0)) {
-        // the block is full (or every event has been used once): wait for the helper threads, start over at its beginning
+        // the block is full (or every flag word has been used once): wait for the helper threads, start over at its beginning
         home_wait(h);
         if (hipStreamSynchronize(h->copy_stream) != hipSuccess) return fail(h, PO_ERR_HIP, "copy stream");
         h->home_used = 0;
         if (bytes > h->home_stage.cap)
             PO_TRY(ensure_host(h, h->home_stage, std::max<size_t>({bytes * 2, (size_t)(h->home_last_bytes + h->home_last_bytes / 8), (size_t)8 << 20})));
     }
-    hipEvent_t& ev = h->ev_home[h->home_seq % N_EV];
-    if (!ev) HIP_TRY(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    // behind the copy, on the same stream: a one-thread kernel writes this piece's number into a page-locked word of the
+    // handle's landing zone (slots 96 ..) -- what the pool's first thread polls
+    const uint32_t slot = (uint32_t)(h->home_seq % N_EV);
+    const uint32_t want = ++h->home_gen;
     char* dst = static_cast<char*>(h->home_stage.p) + h->home_used;
     HIP_TRY(h, hipMemcpyAsync(dst, dev.p, bytes, hipMemcpyDeviceToHost, h->copy_stream));
-    HIP_TRY(h, hipEventRecord(ev, h->copy_stream));
+    hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->copy_stream, reinterpret_cast<uint32_t*>(h->pinned_dev + 96 + slot), (uint64_t)1, want);
+    HIP_TRY(h, hipGetLastError());
     home::Job j;
     j.rec = reinterpret_cast<const po::Cand*>(dst);
     j.n_rec = n_rec;
     j.out = static_cast<po_row*>(R.hb.p) + R.total;
     j.n_rows = nk;
-    j.ready = ev;
+    j.flag = reinterpret_cast<const volatile uint32_t*>(h->pinned + 96 + slot);
+    j.want = want;
     P->paired = (h->bits == 2 && h->paired) ? 1u : 0u;
-    {
-        std::lock_guard<std::mutex> lock(P->mu);
-        P->queue.push_back(j);
-    }
-    P->submitted.fetch_add(1, std::memory_order_release);
+    home::submit(P, j);
     h->home_used += (bytes + 255) & ~size_t(255);
     h->home_last_bytes += bytes;
     ++h->home_seq;
@@ -4543,24 +4576,12 @@ int po_debug_expand_records(const po_cand* records, uint64_t n, const uint32_t* 
     home::Pool* P = home::pool();
     if (!P) return -1;
     std::lock_guard<std::mutex> call(P->call_mu);
-    P->len = lengths;
-    P->n_reads = n_reads;
+    home::begin(P, lengths, n_reads, false);
     P->paired = paired ? 1u : 0u;
-    P->device = 0;
-    P->error.store(0);
-    P->submitted.store(0);
-    P->finished.store(0);
-    {
-        std::lock_guard<std::mutex> lock(P->mu);
-        P->queue.clear();
-        P->active.store(1);
-    }
-    P->cv.notify_all();
     // (several pieces, like a streamed step: the records cut into up to five jobs)
     const uint64_t n_jobs = n ? std::min<uint64_t>(5, (n + 2999) / 3000) : 0;
     uint64_t row0 = 0;
-    int err = 0;
-    for (uint64_t jn = 0; jn < n_jobs && !err; ++jn) {
+    for (uint64_t jn = 0; jn < n_jobs; ++jn) {
         const uint64_t lo = n * jn / n_jobs, hi = n * (jn + 1) / n_jobs;
         uint64_t rows = 0;
         for (uint64_t i = lo; i < hi; ++i) rows += home::rows_of_rec(reinterpret_cast<const po::Cand*>(records)[i], P->paired);
@@ -4570,17 +4591,11 @@ int po_debug_expand_records(const po_cand* records, uint64_t n, const uint32_t* 
         j.n_rec = hi - lo;
         j.out = rows_out + row0;
         j.n_rows = rows;
-        {
-            std::lock_guard<std::mutex> lock(P->mu);
-            P->queue.push_back(j);
-        }
-        P->submitted.fetch_add(1, std::memory_order_release);
+        home::submit(P, j);
         row0 += rows;
     }
-    while (P->finished.load(std::memory_order_acquire) < P->submitted.load(std::memory_order_acquire)) home::cpu_pause();
-    err = P->error.load();
-    P->active.store(0, std::memory_order_release);
-    return err;
+    home::wait_all(P);
+    return P->error.load();
 }
 
 // SIGSEGV / SIGBUS: the faulting address and the NATIVE stack of the faulting thread to `fd`, then the handler that was

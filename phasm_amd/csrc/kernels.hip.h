@@ -456,25 +456,44 @@ __global__ void k_chain_sort_long(const uint32_t* __restrict__ slot_cnt, const u
 // positions) against a table of W entries per read: linear in the input, at the price of random
 // access into a table that lives in HBM.  Needs min_length >= 2W-1 (63 bases at 2 bit).
 //
-// Slot: {key, start, count} as in the narrow index.  Chain entries are 64-bit [W-1-j | b | len(b)] (wide_chain_entry), so
-// that ascending order = ascending candidate position p = W*word - j, then ascending b.  One-entry
-// chains are embedded: start = b, count = SLOT_SINGLE | j << 26 | len[b]  (len < 2^26).
-constexpr uint32_t WIDE_LEN_BITS = 26;
-// A chain entry of the wide index, 64 bits: [W-1-j : 5 | read : 32 | length of the read : 27] -- sorted as a number it is
-// ordered by offset, then read (what the candidate order needs); the read's length rides along so that walking a chain
-// is ONE load per entry instead of two dependent ones (chain, then len[read]).  A length that does not fit (all ones)
-// sends the reader to len[].
-constexpr uint32_t CHAIN_LEN_BITS = 27;
-constexpr uint32_t CHAIN_LEN_ESC = (1u << CHAIN_LEN_BITS) - 1u;
-__host__ __device__ inline uint64_t wide_chain_entry(uint32_t wj, uint32_t read, uint32_t len) {
-    return ((uint64_t)wj << 59) | ((uint64_t)read << CHAIN_LEN_BITS) | (len < CHAIN_LEN_ESC ? len : CHAIN_LEN_ESC);
-}
-__host__ __device__ inline uint32_t wide_chain_read(uint64_t e) { return (uint32_t)(e >> CHAIN_LEN_BITS); }
-__host__ __device__ inline uint32_t wide_chain_wj(uint64_t e) { return (uint32_t)(e >> 59); }
-__device__ inline uint32_t wide_chain_len(uint64_t e, const uint32_t* __restrict__ len) {
-    const uint32_t l = (uint32_t)e & CHAIN_LEN_ESC;
-    return l != CHAIN_LEN_ESC ? l : len[wide_chain_read(e)];
-}
+// Slot: {key, start, count} as in the narrow index.  Chain entries and the one-read chain embedded in its slot: WideEnc.
+// Window minimisers (WW > 1; round 4).  Probing EVERY word of a is one random line fetch per word -- 207 M of them at
+// config 3, at the 54 G lines/s this memory system gives random lines beyond an XCD's L2 (tools/ubench.hip, measured) --
+// and 3 of 4 probes miss.  Instead of b's K-mer at offset j, the index holds, per read b and phase j, the MINIMISER of
+// the first WW word-spaced K-mers of that phase -- the K-mer at offset o = j + W t*, t* = argmin over t < WW of
+// (hash(K-mer at j + W t), t) -- and the scan probes only those words of a that are the minimiser of SOME window of WW
+// consecutive words of a (about 2 / (WW + 1) of them).  No overlap is lost: an overlap (a, p, b) of l >= m bases, j = (-p)
+// mod W, covers the words of a at p + j + W t for t < floor((l - j) / W), which are b's K-mers at offsets j + W t; with
+// m >= W WW + W - 1 the first WW of them lie inside every overlap, they form a complete window of a's words and the
+// same sequence as b's phase-j window, so both sides pick the same element, the word at q = p + o is probed, finds
+// (b, o) and gives p = q - o.  Found exactly once: for given (a, p, b) the phase, hence the entry, hence q is fixed.
+// The streamed step keeps WW = 1: it builds the index from the first TWO words of every read, sent ahead of the pieces.
+template <int WW>
+struct WideEnc {
+    static constexpr uint32_t OBITS = WW == 1 ? 5u : 9u;           // bits of the offset o of an entry (o < W WW <= 512)
+    static constexpr uint32_t OMAX = (1u << OBITS) - 1u;
+    // a one-read chain lives in its slot: start = b, count = SLOT_SINGLE | o << SLOT_LEN_BITS | len[b]
+    static constexpr uint32_t SLOT_LEN_BITS = 31u - OBITS;         // 26 / 22
+    // A chain entry, 64 bits: [OMAX - o : OBITS | read : 32 | length of the read : 32 - OBITS] -- sorted as a number it is
+    // ordered by descending offset = ascending candidate position p = q - o, then by read; the read's length rides along
+    // so that walking a chain is ONE load per entry instead of two dependent ones (chain, then len[read]).  A length that
+    // does not fit (all ones) sends the reader to len[].
+    static constexpr uint32_t CHAIN_LEN_BITS = 32u - OBITS;        // 27 / 23
+    static constexpr uint32_t CHAIN_LEN_ESC = (1u << CHAIN_LEN_BITS) - 1u;
+    __host__ __device__ static inline uint64_t entry(uint32_t o, uint32_t read, uint32_t len) {
+        return ((uint64_t)(OMAX - o) << (32u + CHAIN_LEN_BITS)) | ((uint64_t)read << CHAIN_LEN_BITS) | (len < CHAIN_LEN_ESC ? len : CHAIN_LEN_ESC);
+    }
+    __host__ __device__ static inline uint32_t read(uint64_t e) { return (uint32_t)(e >> CHAIN_LEN_BITS); }
+    __host__ __device__ static inline uint32_t off(uint64_t e) { return OMAX - (uint32_t)(e >> (32u + CHAIN_LEN_BITS)); }
+    __device__ static inline uint32_t len(uint64_t e, const uint32_t* __restrict__ lens) {
+        const uint32_t l = (uint32_t)e & CHAIN_LEN_ESC;
+        return l != CHAIN_LEN_ESC ? l : lens[read(e)];
+    }
+    __device__ static inline uint32_t slot_off(uint32_t count) { return (count >> SLOT_LEN_BITS) & OMAX; }
+    __device__ static inline uint32_t slot_len(uint32_t count) { return count & ((1u << SLOT_LEN_BITS) - 1u); }
+};
+// the order of a window's elements: hash first (its low 7 bits make room for the position), position second
+__host__ __device__ inline uint32_t window_key(uint32_t h2, uint32_t pos) { return (h2 & ~127u) | pos; }
 
 // Sliced wide index (multi-GPU): the table is N sub-tables, a key lives in sub-table wide_slice(key); rank g builds
 // sub-table g only and the sub-tables travel in one all-gather (phasm_amd/dist.py: IndexExchange).  The all-ones key
@@ -483,11 +502,11 @@ __device__ inline uint32_t wide_slice(uint64_t key, uint32_t h2, uint32_t n_slic
     return key == KEY_EMPTY ? 0u : __umulhi(h2, n_slices);
 }
 
-template <int BITS>
+template <int BITS, int WW>
 __global__ void k_wide_insert(const uint64_t* __restrict__ words, const uint64_t* __restrict__ woff,
                               const uint32_t* __restrict__ len, uint32_t n_reads, uint32_t m, Slot* tab,
-                              uint32_t tbits, uint32_t* slot_cnt, uint32_t* entry_slot, uint32_t n_slices,
-                              uint32_t my_slice) {
+                              uint32_t tbits, uint32_t* slot_cnt, uint32_t* entry_slot, uint16_t* __restrict__ entry_off,
+                              uint32_t n_slices, uint32_t my_slice) {
     constexpr uint32_t W = 64 / BITS;
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (uint64_t)n_reads * W) return;
@@ -497,10 +516,29 @@ __global__ void k_wide_insert(const uint64_t* __restrict__ words, const uint64_t
         return;
     }
     const uint64_t* __restrict__ rw = words + woff[r];
-    const uint64_t key = funnel(rw[0], rw[1], j * BITS);  // m >= 2W-1: the K-mer at offset j is inside the read
-    const uint32_t tmask = (1u << tbits) - 1u;
+    uint64_t key = funnel(rw[0], rw[1], j * BITS);  // m >= 2W-1: the K-mer at offset j is inside the read
     uint32_t h1, h2;
     kmer_hash(key, h1, h2);
+    uint32_t o = j;
+    if constexpr (WW > 1) {
+        // the minimiser of this phase's first WW K-mers (m >= W WW + W - 1: all of them inside the read)
+        uint32_t best = window_key(h2, 0u);
+        for (uint32_t t = 1; t < (uint32_t)WW; ++t) {
+            const uint64_t k = funnel(rw[t], rw[t + 1], j * BITS);
+            uint32_t g1, g2;
+            kmer_hash(k, g1, g2);
+            const uint32_t c = window_key(g2, t);
+            if (c < best) {
+                best = c;
+                key = k;
+                h1 = g1;
+                h2 = g2;
+                o = j + W * t;
+            }
+        }
+    }
+    entry_off[e] = (uint16_t)o;
+    const uint32_t tmask = (1u << tbits) - 1u;
     if (n_slices > 1u && wide_slice(key, h2, n_slices) != my_slice) {   // another rank's sub-table
         entry_slot[e] = 0xFFFFFFFFu;
         return;
@@ -521,8 +559,8 @@ __global__ void k_wide_insert(const uint64_t* __restrict__ words, const uint64_t
     entry_slot[e] = i;
 }
 
-template <int BITS>
-__global__ void k_wide_chain_fill(const uint32_t* __restrict__ entry_slot, uint64_t n_entries,
+template <int BITS, int WW>
+__global__ void k_wide_chain_fill(const uint32_t* __restrict__ entry_slot, const uint16_t* __restrict__ entry_off, uint64_t n_entries,
                                   const uint32_t* __restrict__ slot_start, uint32_t* slot_cur, uint64_t* chain,
                                   const uint32_t* __restrict__ len) {
     constexpr uint32_t W = 64 / BITS;
@@ -530,15 +568,15 @@ __global__ void k_wide_chain_fill(const uint32_t* __restrict__ entry_slot, uint6
     if (e >= n_entries) return;
     const uint32_t s = entry_slot[e];
     if (s == 0xFFFFFFFFu) return;
-    const uint32_t r = (uint32_t)(e / W), j = (uint32_t)(e % W);
-    chain[slot_start[s] + atomicAdd(&slot_cur[s], 1u)] = wide_chain_entry(W - 1 - j, r, len[r]);
+    const uint32_t r = (uint32_t)(e / W);
+    chain[slot_start[s] + atomicAdd(&slot_cur[s], 1u)] = WideEnc<WW>::entry(entry_off[e], r, len[r]);
 }
 
-template <int BITS>
+template <int BITS, int WW>
 __global__ void k_wide_finalize(Slot* tab, uint32_t nslots, const uint32_t* __restrict__ slot_cnt,
                                 const uint32_t* __restrict__ slot_start, const uint64_t* __restrict__ chain,
                                 const uint32_t* __restrict__ len) {
-    constexpr uint32_t W = 64 / BITS;
+    using E = WideEnc<WW>;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nslots) return;
     const uint32_t c = slot_cnt[i];
@@ -546,21 +584,21 @@ __global__ void k_wide_finalize(Slot* tab, uint32_t nslots, const uint32_t* __re
     tab[i].count = c;
     if (c == 1) {
         const uint64_t e = chain[slot_start[i]];
-        const uint32_t b = wide_chain_read(e), j = W - 1 - wide_chain_wj(e);
-        const uint32_t lb = wide_chain_len(e, len);
-        if (lb < (1u << WIDE_LEN_BITS)) {
+        const uint32_t b = E::read(e), o = E::off(e);
+        const uint32_t lb = E::len(e, len);
+        if (lb < (1u << E::SLOT_LEN_BITS)) {
             tab[i].start = b;
-            tab[i].count = SLOT_SINGLE | (j << WIDE_LEN_BITS) | lb;
+            tab[i].count = SLOT_SINGLE | (o << E::SLOT_LEN_BITS) | lb;
         }
     }
 }
 
 // candidates of the word-aligned K-mer at base offset pw of read a, given the slot it found
-template <int BITS, bool STREAM = false, typename F>
+template <int BITS, bool STREAM = false, int WW = 1, typename F>
 __device__ inline void for_each_candidate_wide(const uint64_t* __restrict__ chain, const uint32_t* __restrict__ len,
                                                uint32_t paired, uint32_t z, uint32_t w, uint32_t a, uint32_t la,
                                                uint32_t pw, uint32_t m, F&& f) {
-    constexpr uint32_t W = 64 / BITS;
+    using E = WideEnc<WW>;
     auto one = [&](uint32_t b, uint32_t j, uint32_t lb) __attribute__((always_inline)) {
         if (j > pw) return;            // p = pw - j would be negative
         const uint32_t p = pw - j;
@@ -569,11 +607,11 @@ __device__ inline void for_each_candidate_wide(const uint64_t* __restrict__ chai
         if (k) f(b, p, k);
     };
     if (w & SLOT_SINGLE) {
-        one(z, (w >> WIDE_LEN_BITS) & (W - 1), w & ((1u << WIDE_LEN_BITS) - 1u));
+        one(z, E::slot_off(w), E::slot_len(w));
     } else {
         for (uint32_t i = 0; i < w; ++i) {
             const uint64_t e = chain[z + i];
-            one(wide_chain_read(e), W - 1 - wide_chain_wj(e), wide_chain_len(e, len));
+            one(E::read(e), E::off(e), E::len(e, len));
         }
     }
 }
@@ -611,9 +649,51 @@ struct WideArgs {
 // more than WIDE_TASK_CAP entries (tandem repeats) walks per lane as before.
 constexpr uint32_t WIDE_TASK_CAP = 256;
 
-template <int BITS, bool FILL, bool STREAM = false>
+// Which words of a tile are window minimisers (WW > 1)?  V = the window keys of the PAD = WW - 1 words before the tile,
+// the tile's 64 words and the PAD words behind it (0xFFFFFFFF for positions outside the read's complete words: a window
+// that holds one is not a window of the read, and whatever it selects beyond the true minimisers only costs a probe),
+// held as R0[l] = V[l] and R1[l] = V[64 + l] (l < 2 PAD).  Word i is selected iff it is the minimum of one of the WW
+// windows that contain it: sliding minimum over WW (doubling, forwards), then the sliding MAXIMUM of those minima over
+// the windows that contain i (doubling, backwards) -- every one of them is <= V[i], so the maximum equals V[i] iff one
+// of them does.  All 64 lanes take part (ds_bpermute).
+// own: window_key(hash, PAD + lane) of the lane's own word; side: lanes < PAD the word PAD - lane before the tile
+// (position lane), lanes PAD .. 2 PAD - 1 the words behind it (position 64 + lane).
+template <int WW>
+__device__ __forceinline__ bool window_selected(uint32_t own, uint32_t side, uint32_t lane) {
+    constexpr uint32_t PAD = WW - 1, INF = 0xFFFFFFFFu;
+    const uint32_t up = (uint32_t)__shfl((int)own, (int)((lane - PAD) & 63u));        // own[lane - PAD]
+    const uint32_t dn = (uint32_t)__shfl((int)own, (int)((lane + 64u - PAD) & 63u));  // own[lane + 64 - PAD]
+    uint32_t r0 = lane < PAD ? side : up;
+    uint32_t r1 = lane < PAD ? dn : (lane < 2u * PAD ? side : INF);
+#pragma unroll
+    for (uint32_t k = 1; k < (uint32_t)WW; k <<= 1) {   // r[i] = min V[i .. i + 2k - 1]
+        const uint32_t x0 = (uint32_t)__shfl((int)r0, (int)((lane + k) & 63u));
+        const uint32_t x1 = (uint32_t)__shfl((int)r1, (int)((lane + k) & 63u));
+        const uint32_t n0 = lane + k < 64u ? x0 : x1;
+        const uint32_t n1 = lane + k < 2u * PAD ? x1 : INF;
+        r0 = r0 < n0 ? r0 : n0;
+        r1 = r1 < n1 ? r1 : n1;
+    }
+#pragma unroll
+    for (uint32_t k = 1; k < (uint32_t)WW; k <<= 1) {   // r[i] = max Wmin[i - 2k + 1 .. i]
+        const uint32_t y0 = (uint32_t)__shfl((int)r0, (int)((lane - k) & 63u));
+        const uint32_t y1 = (uint32_t)__shfl((int)r1, (int)((lane - k) & 63u));
+        const uint32_t m0 = lane >= k ? y0 : 0u;        // (no window starts before the loaded words)
+        const uint32_t m1 = lane >= k ? y1 : y0;        // V-index 64 + lane - k < 64: in r0, at lane 64 + lane - k
+        r0 = r0 > m0 ? r0 : m0;
+        r1 = r1 > m1 ? r1 : m1;
+    }
+    // the lane's own word sits at V-index PAD + lane
+    const uint32_t a0 = (uint32_t)__shfl((int)r0, (int)((lane + PAD) & 63u));
+    const uint32_t a1 = (uint32_t)__shfl((int)r1, (int)((lane + PAD) & 63u));
+    const uint32_t y = lane + PAD < 64u ? a0 : a1;
+    return own != INF && y == own;
+}
+
+template <int BITS, bool FILL, bool STREAM = false, int WW = 1>
 __global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A, const CandGuard G) {
     constexpr uint32_t W = 64 / BITS;
+    using E = WideEnc<WW>;
     __shared__ uint8_t s_owner[256 / WAVE][WIDE_TASK_CAP];
     __shared__ uint8_t s_kept[256 / WAVE][WAVE];
     const uint32_t lane = lane_id();
@@ -629,11 +709,30 @@ __global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A, const CandG
     uint32_t n = 0, z = 0, w = 0, slot1 = 0, base = 0;
     const bool live = la >= A.m && pw + W <= la;  // the word lies wholly inside the read
     if (!FILL) {
+        uint64_t kmer = 0;
+        uint32_t h1 = 0, h2 = 0;
         if (live) {
-            const uint64_t kmer = A.words[rec.wabs + lane];
-            const uint32_t tmask = (1u << A.tbits) - 1u;
-            uint32_t h1, h2;
+            kmer = A.words[rec.wabs + lane];
             kmer_hash(kmer, h1, h2);
+        }
+        bool probe = live;
+        if constexpr (WW > 1) {
+            // only the window minimisers among a's words are probed (see WideEnc): the lane's own key, and -- lanes below
+            // 2 (WW - 1) -- the key of one of the words just before / just behind the tile
+            constexpr uint32_t PAD = WW - 1;
+            const uint32_t n_words = la >= A.m ? la / W : 0u;   // complete words of the read
+            const int64_t sw = lane < PAD ? (int64_t)rec.word0 - (int64_t)PAD + (int64_t)lane : (int64_t)rec.word0 + 64 + (int64_t)(lane - PAD);
+            uint32_t side = 0xFFFFFFFFu;
+            if (lane < 2u * PAD && sw >= 0 && sw < (int64_t)n_words) {
+                uint32_t g1, g2;
+                kmer_hash(A.words[rec.wread + (uint64_t)sw], g1, g2);
+                side = window_key(g2, lane < PAD ? lane : 64u + lane);
+            }
+            const uint32_t own = live ? window_key(h2, PAD + lane) : 0xFFFFFFFFu;
+            probe = window_selected<WW>(own, side, lane);
+        }
+        if (probe) {
+            const uint32_t tmask = (1u << A.tbits) - 1u;
             // (sliced index: the key's sub-table; its slots and its chain segment sit in one chunk)
             base = A.n_slices > 1u ? wide_slice(kmer, h2, A.n_slices) * A.chunk_slots : 0u;
             const Slot* __restrict__ tab = A.table + base;
@@ -693,13 +792,13 @@ __global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A, const CandG
                 uint32_t j, lb;
                 if (wo & SLOT_SINGLE) {
                     cb = zo;
-                    j = (wo >> WIDE_LEN_BITS) & (W - 1);
-                    lb = wo & ((1u << WIDE_LEN_BITS) - 1u);
+                    j = E::slot_off(wo);
+                    lb = E::slot_len(wo);
                 } else {
                     const uint64_t e = chain_of(bo)[zo + eo];
-                    cb = wide_chain_read(e);
-                    j = W - 1 - wide_chain_wj(e);
-                    lb = wide_chain_len(e, A.len);
+                    cb = E::read(e);
+                    j = E::off(e);
+                    lb = E::len(e, A.len);
                 }
                 if (j <= pwo) {
                     cp = pwo - j;
@@ -730,7 +829,7 @@ __global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A, const CandG
     // ---- more entries than the task list holds: every lane walks its own
     const uint64_t* __restrict__ chain = chain_of(base);
     if (!FILL) {
-        if (w) for_each_candidate_wide<BITS, STREAM>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
+        if (w) for_each_candidate_wide<BITS, STREAM, WW>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
                                                      [&](uint32_t, uint32_t, uint32_t) { ++n; });
         if (!n) slot1 = 0;
         A.lane_slot[li] = slot1;
@@ -738,12 +837,12 @@ __global__ __launch_bounds__(256) void k_wide_scan(const WideArgs A, const CandG
         if (lane == 0) A.tile_count[t] = tot;
     } else {
         if (slot1)
-            for_each_candidate_wide<BITS, STREAM>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
+            for_each_candidate_wide<BITS, STREAM, WW>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
                                           [&](uint32_t, uint32_t, uint32_t) { ++n; });
         const uint32_t inc = wave_incl_scan(n);
         uint32_t off = A.tile_off[t] + inc - n;
         if (n) {
-            for_each_candidate_wide<BITS, STREAM>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
+            for_each_candidate_wide<BITS, STREAM, WW>(chain, A.len, A.paired, z, w, a, la, pw, A.m,
                                           [&](uint32_t b, uint32_t p, uint32_t) {
                                               A.cand_a[off] = a;
                                               A.cand_p[off] = p;
@@ -1845,11 +1944,14 @@ __device__ inline uint32_t pair_slot(uint32_t a, uint32_t b, uint32_t tbits) {
 // Longest-only selection inside one read's candidate list, in LDS (sharded calls and the wide index, which do
 // not know which reads repeat their prefix): two verified A candidates of one (a, b) pair are necessarily in a's
 // own list, so a wave takes one read, enters its verified A candidates into a small LDS table b -> smallest
-// candidate index, and clears the A bit of every candidate that is not that smallest one.  No global table, no
+// candidate POSITION p (the longest overlap; a list need not come in ascending p: the window-minimiser index emits a
+// read's candidates in the order its probed words find them), and clears the A bit of every candidate of that b at
+// another position -- (a, p, b) is found once, so the position names the candidate.  No global table, no
 // device-scope atomics (9.3 M of them cost 1.3 ms at config 3).  A read with more verified A candidates than the
 // table takes (tandem repeats) marks its b's as suspects instead and leaves them to the global table below.
 constexpr uint32_t SEL_CAP = 512;  // LDS table entries per wave (load <= 1/2)
 __global__ __launch_bounds__(256) void k_select_local(const uint32_t* __restrict__ read_tile0, const uint32_t* __restrict__ tile_off,
+                                                      const uint32_t* __restrict__ cand_p,
                                                       const uint32_t* __restrict__ cand_b, uint8_t* __restrict__ type,
                                                       uint32_t r_begin, uint32_t n_reads, uint32_t* __restrict__ selfrep,
                                                       uint32_t* __restrict__ n_deferred, const CandGuard G) {
@@ -1890,7 +1992,7 @@ __global__ __launch_bounds__(256) void k_select_local(const uint32_t* __restrict
             if (prev == 0u || prev == b + 1u) break;
             s = (s + 1u) & (SEL_CAP - 1u);
         }
-        atomicMin(&mn[s], c);
+        atomicMin(&mn[s], cand_p[c]);
     }
     wave_lds_fence();
     for (uint32_t c = seg0 + lane; c < seg1; c += WAVE) {
@@ -1899,7 +2001,7 @@ __global__ __launch_bounds__(256) void k_select_local(const uint32_t* __restrict
         const uint32_t b = cand_b[c];
         uint32_t s = (b * 0x9E3779B1u) >> (32 - 9);
         while (key[s] != b + 1u) s = (s + 1u) & (SEL_CAP - 1u);
-        if (mn[s] != c) type[c] = (uint8_t)(t & ~1u);  // a longer overlap of the same pair exists
+        if (mn[s] != cand_p[c]) type[c] = (uint8_t)(t & ~1u);  // a longer overlap of the same pair exists
     }
 }
 
@@ -1929,7 +2031,7 @@ __global__ void k_fill_gated(uint4* __restrict__ p, uint64_t n16, uint32_t v, co
         p[i] = uint4{v, v, v, v};
 }
 
-__global__ void k_select_mark(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_b,
+__global__ void k_select_mark(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p, const uint32_t* __restrict__ cand_b,
                               const uint8_t* __restrict__ type, uint32_t n_cand, const uint32_t* __restrict__ selfrep,
                               PairSlot* __restrict__ ptab, uint32_t tbits, const uint32_t* __restrict__ gate) {
     if (gate && *gate == 0u) return;
@@ -1946,7 +2048,7 @@ __global__ void k_select_mark(const uint32_t* __restrict__ cand_a, const uint32_
         if (prev == ~0ull || prev == key) break;
         s = (s + 1u) & tmask;
     }
-    atomicMin(&ptab[s].min_idx, i);
+    atomicMin(&ptab[s].min_idx, cand_p[i]);   // (the smallest POSITION = the longest overlap of the pair)
 }
 
 // Rows per verified candidate in emission order: A row, [its mirror], B row, [its mirror].
@@ -1956,7 +2058,7 @@ __device__ inline uint32_t rows_of(uint32_t t, uint32_t a, uint32_t b, uint32_t 
 }
 
 // ptab == nullptr: no read has a self-repeating prefix, every verified A candidate is the longest
-__global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_b,
+__global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p, const uint32_t* __restrict__ cand_b,
                          uint8_t* __restrict__ type, uint32_t n_cand, const uint32_t* __restrict__ selfrep,
                          const PairSlot* __restrict__ ptab, uint32_t tbits,
                          uint32_t paired, uint8_t* __restrict__ rowcnt, uint8_t* __restrict__ flag,
@@ -1984,7 +2086,7 @@ __global__ void k_select(const uint32_t* __restrict__ cand_a, const uint32_t* __
             }
             s = (s + 1u) & tmask;
         }
-        if (first != i) {  // a longer overlap of the same pair exists
+        if (first != cand_p[i]) {  // a longer overlap of the same pair exists
             t &= ~1u;
             type[i] = (uint8_t)t;
         }

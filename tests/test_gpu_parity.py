@@ -353,6 +353,53 @@ def test_wide_index_matches_goldens(monkeypatch):
         same(got, ck.oracle_overlaps(seqs8, m8), m8)
 
 
+@pytest.mark.parametrize("window", ["1", "4", "16"])
+def test_wide_index_window_minimisers(window, monkeypatch):
+    """The wide index probes only the window minimisers among a's words (kernels.hip.h WideEnc; window 16 from
+    min_length 543 on, 4 from 159 on): every window must give the reference's rows -- ladders (variable lengths,
+    containments, three and four haplotypes), tandem repeats (hundreds of verified hits per pair, ties inside windows),
+    shards, mirror off, and read sets whose min_length sits exactly on a window's threshold."""
+    monkeypatch.setenv("PHASM_INDEX", "wide")
+    monkeypatch.setenv("PHASM_WIDE_WINDOW", window)
+    for name in gu.LADDER_NAMES:
+        _, seqs, m, want = gu.ladder_case(name)
+        got, st = hip_rows(seqs, m)
+        assert st["wide_index"] == 1, name
+        same(got, want, name)
+    for name, seqs, m, want in gu.repeats_cases():
+        got, st = hip_rows(seqs, m)
+        same(got, want, name)
+    _, seqs, m, want = gu.ladder_case("ladder_varlen")
+    got, _ = hip_rows(seqs, m, shard=3)
+    same(got, want)
+    monkeypatch.setenv("PHASM_NO_MIRROR", "1")
+    got, st = hip_rows(seqs, m)
+    same(got, want)
+    monkeypatch.delenv("PHASM_NO_MIRROR")
+    # min_length on and around the thresholds (W ww + W - 1 = 159 and 543), reads barely longer than that, low complexity
+    rng = np.random.default_rng(41)
+    rc = bytes.maketrans(b"ACGT", b"TGCA")
+    for trial in range(12):
+        glen = int(rng.integers(700, 5000))
+        if trial % 3 == 2:
+            unit = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=int(rng.integers(2, 50))))
+            g = bytearray((unit * (glen // len(unit) + 1))[:glen])
+            for pos in rng.integers(0, glen, size=glen // 80):
+                g[pos] = b"ACGT"[rng.integers(4)]
+            genome = bytes(g)
+        else:
+            genome = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=glen))
+        m = int(rng.choice([158, 159, 160, 542, 543, 544, 600]))
+        seqs = []
+        for _ in range(int(rng.integers(6, 50))):
+            ln = min(glen, int(rng.choice([m, m + 1, m + 31, m + 32, 2 * m, int(rng.integers(m, 4 * m))])))
+            st0 = int(rng.integers(0, glen - ln + 1))
+            r = genome[st0:st0 + ln]
+            seqs += [r, r.translate(rc)[::-1]]
+        got, st = hip_rows(seqs, m)
+        same(got, ck.oracle_overlaps(seqs, m), "trial %d m %d window %s" % (trial, m, window))
+
+
 def test_wide_index_midsize_against_oracle(monkeypatch):
     monkeypatch.setenv("PHASM_INDEX", "wide")
     cfg = synth.scaled(synth.CONFIGS["cfg2"], 2000)
