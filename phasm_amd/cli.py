@@ -102,7 +102,8 @@ def overlap(args) -> int:
         res.free()
     mark("E lines formatted and written")
     args.output.flush()
-    overlapper.close()
+    if not getattr(args, "leave_handle_to_exit", False):
+        overlapper.close()
     mark("flush + handle closed")
     if getattr(args, "timing", False):
         import json
@@ -204,6 +205,7 @@ def main(argv=None) -> int:
     p.add_argument("--device", type=int, default=None, help="HIP device ordinal (default 0)")
     p.add_argument("--python-ingest", action="store_true", help="parse the FASTA in Python instead of po_add_fasta")
     p.add_argument("--timing", action="store_true", help="print the command's stage times as one JSON line on stderr")
+    p.add_argument("--leave-handle-to-exit", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--max-diff", type=int, default=0,
                    help="(extension beyond the exact reference) accept overlaps with up to this many differences: banded "
                         "seed-extension DP on the GPU; 0 = exact, the reference's behaviour (default)")
@@ -240,8 +242,39 @@ def main(argv=None) -> int:
     logging.basicConfig(level=[logging.WARNING, logging.INFO, logging.DEBUG][min(args.verbose, 2)],
                         stream=sys.stderr)
     args.func(args)
+    for name in ("output", "out"):   # (the command may end with os._exit: nothing may be left in a Python buffer)
+        f = getattr(args, name, None)
+        if f is not None and f not in (sys.stdout, sys.stderr):
+            f.close()
+        elif f is not None:
+            f.flush()
     return 0
 
 
+def _run_as_command() -> None:
+    """The command ends when its output is on disk: the handle's device buffers, the page-locked pools and the GPU runtime
+    are left to the operating system (giving 600 MB of page-locked and device memory back buffer by buffer, and unloading
+    the runtime, took 0.15 s of the `overlap` command's 0.8 s)."""
+    import os
+    argv = sys.argv[1:]
+    if argv and argv[0] == "overlap" and "--keep-teardown" not in argv:
+        argv = ["overlap", "--leave-handle-to-exit"] + argv[1:]
+    else:
+        argv = [a for a in argv if a != "--keep-teardown"]
+    rc = 1
+    try:
+        rc = main(argv)
+        sys.stdout.flush()
+        sys.stderr.flush()
+    except SystemExit as e:
+        raise e
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)
+    os._exit(rc)
+
+
 if __name__ == "__main__":
-    sys.exit(main())
+    _run_as_command()

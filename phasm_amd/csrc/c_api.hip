@@ -1996,7 +1996,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         } else {
             // a's words live in LDS (read length + 3 guard words); reads too long for 64 KB use the global path
             const uint64_t need_words = ((uint64_t)h->max_len + W - 1) / W + 3;
-            const uint32_t lds_words_raw = (uint32_t)std::min<uint64_t>(need_words, 8192 - 1100);  // (room for the records in 64 KB)
+            const uint32_t lds_words_raw = (uint32_t)std::min<uint64_t>(need_words, 8192 - 1100 - (PO_VER_LDS_SWZ ? 256 : 0));  // (room for the records in 64 KB)
             const uint32_t n_a = r_end - r_begin;
             const uint32_t* perm = nullptr;
             // (sharded calls too: 0.65 -> 0.51 ms at 2 shards, 0.19 -> 0.17 at 8 -- once the label of a read ranked by
@@ -2041,7 +2041,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                                        : (staged ? po::k_verify_a<BITS, false, true> : po::k_verify_a<BITS, false, false>);
             if (streamed) verify = staged ? po::k_verify_a<BITS, false, true, BITS == 2> : po::k_verify_a<BITS, false, false, BITS == 2>;
             const uint32_t lds_words = (lds_words_raw + 1u) & ~1u;  // even: the records behind a sit on a 16-byte boundary
-            const size_t ver_lds = (size_t)lds_words * 8 + (size_t)po::VREC_CAP * sizeof(po::VRec) + 16;
+            const size_t ver_lds = (size_t)po::ver_a_words(lds_words) * 8 + (size_t)po::VREC_CAP * sizeof(po::VRec) + 16;
             if (ver_lds > 48 * 1024)
                 HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(verify), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ver_lds));
             HIP_TRY(h, hipEventRecord(h->ev[EV_VER0], st));

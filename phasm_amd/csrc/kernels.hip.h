@@ -35,6 +35,18 @@ constexpr int WAVE = 64;
 // -DPO_VER_PAD=n / -DPO_SCAN_PAD=n (measurement builds, tools/pad_probe.sh): n extra full-rate VALU instructions per
 // 16-byte compare of the verify kernel / per position of the scan filter.  How much a kernel's time grows per added
 // VALU cycle says how far it is bound by VALU issue (slope 1) rather than by latency (slope 0).
+// -DPO_VER_LDS_SWZ=1 (measurement build, tools/lds_swz_probe.sh): the words of a sit in LDS with ONE PAD DWORD PER 32 --
+// physical dword = x + (x >> 5).  A 16-lane group reads a at a stride of four dwords (16 bytes of b per lane), which
+// touches 8 of the 32 banks twice; with the pad the upper eight lanes move one bank on and the group's 16 reads hit 16
+// banks.  Costs a shift and an add per LDS dword read.
+#ifndef PO_VER_LDS_SWZ
+#define PO_VER_LDS_SWZ 0
+#endif
+__host__ __device__ inline uint32_t ver_swz(uint32_t x) { return PO_VER_LDS_SWZ ? x + (x >> 5) : x; }
+// 64-bit words of LDS that hold lds_words words of a
+__host__ __device__ inline uint32_t ver_a_words(uint32_t lds_words) {
+    return PO_VER_LDS_SWZ ? (((2u * lds_words + ((2u * lds_words) >> 5) + 2u) / 2u + 1u) & ~1u) : lds_words;
+}
 #ifndef PO_VER_PAD
 #define PO_VER_PAD 0
 #endif
@@ -1766,11 +1778,11 @@ __device__ __forceinline__ void verify_run(const uint64_t* __restrict__ words, c
     auto cmp16 = [&](uint32_t dd, u32x4 bv) __attribute__((always_inline)) -> uint32_t {
         uint32_t a0, a1, a2, a3, a4;
         if constexpr (IN_LDS) {
-            a0 = s_a[q + dd];
-            a1 = s_a[q + dd + 1];
-            a2 = s_a[q + dd + 2];
-            a3 = s_a[q + dd + 3];
-            a4 = s_a[q + dd + 4];
+            a0 = s_a[ver_swz(q + dd)];
+            a1 = s_a[ver_swz(q + dd + 1)];
+            a2 = s_a[ver_swz(q + dd + 2)];
+            a3 = s_a[ver_swz(q + dd + 3)];
+            a4 = s_a[ver_swz(q + dd + 4)];
         } else {
             a0 = ga32[q + dd];
             a1 = ga32[q + dd + 1];
@@ -1874,11 +1886,21 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
     const bool in_lds = nwa + 3 <= lds_words;  // workgroup-uniform
     // dynamic LDS only (a static variable would move its base off the 16-byte boundary the records need):
     // lds_words (even) words of a, VREC_CAP candidate records, the draw counter
-    VRec* s_rec = reinterpret_cast<VRec*>(s_a64 + lds_words);
+    VRec* s_rec = reinterpret_cast<VRec*>(s_a64 + ver_a_words(lds_words));
     uint32_t* s_next = reinterpret_cast<uint32_t*>(s_rec + VREC_CAP);
     constexpr uint32_t NGROUPS = VER_BLOCK / VER_GROUP;
-    if (in_lds)
-        for (uint32_t i = threadIdx.x; i < nwa + 3; i += VER_BLOCK) s_a64[i] = ga[i];
+    if (in_lds) {
+        if constexpr (PO_VER_LDS_SWZ) {
+            uint32_t* s_w = reinterpret_cast<uint32_t*>(s_a64);
+            for (uint32_t i = threadIdx.x; i < nwa + 3; i += VER_BLOCK) {
+                const uint64_t v = ga[i];
+                s_w[ver_swz(2u * i)] = (uint32_t)v;
+                s_w[ver_swz(2u * i + 1u)] = (uint32_t)(v >> 32);
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < nwa + 3; i += VER_BLOCK) s_a64[i] = ga[i];
+        }
+    }
     const uint32_t seg0 = tile_off[t0], seg1 = tile_off[t1];
     if (seg0 == seg1) return;  // (workgroup-uniform)
     const uint32_t* __restrict__ s_a = reinterpret_cast<const uint32_t*>(s_a64);
