@@ -304,7 +304,7 @@ def visible_gpu_count() -> int:
     n = 0
     files = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
     if not files:
-        return -1    # (no topology to read: unknown -- the ranks will say so themselves)
+        return 0 if not os.path.isdir("/sys/class/kfd") else -1   # (no KFD driver: no GPU; nodes unreadable: unknown)
     for f in files:
         try:
             with open(f) as fh:
@@ -526,6 +526,24 @@ def main() -> int:
         n_rows = int(t.item())
     incl_acc = dict(acc)
     incl_last = dict(last)   # (statistics of the last host-to-host step, before the resident loop overwrites them)
+    # The pieces of a streamed step record no timing events inside the timed region (a marker between two kernels costs ~5 us
+    # of device time, seven per piece): the per-kernel sums of the SAME step are taken from three extra steps with
+    # PHASM_PHASE_EVENTS=2 (events around the two big kernels and around each piece), outside the timed region.
+    ev_steps = 3
+    if world == 1 and not args.dist_path and incl_last.get("streamed"):
+        keep_pcie = dict(pcie)
+        for k in acc:
+            acc[k] = 0.0
+        os.environ["PHASM_PHASE_EVENTS"] = "2"
+        for _ in range(ev_steps):
+            step(True)
+        os.environ.pop("PHASM_PHASE_EVENTS")
+        fence()
+        for k in ("ms_scan_probe", "ms_verify_kernel", "ms_total"):
+            incl_acc[k] = acc[k] * args.steps / ev_steps     # (scaled to the K steps the averages below divide by)
+        pcie.clear()
+        pcie.update(keep_pcie)
+        step(False)   # (one step without the events again: the statistics of `last` are those of the timed form)
     # the kernel pipeline alone (reads resident in HBM, rows left in HBM): an extra, never `value`
     for k in acc:
         acc[k] = 0.0
@@ -618,6 +636,8 @@ def main() -> int:
         except (OSError, ValueError, KeyError):
             valu_model = {}
         positions = last["shard_bases"]                  # one filter lookup (8 B of LDS) per position of the scan
+        # (timed_region_sum_ms: summed over the pieces of a host-to-host step of the same form, taken with PHASM_PHASE_EVENTS=2
+        # in three extra steps right behind the timed loop -- the timed steps themselves record no per-kernel events)
         # Launch durations: HIP events around the kernel in the RESIDENT loop (one whole-set launch per step, the same
         # launches the rocprofv3 --pmc passes profile); inside the host-to-host region the same work runs as 4 chunk
         # launches, whose summed duration is reported next to it (`timed_region_sum_ms`).

@@ -102,8 +102,15 @@ struct HostBuf {
 // retire between two kernels (~5 us each, measured): a whole-set call records all of them, the pieces of a streamed step only
 // the pairs around the two big kernels (ms_scan_probe, ms_verify_kernel) unless PHASM_PHASE_EVENTS=1 / PHASM_STREAM_TRACE ask.
 inline int phase_events_env() {
-    const int v = getenv("PHASM_PHASE_EVENTS") ? (atoi(getenv("PHASM_PHASE_EVENTS")) != 0 ? 1 : 0) : (getenv("PHASM_STREAM_TRACE") ? 1 : -1);
-    return v;
+    // -1: default (whole-set calls record every stage boundary, the pieces of a streamed step NOTHING but their end -- round 4:
+    // with the rows going home as records the step is paced by the device, and seven markers per piece were 35 us of it);
+    // 0: nothing but the end anywhere; 1: every boundary everywhere; 2: pieces record the pairs around their two big kernels
+    // (ms_scan_probe, ms_verify_kernel) and their start / end (ms_total) -- what bench.py's extra steps ask for
+    if (const char* e = getenv("PHASM_PHASE_EVENTS")) {
+        const int v = atoi(e);
+        return v == 1 ? 1 : v == 2 ? 2 : 0;
+    }
+    return getenv("PHASM_STREAM_TRACE") ? 1 : -1;
 }
 enum { EV_START = 0, EV_INDEX, EV_COUNT, EV_FILL, EV_VERIFY, EV_SELECT, EV_EMIT, EV_PROBE0, EV_PROBE1, EV_VER0, EV_VER1, EV_DONE, EV_N };
 
@@ -286,6 +293,7 @@ struct po_handle {
         po_stats S = {};
         bool ver_timed = false;
         bool full_events = true;
+        bool pair_events = true;
         bool tail = false;         // the piece's tail ran as k_tail: counts in pinned[zone..], fallback flag in pinned[zone + 7]
         bool compact = false;      // ... as k_tail_cands: the piece's buffer holds records
         int zone = 48;
@@ -298,6 +306,7 @@ struct po_handle {
     std::vector<uint32_t> st_pred_sig;
     bool st_pred_valid = false;
     bool phase_events = true;   // this call records the stage-boundary events (phase_events_env)
+    bool pair_events = true;    // ... at least the pairs around the two big kernels and the call's start / end
     bool st_early_index = false;   // this streamed step builds its index before piece 0 has landed
     bool st_tail_gave_up = false;  // the last streamed step was abandoned because of tandem-repeat reads (statistics / tests)
     bool idx_only = false;         // run_overlaps stops behind the index build (the streamed step builds it ahead of piece 0)
@@ -880,6 +889,30 @@ po_status init_device(po_handle* h) {
     // the library's code object is loaded by the first launch out of it (15 ms in a fresh process): here, not in a call
     hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->stream, reinterpret_cast<uint32_t*>(h->pinned_dev + 63), (uint64_t)1, 0u);
     (void)hipGetLastError();
+    // ... and so are the hardware queues behind the three other streams and the runtime's copy paths: a stream's queue is made
+    // by the first command it gets, the host->device / device->host machinery by the first copy in each direction -- 15 ms
+    // of the first call of a process (`8 pieces queued at 15.056 ms`, tools/cold_probe.py) when left to the call.  One
+    // word each way on the streams that will carry the copies, one launch on every stream; the device comes up while the
+    // reads are still being added (result_pool_grow, po_add_fasta's warm-up thread), so none of this is waited for there.
+    if (!getenv("PHASM_NO_WARM")) {
+        void* w = nullptr;
+        if (hipMalloc(&w, 256) == hipSuccess) {
+            uint32_t* wd = static_cast<uint32_t*>(w);
+            (void)hipMemcpyAsync(wd, h->pinned + 62, 8, hipMemcpyHostToDevice, h->up_stream);
+            hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->up_stream, wd + 8, (uint64_t)1, 0u);
+            (void)hipMemcpyAsync(wd + 16, h->pinned + 62, 8, hipMemcpyHostToDevice, h->stream);
+            hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->rc_stream, wd + 24, (uint64_t)1, 0u);
+            hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->copy_stream, wd + 32, (uint64_t)1, 0u);
+            (void)hipMemcpyAsync(h->pinned + 61, wd + 32, 8, hipMemcpyDeviceToHost, h->copy_stream);
+            (void)hipMemcpyAsync(h->pinned + 60, wd + 16, 8, hipMemcpyDeviceToHost, h->stream);
+            (void)hipStreamSynchronize(h->up_stream);
+            (void)hipStreamSynchronize(h->rc_stream);
+            (void)hipStreamSynchronize(h->copy_stream);
+            (void)hipStreamSynchronize(h->stream);
+            (void)hipFree(w);
+        }
+        (void)hipGetLastError();
+    }
     h->dev_ready = true;
     return PO_OK;
 }
@@ -1395,7 +1428,12 @@ po_status prefix_sum_small(po_handle* h, uint32_t* in, const uint32_t* extra, ui
     return PO_OK;
 }
 
-void stage_times(po_stats& S, hipEvent_t* ev, bool ver_timed, bool full) {
+void stage_times(po_stats& S, hipEvent_t* ev, bool ver_timed, bool full, bool pairs = true) {
+    if (!full && !pairs) {   // (a piece of a streamed step that recorded nothing but its end)
+        S.ms_index = S.ms_scan_count = S.ms_scan_fill = S.ms_verify = S.ms_select = S.ms_emit = 0.f;
+        S.ms_total = S.ms_scan_probe = S.ms_verify_kernel = 0.f;
+        return;
+    }
     if (!full) {
         S.ms_index = S.ms_scan_count = S.ms_scan_fill = S.ms_verify = S.ms_select = S.ms_emit = 0.f;
         (void)hipEventElapsedTime(&S.ms_total, ev[EV_START], ev[EV_EMIT]);
@@ -1434,7 +1472,7 @@ uint64_t finish_piece(po_handle* h, bool* needs_classic) {
     P.S.sum_overlap_bases = h->pinned[c + 1];
     P.S.verify_bytes_algo = h->pinned[c + 2];
     P.S.verify_bytes_exec = h->pinned[c + 3];
-    stage_times(P.S, P.ev, P.ver_timed, P.full_events);
+    stage_times(P.S, P.ev, P.ver_timed, P.full_events, P.pair_events);
     P.valid = false;
     return n_rows;
 }
@@ -1601,8 +1639,9 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     {
         const int pe = phase_events_env();
         h->phase_events = pe >= 0 ? pe == 1 : !streamed;
+        h->pair_events = h->phase_events || pe == 2 || (pe < 0 && !streamed);
     }
-    HIP_TRY(h, hipEventRecord(h->ev[EV_START], st));
+    if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_START], st));
     const bool reuse_index = !slice_build && !ext_idx && h->idx_valid && h->idx_gen == h->upload_gen && h->idx_m == m &&
                              h->idx_wide == wide && h->idx_tbits == tbits && h->idx_bits == (uint32_t)BITS && h->idx_ww == ww && h->poison < 0 &&
                              !getenv("PHASM_NO_INDEX_REUSE");
@@ -1746,11 +1785,11 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     WA.lane_slot = A.truemask;
     WA.tile_off = A.tile_off;
     if (wide) {
-        HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE0], st));
+        if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE0], st));
         auto wscan = streamed ? po::k_wide_scan<BITS, false, BITS == 2, 1>
                      : ww == 16 ? po::k_wide_scan<BITS, false, false, 16> : ww == 4 ? po::k_wide_scan<BITS, false, false, 4> : po::k_wide_scan<BITS, false, false, 1>;
         hipLaunchKernelGGL(wscan, dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA, po::CandGuard{nullptr, 0u});
-        HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
+        if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
     } else {
         const size_t scan_lds = (size_t)scan_waves * po::SCAN_LDS_PER_WAVE + bloom_bytes;
         if (scan_lds > h->lds_max) return fail(h, PO_ERR_HIP, "device LDS too small for the scan kernel");
@@ -1774,9 +1813,9 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         A.left = h->d_left.as<uint2>();
         A.left_cnt = h->d_left_cnt.as<uint32_t>();
         A.tile_extra = h->d_tile_extra.as<uint32_t>();
-        HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE0], st));
+        if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE0], st));
         hipLaunchKernelGGL(K == W ? probe_full : probe_part, dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
-        HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
+        if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
         auto fixup = streamed ? po::k_scan_fixup<BITS, CAN_STREAM> : po::k_scan_fixup<BITS, false>;
         hipLaunchKernelGGL(fixup, dim3(n_scan_waves), dim3(256), 0, st, A, n_scan_waves);
         // (the leftover counts, tile_extra, are added to the tile counts by the prefix sum below)
@@ -1811,7 +1850,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     // piece.  Needs every per-piece buffer to hold cap_c already (a re-allocation would synchronise the device).
     const int zone = 64 + 16 * (int)(shard & 1u);   // this piece's slots of the pinned landing area
     uint32_t cap_c = 0;
-    bool async_count = false;
+    bool async_count = false, pred_order = true;
     if (streamed && h->st_harvest && h->st_pred_valid && !dp && !want_cands && !getenv("PHASM_SYNC_COUNT") && !getenv("PHASM_TAIL_CLASSIC")) {
         uint64_t pred = h->st_pred_cand[shard];
         uint64_t cap = pred + pred / 50 + 256;
@@ -1819,13 +1858,15 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         const uint64_t worst = cap * 4u;
         bool order = pred >= 400000 && (r_end - r_begin) >= 4096;
         if (const char* e = getenv("PHASM_VERIFY_ORDER")) order = atoi(e) != 0;
+        if (const char* e = getenv("PHASM_PIECE_ORDER")) order = order && atoi(e) != 0;   // (A/B: pieces without the locality order)
+        pred_order = order;
         auto fits = [](const DevBuf& b, uint64_t bytes) { return b.p && b.cap >= bytes; };
-        async_count = pred > 0 && order && cap < (4u << 20) && cdiv(cap, po::TAIL_TILE) <= po::TAIL_MAX_TILES &&
+        async_count = pred > 0 && cap < (4u << 20) && cdiv(cap, po::TAIL_TILE) <= po::TAIL_MAX_TILES &&
                       fits(h->d_cand_a, cap * 4) && fits(h->d_cand_p, cap * 4) && fits(h->d_cand_b, cap * 4) && fits(h->d_type, cap) &&
                       fits(h->d_rowcnt, cap) && fits(h->d_row_off, (cap + 1) * 4) &&
                       fits(h->spare_rows, h->home_on ? cap * sizeof(po::Cand) : worst * sizeof(po_row)) &&
-                      fits(h->d_vlabel, (uint64_t)(r_end - r_begin) * 4) && fits(h->d_vperm, (uint64_t)(r_end - r_begin) * 4) &&
-                      fits(h->d_vrank, (uint64_t)(r_end - r_begin) * 4) && h->dev_words < 0xFFFFFFF0ull;
+                      (!order || (fits(h->d_vlabel, (uint64_t)(r_end - r_begin) * 4) && fits(h->d_vperm, (uint64_t)(r_end - r_begin) * 4) &&
+                                  fits(h->d_vrank, (uint64_t)(r_end - r_begin) * 4))) && h->dev_words < 0xFFFFFFF0ull;
         cap_c = (uint32_t)cap;
     }
     volatile uint64_t* count_slot = async_count ? &h->pinned[zone + 8] : &h->pinned[1];
@@ -1902,6 +1943,9 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         const bool use_order_early = [&]() {
             bool u = n_cand >= 400000 && (r_end - r_begin) >= 4096;
             if (const char* e = getenv("PHASM_VERIFY_ORDER")) u = atoi(e) != 0;
+            if (streamed)
+                if (const char* e = getenv("PHASM_PIECE_ORDER")) u = u && atoi(e) != 0;
+            if (async_count) u = pred_order;   // (decided from the predicted count, before anything was launched)
             return u && !dp;
         }();
         const bool defer_needed = streamed && r_end < n;
@@ -1909,7 +1953,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             // containment candidates whose b has not arrived: onto the deferred list (the verify kernel skips them);
             // when the locality order is computed, k_read_label's walk over the candidates does this on the way
             hipLaunchKernelGGL(po::k_defer_split, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, A.cand_a, A.cand_p, A.cand_b, n_cand,
-                               r_end, h->d_defer.as<po::Cand>(), h->st_defer_cap, h->d_defer.as<uint32_t>() + (size_t)h->st_defer_cap * 4);
+                               r_end, h->d_defer.as<po::Cand>(), h->st_defer_cap, h->d_defer.as<uint32_t>() + (size_t)h->st_defer_cap * 4, G);
         }
         HIP_TRY(h, hipGetLastError());
         if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_FILL], st));
@@ -1958,7 +2002,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             if (const char* e = getenv("PHASM_DP_KERNEL_SOFT"))   // (tests: "lanes" where a lane mapping applies at all, no error elsewhere)
                 if (!strcmp(e, "lanes")) bitvec = false;
             S.dp_lanes = bitvec ? 2u : lanes ? 1u : 0u;
-            HIP_TRY(h, hipEventRecord(h->ev[EV_VER0], st));
+            if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_VER0], st));
             if (lanes) {
                 // candidates ordered by the rows they need, so that the 64 lanes of a wave finish together
                 const uint32_t* perm = nullptr;
@@ -1990,7 +2034,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             } else {
                 hipLaunchKernelGGL((po::k_extend_dp<BITS>), dim3(cdiv(n_cand, 256 / po::WAVE)), dim3(256), 0, st, X);
             }
-            HIP_TRY(h, hipEventRecord(h->ev[EV_VER1], st));
+            if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_VER1], st));
             HIP_TRY(h, hipMemcpyAsync(h->pinned + 32, h->d_dpcnt.p, 16, hipMemcpyDeviceToHost, st));
             ver_timed = true;
         } else {
@@ -2044,13 +2088,13 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             const size_t ver_lds = (size_t)po::ver_a_words(lds_words) * 8 + (size_t)po::VREC_CAP * sizeof(po::VRec) + 16;
             if (ver_lds > 48 * 1024)
                 HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(verify), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ver_lds));
-            HIP_TRY(h, hipEventRecord(h->ev[EV_VER0], st));
+            if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_VER0], st));
             hipLaunchKernelGGL(verify, dim3(ver_grid), dim3(po::VER_BLOCK), ver_lds, st,
                                words, woff, len, h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_p,
                                A.cand_b, r_begin, lds_words, paired_ver,
                                h->n_exc_uploaded ? h->d_exc_off.as<uint32_t>() : nullptr, h->d_exc_pos.as<uint32_t>(),
                                h->d_exc_byte.as<uint8_t>(), h->d_type.as<uint8_t>(), perm, n_a, G);
-            HIP_TRY(h, hipEventRecord(h->ev[EV_VER1], st));
+            if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_VER1], st));
             ver_timed = true;
         }
         HIP_TRY(h, hipGetLastError());
@@ -2264,7 +2308,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
         if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_SELECT], st));
     }
-    HIP_TRY(h, hipEventRecord(h->ev[EV_EMIT], st));
+    if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_EMIT], st));
     uint64_t* counters = h->pinned + 4;
     if (!used_tail) HIP_TRY(h, hipMemcpyAsync(counters, scalars + 4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     res->unique_twins = !want_cands && paired != 0 && !dpE;
@@ -2286,6 +2330,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         h->st_pend.S = S;
         h->st_pend.ver_timed = ver_timed;
         h->st_pend.full_events = h->phase_events;
+        h->st_pend.pair_events = h->pair_events;
         h->st_pend.ev = h->ev;
         res->count = 0;
         return PO_OK;
@@ -2331,7 +2376,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         S.dp_steps = h->pinned[32];
         S.dp_stopped = h->pinned[33];
     }
-    stage_times(S, h->ev, ver_timed, h->phase_events);
+    stage_times(S, h->ev, ver_timed, h->phase_events, h->pair_events);
     return PO_OK;
 }
 

@@ -2359,8 +2359,12 @@ __global__ void k_scatter_first(uint64_t* __restrict__ words, const uint64_t* __
 // counter[0] keeps counting past `cap`, so that the host learns how much room the list needed.
 __global__ void k_defer_split(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
                               const uint32_t* __restrict__ cand_b, uint32_t n_cand, uint32_t b_limit, Cand* __restrict__ out,
-                              uint32_t cap, uint32_t* __restrict__ counter) {
+                              uint32_t cap, uint32_t* __restrict__ counter, const CandGuard G) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (G.n_dev) {   // (predicted count: the grid covers G.cap candidates, the real number is on the device)
+        if (G.overflow()) return;
+        n_cand = (uint32_t)*G.n_dev;
+    }
     if (i >= n_cand) return;
     const uint32_t b = cand_b[i];
     if (b < b_limit) return;
