@@ -307,6 +307,7 @@ struct po_handle {
     bool st_pred_valid = false;
     bool phase_events = true;   // this call records the stage-boundary events (phase_events_env)
     bool pair_events = true;    // ... at least the pairs around the two big kernels and the call's start / end
+    bool st_selfclean = false;     // the previous piece of this streamed step left the per-call counters zero (no reset launch needed)
     bool st_early_index = false;   // this streamed step builds its index before piece 0 has landed
     bool st_tail_gave_up = false;  // the last streamed step was abandoned because of tandem-repeat reads (statistics / tests)
     bool idx_only = false;         // run_overlaps stops behind the index build (the streamed step builds it ahead of piece 0)
@@ -509,6 +510,20 @@ void result_pool_grow(po_handle* h, uint64_t bases = 0) {
         pin_note(h->spare_host.p, want, 1u);
         // the landing block of the compact records (a third of the row bytes), sized with it -- not inside the first call
         if (home_enabled() && h->home_stage.cap < want / 3) (void)ensure_host(h, h->home_stage, want / 3);
+        // and the first LARGE copy in each direction (the copy engines' queues are made by it: the first piece of the first
+        // call of a process took 7.5 ms instead of 0.5) moves 8 MB of the fresh pool to the device and back
+        if (h->dev_ready && h->up_stream && h->copy_stream && want >= (16u << 20) && !getenv("PHASM_NO_WARM")) {
+            void* w = nullptr;
+            const size_t nb = 8u << 20;
+            if (hipMalloc(&w, nb) == hipSuccess) {
+                (void)hipMemcpyAsync(w, h->spare_host.p, nb, hipMemcpyHostToDevice, h->up_stream);
+                (void)hipStreamSynchronize(h->up_stream);
+                (void)hipMemcpyAsync(static_cast<char*>(h->spare_host.p) + nb, w, nb, hipMemcpyDeviceToHost, h->copy_stream);
+                (void)hipStreamSynchronize(h->copy_stream);
+                (void)hipFree(w);
+            }
+            (void)hipGetLastError();
+        }
     } else {
         (void)hipGetLastError();
         h->spare_host.p = nullptr;
@@ -910,6 +925,32 @@ po_status init_device(po_handle* h) {
             (void)hipStreamSynchronize(h->copy_stream);
             (void)hipStreamSynchronize(h->stream);
             (void)hipFree(w);
+        }
+        (void)hipGetLastError();
+        // every kernel of a 2-bit call is looked up in the code object now (the runtime resolves a kernel at its first launch:
+        // ~35 of them at 0.1-0.3 ms each inside the first call otherwise)
+        static const void* const warm_kernels[] = {
+            (const void*)po::k_abs_woff, (const void*)po::k_build_tiles, (const void*)po::k_revcomp_store, (const void*)po::k_scatter_first,
+            (const void*)po::k_paired_check, (const void*)po::k_call_init, (const void*)po::k_call_reset, (const void*)po::k_table_insert,
+            (const void*)po::k_chain_fill, (const void*)po::k_chain_sort_short<uint32_t>, (const void*)po::k_chain_sort_long<uint32_t>,
+            (const void*)po::k_table_finalize, (const void*)po::k_ps_reduce<uint32_t>, (const void*)po::k_ps_spine, (const void*)po::k_ps_down<uint32_t>,
+            (const void*)po::k_ps_reduce<uint8_t>, (const void*)po::k_ps_down<uint8_t>, (const void*)po::k_ps_chain<uint32_t>,
+            (const void*)po::k_ps_chain<uint8_t>, (const void*)po::k_ps_small,
+            (const void*)po::k_scan_probe<2, true, true>, (const void*)po::k_scan_probe<2, true, false>, (const void*)po::k_scan_fixup<2, true>,
+            (const void*)po::k_scan_fixup<2, false>, (const void*)po::k_scan_fill<2, true>, (const void*)po::k_scan_fill<2, false>,
+            (const void*)po::k_read_label, (const void*)po::k_read_sort, (const void*)po::k_read_invert, (const void*)po::k_defer_split,
+            (const void*)po::k_verify_a<2, false, true, true>, (const void*)po::k_verify_a<2, false, true, false>,
+            (const void*)po::k_verify_a<2, true, true, false>, (const void*)po::k_select_local, (const void*)po::k_tile_rows<true>,
+            (const void*)po::k_tile_rows<false>, (const void*)po::k_tail, (const void*)po::k_tail_cands, (const void*)po::k_select,
+            (const void*)po::k_emit, (const void*)po::k_verify_flat, (const void*)po::k_deferred_rowcnt, (const void*)po::k_emit_cands,
+            (const void*)po::k_wide_insert<2, 1>, (const void*)po::k_wide_insert<2, 16>, (const void*)po::k_wide_chain_fill<2, 1>,
+            (const void*)po::k_wide_chain_fill<2, 16>, (const void*)po::k_wide_finalize<2, 1>, (const void*)po::k_wide_finalize<2, 16>,
+            (const void*)po::k_chain_sort_short<uint64_t>, (const void*)po::k_chain_sort_long<uint64_t>,
+            (const void*)po::k_wide_scan<2, false, true, 1>, (const void*)po::k_wide_scan<2, true, true, 1>,
+            (const void*)po::k_wide_scan<2, false, false, 16>, (const void*)po::k_wide_scan<2, true, false, 16>};
+        for (const void* k : warm_kernels) {
+            hipFuncAttributes fa;
+            (void)hipFuncGetAttributes(&fa, k);
         }
         (void)hipGetLastError();
     }
@@ -1563,6 +1604,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     bool rows_late = false;  // rows emitted into a kept buffer before their number reached the host
     bool cands_late = false, cands_ext = false;  // the same for compacted candidates (want_cands): destination chosen before the number was known
     uint64_t cands_cap = 0;
+    bool self_clean = false;  // a piece of a streamed step that leaves the per-call counters zero for the next piece
     bool used_tail = false;  // the call's tail ran as k_tail (counts in pinned[tail_zone..], fallback flag in pinned[tail_zone + 7])
     int tail_zone = 48;
     std::function<po_status()> tail_fallback;
@@ -1803,9 +1845,15 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         PO_TRY(ensure(h, h->d_left, (size_t)n_scan_waves * po::LEFT_CAP * sizeof(uint2)));
         PO_TRY(ensure(h, h->d_left_cnt, (size_t)n_scan_waves * 4));
         PO_TRY(ensure(h, h->d_tile_extra, ((size_t)h->n_tiles + 1) * 4));
-        if (fold_clear) {
-            hipLaunchKernelGGL(po::k_call_reset, dim3(cdiv(std::max(std::max(n, 8u), std::max(n_scan_waves, ntiles)), 256)), dim3(256), 0, st,
-                               selfrep, n, scalars, h->d_left_cnt.as<uint32_t>(), n_scan_waves, h->d_tile_extra.as<uint32_t>() + tile_begin, ntiles);
+        // (the pieces of a streamed step clean up after themselves -- k_scan_fixup zeroes its list counters, the fused tail its
+        // counters, the first piece's reset clears tile_extra for every tile of the read set --: no reset launch per piece)
+        self_clean = streamed && !getenv("PHASM_DEBUG_LEFT") && !getenv("PHASM_PIECE_RESET");
+        if (fold_clear && self_clean && h->st_selfclean) {
+            // nothing to launch
+        } else if (fold_clear) {
+            const uint32_t te0 = self_clean ? 0u : tile_begin, ten = self_clean ? h->n_tiles : ntiles;
+            hipLaunchKernelGGL(po::k_call_reset, dim3(cdiv(std::max(std::max(n, 8u), std::max(n_scan_waves, ten)), 256)), dim3(256), 0, st,
+                               selfrep, n, scalars, h->d_left_cnt.as<uint32_t>(), n_scan_waves, h->d_tile_extra.as<uint32_t>() + te0, ten);
         } else {
             HIP_TRY(h, hipMemsetAsync(h->d_left_cnt.p, 0, (size_t)n_scan_waves * 4, st));
             HIP_TRY(h, hipMemsetAsync(h->d_tile_extra.as<uint32_t>() + tile_begin, 0, (size_t)ntiles * 4, st));
@@ -1817,7 +1865,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         hipLaunchKernelGGL(K == W ? probe_full : probe_part, dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
         if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
         auto fixup = streamed ? po::k_scan_fixup<BITS, CAN_STREAM> : po::k_scan_fixup<BITS, false>;
-        hipLaunchKernelGGL(fixup, dim3(n_scan_waves), dim3(256), 0, st, A, n_scan_waves);
+        hipLaunchKernelGGL(fixup, dim3(n_scan_waves), dim3(256), 0, st, A, n_scan_waves, self_clean ? 1u : 0u);
         // (the leftover counts, tile_extra, are added to the tile counts by the prefix sum below)
         if (getenv("PHASM_DEBUG_LEFT")) {  // how many positions did the scan waves defer to k_scan_fixup?
             PO_TRY(ensure_host(h, h->scratch_host, (size_t)n_scan_waves * 4));
@@ -2313,6 +2361,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     if (!used_tail) HIP_TRY(h, hipMemcpyAsync(counters, scalars + 4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     res->unique_twins = !want_cands && paired != 0 && !dpE;
     HIP_TRY(h, hipEventRecord(h->ev[EV_DONE], st));
+    h->st_selfclean = streamed && self_clean && used_tail && !wide;   // (the next piece of this step may skip its reset)
     if (async_count && h->st_pend.valid) {
         // everything of this piece is queued; now collect the piece before it (its numbers sit in the other zone)
         HIP_TRY(h, hipEventSynchronize(h->st_pend.ev[EV_DONE]));
@@ -3359,7 +3408,7 @@ bool home_begin(po_handle* h) {
     home::Pool* P = home::pool();
     if (!P) return false;
     P->call_mu.lock();
-    home::begin(P, h->len.data(), (uint32_t)h->len.size(), getenv("PHASM_STREAM_TRACE") != nullptr);
+    home::begin(P, h->len.data(), (uint32_t)h->len.size(), getenv("PHASM_STREAM_TRACE") != nullptr || getenv("PHASM_HOME_TRACE") != nullptr);
     h->home_on = true;
     h->home_used = 0;
     h->home_seq = 0;
@@ -3657,6 +3706,7 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
     uint64_t new_pred[PO_MAX_PIECES] = {};
     // the index ahead of piece 0: it needs every read's first word(s) only, and at 400 k reads (wide index, 2.9 ms; 16 ms at
     // 2 M reads) building it inside piece 0 -- after the piece has landed -- kept every later piece 2-3 ms behind its data
+    h->st_selfclean = false;
     h->st_early_index = P > 1 && h->poison < 0 && !getenv("PHASM_NO_INDEX_REUSE") && !getenv("PHASM_LATE_INDEX");
     PO_TRY(stream_begin(h, bounds));
     if (trace) std::fprintf(stderr, "[stream] %u pieces queued at %.3f ms\n", P, since());

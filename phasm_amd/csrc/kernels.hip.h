@@ -1326,8 +1326,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_probe(const ScanArgs A) {  
 // Settle the positions the scan waves deferred (k_scan_probe: third table slot needed, chain of several
 // reads, more than NPEND survivors in a lane): one thread each, ordinary dependent loads, results
 // added to the tile's truemask bit and candidate count.  Runs after k_scan_probe has retired every tile.
+// clean != 0: the list's counter is zero again when the kernel ends (the pieces of a streamed step: no reset launch per piece)
 template <int BITS, bool STREAM = false>
-__global__ void k_scan_fixup(const ScanArgs A, uint32_t n_waves) {
+__global__ void k_scan_fixup(const ScanArgs A, uint32_t n_waves, uint32_t clean) {
     constexpr int W = 64 / BITS;
     // one workgroup of 256 threads per scan wave's list: every position is a chain of dependent loads, so the
     // kernel's time is a latency times the number of rounds (64 threads per list: 16 rounds for a full list;
@@ -1361,6 +1362,10 @@ __global__ void k_scan_fixup(const ScanArgs A, uint32_t n_waves) {
             atomicOr(&A.truemask[(size_t)t * WAVE + ln], 1u << sft);
             atomicAdd(&A.tile_count[t], n);
         }
+    }
+    if (clean) {
+        __syncthreads();   // (every thread has read its entries' count)
+        if (threadIdx.x == 0) A.left_cnt[wv] = 0;
     }
 }
 
@@ -2943,7 +2948,10 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail(const uint32_t* __restrict_
         s_last = atomicAdd(done, 1u) == n_tiles - 1u ? 1u : 0u;
         if (s_last) {
             *done = 0;
-            for (int k = 0; k < 4; ++k) host_out[1 + k] = __hip_atomic_load(&counters[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < 4; ++k) {
+                host_out[1 + k] = __hip_atomic_load(&counters[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                counters[k] = 0;   // (zero again for the next piece: every workgroup's add has been performed, see above)
+            }
             host_out[7] = 0;
         }
     }
@@ -3093,7 +3101,11 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail_cands(const uint32_t* __res
         if (s_last) {
             *done = 0;
             host_out[0] = __hip_atomic_load(rows_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int k = 0; k < 4; ++k) host_out[1 + k] = __hip_atomic_load(&counters[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *rows_ctr = 0;
+            for (int k = 0; k < 4; ++k) {
+                host_out[1 + k] = __hip_atomic_load(&counters[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                counters[k] = 0;   // (zero again for the next piece)
+            }
             host_out[7] = 0;
         }
     }

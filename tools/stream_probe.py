@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--steps", type=int, default=15)
     ap.add_argument("--cuts", nargs="*", default=["default", "off"])
     ap.add_argument("--trace", action="store_true", help="one more step per setting with PHASM_STREAM_TRACE")
+    ap.add_argument("--home-trace", action="store_true", help="one more step per setting with PHASM_HOME_TRACE (no timing events)")
     ap.add_argument("--n-rate", type=float, default=0.0, help="turn this fraction of the bases into N (both strands consistently): exception records")
     args = ap.parse_args()
     cfg = synth.CONFIGS[args.config]
@@ -65,6 +66,13 @@ def main():
             os.environ["PHASM_STREAM_TRACE"] = "1"
             step()
             os.environ.pop("PHASM_STREAM_TRACE")
+        if args.home_trace and st["streamed"]:
+            # when each piece's records were home and its rows written, WITHOUT the timing events a full trace records
+            os.environ["PHASM_HOME_TRACE"] = "1"
+            t0 = time.perf_counter()
+            step()
+            print("  (that step: %.3f ms)" % ((time.perf_counter() - t0) * 1e3), flush=True)
+            os.environ.pop("PHASM_HOME_TRACE")
     ov.close()
 
 
