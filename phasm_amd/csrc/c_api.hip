@@ -639,6 +639,12 @@ struct Job {
     // hipEventQuery takes the runtime's locks on every call).  flag == nullptr: the records are there already.
     const volatile uint32_t* flag = nullptr;
     uint32_t want = 0;
+    // A piece may arrive in several copies (the LAST piece of a step does: its rows are what the call ends with, and its
+    // first part is expanded while the rest is still crossing PCIe).  A part knows its rows only when the pool has counted
+    // them: cont = this part's rows start where the previous part's ended; n_rows = 0 for every part but the last, which
+    // carries the piece's total for the check.
+    bool cont = false;
+    bool more = false;               // further parts of the same piece follow
 };
 
 struct Pool {
@@ -655,6 +661,8 @@ struct Pool {
     uint32_t n_reads = 0, paired = 0;
     // the piece being expanded
     Job cur;
+    po_row* part_next = nullptr;     // where the next part of the current piece starts
+    uint64_t part_rows = 0;          // rows of the piece's parts so far
     uint64_t job_seq = 0;            // (under mu) pieces published so far
     uint32_t n_chunks = 0;
     std::vector<uint64_t> chunk_off;
@@ -729,7 +737,9 @@ void run_phases(Pool& P, bool lead) {
         while (P.done_count.load(std::memory_order_acquire) < nc) cpu_pause();
         P.chunk_off[0] = 0;
         for (uint32_t c = 0; c < nc; ++c) P.chunk_off[c + 1] += P.chunk_off[c];
-        if (P.chunk_off[nc] != P.cur.n_rows) P.error.store(1);   // (the device counted differently: nothing is written)
+        P.part_rows += P.chunk_off[nc];
+        if (!P.cur.more && P.part_rows != P.cur.n_rows) P.error.store(1);   // (the device counted differently: nothing is written)
+        P.part_next = P.cur.out + P.chunk_off[nc];
         P.phase.store(P.error.load() ? 0 : 2, std::memory_order_release);
     } else {
         while (P.phase.load(std::memory_order_acquire) == 1) cpu_pause();
@@ -779,6 +789,8 @@ void leader(Pool* Pp) {
         if (P.error.load() == 0 && j.n_rec) {
             // (no helper is inside the previous piece's loops any more: the counters may be reset)
             while (P.inside.load(std::memory_order_acquire) != 0) cpu_pause();
+            if (j.cont) j.out = P.part_next;
+            else P.part_rows = 0;
             P.cur = j;
             P.n_chunks = (uint32_t)((j.n_rec + CHUNK - 1) / CHUNK);
             if (P.chunk_off.size() < (size_t)P.n_chunks + 1) P.chunk_off.resize((size_t)P.n_chunks + 1);
@@ -3464,7 +3476,7 @@ po_status append_home(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t n_r
     home::Pool* P = home::g_pool;
     PO_TRY(rows_room(h, R, nk, k, n_chunks, seen_share));
     const size_t bytes = (size_t)n_rec * sizeof(po::Cand);
-    constexpr uint64_t N_EV = PO_MAX_PIECES + 2;
+    constexpr uint64_t N_EV = 32;   // flag words: slots 96 .. 127 of the landing zone
     if (h->home_used + bytes > h->home_stage.cap || (h->home_seq && h->home_seq % N_EV == 0)) {
         // the block is full (or every flag word has been used once): wait for the helper threads, start over at its beginning
         home_wait(h);
@@ -3473,26 +3485,37 @@ po_status append_home(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t n_r
         if (bytes > h->home_stage.cap)
             PO_TRY(ensure_host(h, h->home_stage, std::max<size_t>({bytes * 2, (size_t)(h->home_last_bytes + h->home_last_bytes / 8), (size_t)8 << 20})));
     }
-    // behind the copy, on the same stream: a one-thread kernel writes this piece's number into a page-locked word of the
-    // handle's landing zone (slots 96 ..) -- what the pool's first thread polls
-    const uint32_t slot = (uint32_t)(h->home_seq % N_EV);
-    const uint32_t want = ++h->home_gen;
-    char* dst = static_cast<char*>(h->home_stage.p) + h->home_used;
-    HIP_TRY(h, hipMemcpyAsync(dst, dev.p, bytes, hipMemcpyDeviceToHost, h->copy_stream));
-    hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->copy_stream, reinterpret_cast<uint32_t*>(h->pinned_dev + 96 + slot), (uint64_t)1, want);
-    HIP_TRY(h, hipGetLastError());
-    home::Job j;
-    j.rec = reinterpret_cast<const po::Cand*>(dst);
-    j.n_rec = n_rec;
-    j.out = static_cast<po_row*>(R.hb.p) + R.total;
-    j.n_rows = nk;
-    j.flag = reinterpret_cast<const volatile uint32_t*>(h->pinned + 96 + slot);
-    j.want = want;
+    // behind a copy, on the same stream: a one-thread kernel writes a number into a page-locked word of the handle's landing
+    // zone (slots 96 ..) -- what the pool's first thread polls.  The LAST piece of a call travels in up to four parts, so
+    // that its first rows are being written while its last records are still on the wire.
+    uint32_t n_parts = 1;
+    if (k + 1 == n_chunks && n_rec >= 65536 && !getenv("PHASM_HOME_NO_SPLIT")) n_parts = 4;
+    if (h->home_seq % N_EV + n_parts > N_EV) n_parts = 1;   // (not enough unused flag words left in this round)
     P->paired = (h->bits == 2 && h->paired) ? 1u : 0u;
-    home::submit(P, j);
+    char* dst0 = static_cast<char*>(h->home_stage.p) + h->home_used;
+    for (uint32_t part = 0; part < n_parts; ++part) {
+        const uint64_t lo = n_rec * part / n_parts, hi = n_rec * (part + 1) / n_parts;
+        const uint32_t slot = (uint32_t)(h->home_seq % N_EV);
+        const uint32_t want = ++h->home_gen;
+        char* dst = dst0 + lo * sizeof(po::Cand);
+        HIP_TRY(h, hipMemcpyAsync(dst, static_cast<const char*>(dev.p) + lo * sizeof(po::Cand), (hi - lo) * sizeof(po::Cand),
+                                  hipMemcpyDeviceToHost, h->copy_stream));
+        hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->copy_stream, reinterpret_cast<uint32_t*>(h->pinned_dev + 96 + slot), (uint64_t)1, want);
+        HIP_TRY(h, hipGetLastError());
+        home::Job j;
+        j.rec = reinterpret_cast<const po::Cand*>(dst);
+        j.n_rec = hi - lo;
+        j.out = static_cast<po_row*>(R.hb.p) + R.total;
+        j.n_rows = nk;
+        j.flag = reinterpret_cast<const volatile uint32_t*>(h->pinned + 96 + slot);
+        j.want = want;
+        j.cont = part > 0;
+        j.more = part + 1 < n_parts;
+        home::submit(P, j);
+        ++h->home_seq;
+    }
     h->home_used += (bytes + 255) & ~size_t(255);
     h->home_last_bytes += bytes;
-    ++h->home_seq;
     R.total += nk;
     return PO_OK;
 }
@@ -4673,21 +4696,18 @@ int po_debug_expand_records(const po_cand* records, uint64_t n, const uint32_t* 
     std::lock_guard<std::mutex> call(P->call_mu);
     home::begin(P, lengths, n_reads, false);
     P->paired = paired ? 1u : 0u;
-    // (several pieces, like a streamed step: the records cut into up to five jobs)
+    // (as the last piece of a streamed step travels: up to five parts of ONE piece, each part's rows behind the part before)
     const uint64_t n_jobs = n ? std::min<uint64_t>(5, (n + 2999) / 3000) : 0;
-    uint64_t row0 = 0;
     for (uint64_t jn = 0; jn < n_jobs; ++jn) {
         const uint64_t lo = n * jn / n_jobs, hi = n * (jn + 1) / n_jobs;
-        uint64_t rows = 0;
-        for (uint64_t i = lo; i < hi; ++i) rows += home::rows_of_rec(reinterpret_cast<const po::Cand*>(records)[i], P->paired);
-        if (jn + 1 == n_jobs && row0 + rows != n_rows_expected) rows = n_rows_expected - row0;   // (a wrong expectation must be noticed)
         home::Job j;
         j.rec = reinterpret_cast<const po::Cand*>(records) + lo;
         j.n_rec = hi - lo;
-        j.out = rows_out + row0;
-        j.n_rows = rows;
+        j.out = rows_out;
+        j.n_rows = n_rows_expected;
+        j.cont = jn > 0;
+        j.more = jn + 1 < n_jobs;
         home::submit(P, j);
-        row0 += rows;
     }
     home::wait_all(P);
     return P->error.load();
