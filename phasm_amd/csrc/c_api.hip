@@ -265,6 +265,17 @@ struct po_handle {
     // beside whatever the handle's stream is doing for the piece before: ev_rc[k] = piece k is complete, both strands
     hipStream_t rc_stream = nullptr;
     hipEvent_t ev_rc[PO_MAX_PIECES] = {};
+    // Two-stream pieces (round 4): with the rows going home as records the streamed step is paced by the DEVICE, and a piece
+    // is two halves that need different things -- the counting pass (k_scan_probe, k_scan_fixup, the tile prefix sum) needs
+    // the piece's own reads and the index, everything behind it (fill, locality order, verify, select, tail) the candidate
+    // buffers.  The counting pass of piece k + 1 runs on scan_stream beside the second half of piece k on the handle's
+    // stream: ev_s1[k & 1] = piece k's counting pass is done; the small per-piece state both halves touch (scalars,
+    // tile offsets) exists twice, by the piece's parity.
+    hipStream_t scan_stream = nullptr;
+    hipEvent_t ev_s1[2] = {};
+    hipEvent_t ev_idx = nullptr;     // the step's index (and everything queued before it on the handle's stream) is complete
+    bool two_stream = false;         // this streamed step runs its pieces that way
+    uint32_t st_k = 0;               // the piece run_overlaps is working on (its event in ev_rc)
     hipEvent_t ev_meta = nullptr;
     hipEvent_t ev_first = nullptr;   // the first words of the later pieces are in place
     // first two packed words of every read, appended as the reads are added (registered memory: the streamed step sends
@@ -473,6 +484,7 @@ void quiesce_store(po_handle* h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->up_stream) (void)hipStreamSynchronize(h->up_stream);
     if (h->rc_stream) (void)hipStreamSynchronize(h->rc_stream);
+    if (h->scan_stream) (void)hipStreamSynchronize(h->scan_stream);
 }
 
 // Pinned result pool, sized WHILE THE READS ARE ADDED.  A fresh 170 MB page-locked array costs 8 ms (hipHostMalloc maps
@@ -543,7 +555,8 @@ void result_pool_grow(po_handle* h, uint64_t bases = 0) {
 // buys nothing, and ~1 ms of a fresh handle's first call.  A kit is idle when it is put back (every stream synchronised).
 struct DevKit {
     int device = -1;
-    hipStream_t stream = nullptr, copy_stream = nullptr, up_stream = nullptr, rc_stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr, up_stream = nullptr, rc_stream = nullptr, scan_stream = nullptr;
+    hipEvent_t ev_s1[2] = {}, ev_idx = nullptr;
     hipEvent_t ev_sets[2][EV_N] = {};
     hipEvent_t ev_up0 = nullptr, ev_up1 = nullptr, ev_meta = nullptr, ev_first = nullptr;
     hipEvent_t ev_piece[PO_MAX_PIECES] = {}, ev_rc[PO_MAX_PIECES] = {}, ev_lay[4] = {};
@@ -565,6 +578,10 @@ bool kit_take(po_handle* h) {
         h->copy_stream = k.copy_stream;
         h->up_stream = k.up_stream;
         h->rc_stream = k.rc_stream;
+        h->scan_stream = k.scan_stream;
+        h->ev_s1[0] = k.ev_s1[0];
+        h->ev_s1[1] = k.ev_s1[1];
+        h->ev_idx = k.ev_idx;
         std::memcpy(h->ev_sets, k.ev_sets, sizeof(k.ev_sets));
         h->ev_up0 = k.ev_up0;
         h->ev_up1 = k.ev_up1;
@@ -582,9 +599,10 @@ bool kit_take(po_handle* h) {
 
 // true: the handle's streams / events / landing zone went back to the pool (the caller must not destroy them)
 bool kit_give(po_handle* h) {
-    if (getenv("PHASM_NO_KIT_POOL") || !h->stream || !h->copy_stream || !h->up_stream || !h->rc_stream || !h->pinned) return false;
+    if (getenv("PHASM_NO_KIT_POOL") || !h->stream || !h->copy_stream || !h->up_stream || !h->rc_stream || !h->scan_stream || !h->pinned) return false;
     if (hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->copy_stream) != hipSuccess ||
-        hipStreamSynchronize(h->up_stream) != hipSuccess || hipStreamSynchronize(h->rc_stream) != hipSuccess) {
+        hipStreamSynchronize(h->up_stream) != hipSuccess || hipStreamSynchronize(h->rc_stream) != hipSuccess ||
+        hipStreamSynchronize(h->scan_stream) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
@@ -594,6 +612,10 @@ bool kit_give(po_handle* h) {
     k.copy_stream = h->copy_stream;
     k.up_stream = h->up_stream;
     k.rc_stream = h->rc_stream;
+    k.scan_stream = h->scan_stream;
+    k.ev_s1[0] = h->ev_s1[0];
+    k.ev_s1[1] = h->ev_s1[1];
+    k.ev_idx = h->ev_idx;
     std::memcpy(k.ev_sets, h->ev_sets, sizeof(k.ev_sets));
     k.ev_up0 = h->ev_up0;
     k.ev_up1 = h->ev_up1;
@@ -907,6 +929,10 @@ po_status init_device(po_handle* h) {
     HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     HIP_TRY(h, hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
     HIP_TRY(h, hipStreamCreateWithFlags(&h->rc_stream, hipStreamNonBlocking));
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->scan_stream, hipStreamNonBlocking));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_s1[0], hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_s1[1], hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_idx, hipEventDisableTiming));
     for (int k = 0; k < PO_MAX_PIECES; ++k) {
         HIP_TRY(h, hipEventCreate(&h->ev_piece[k]));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_rc[k], hipEventDisableTiming));
@@ -929,11 +955,14 @@ po_status init_device(po_handle* h) {
             hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->up_stream, wd + 8, (uint64_t)1, 0u);
             (void)hipMemcpyAsync(wd + 16, h->pinned + 62, 8, hipMemcpyHostToDevice, h->stream);
             hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->rc_stream, wd + 24, (uint64_t)1, 0u);
+            hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->scan_stream, wd + 40, (uint64_t)1, 0u);
             hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->copy_stream, wd + 32, (uint64_t)1, 0u);
             (void)hipMemcpyAsync(h->pinned + 61, wd + 32, 8, hipMemcpyDeviceToHost, h->copy_stream);
             (void)hipMemcpyAsync(h->pinned + 60, wd + 16, 8, hipMemcpyDeviceToHost, h->stream);
             (void)hipStreamSynchronize(h->up_stream);
             (void)hipStreamSynchronize(h->rc_stream);
+            if (h->scan_stream) (void)hipStreamSynchronize(h->scan_stream);
+            (void)hipStreamSynchronize(h->scan_stream);
             (void)hipStreamSynchronize(h->copy_stream);
             (void)hipStreamSynchronize(h->stream);
             (void)hipFree(w);
@@ -1348,7 +1377,7 @@ po_status upload(po_handle* h) {
             // test mode: the host's own store 1 is uploaded next to the generated one and compared word by word
             DevBuf tmp;
             PO_TRY(ensure(h, tmp, h->words[1].size() * 8));
-            PO_TRY(ensure(h, h->d_scalars, 64));
+            PO_TRY(ensure(h, h->d_scalars, 128));
             HIP_TRY(h, hipMemsetAsync(h->d_scalars.p, 0, 64, h->stream));
             HIP_TRY(h, hipMemcpyAsync(tmp.p, h->words[1].data(), h->words[1].size() * 8, hipMemcpyHostToDevice, h->stream));
             hipLaunchKernelGGL(po::k_count_diff, dim3(1024), dim3(256), 0, h->stream, dw + base1, tmp.as<uint64_t>(),
@@ -1369,7 +1398,7 @@ po_status upload(po_handle* h) {
     const bool try_paired = h->bits == 2 && n >= 2 && (n % 2) == 0 && mirror_ok && !generate;
     if (generate && mirror_ok) h->paired = true;  // (checked word by word on the host as the reads arrived)
     if (try_paired) {
-        PO_TRY(ensure(h, h->d_scalars, 64));
+        PO_TRY(ensure(h, h->d_scalars, 128));
         HIP_TRY(h, hipMemsetAsync(h->d_scalars.p, 0, 64, h->stream));
         const uint8_t* pair_state = nullptr;
         if (n_exc) {  // pairs with exception records were compared byte-wise on the host
@@ -1423,11 +1452,11 @@ void shard_range(const po_handle* h, uint32_t shard, uint32_t nshards, uint32_t*
 // exclusive scan of n items (u8 or u32) -> u32 offsets; *total_host gets the grand total
 // (a pinned slot: valid after the next hipStreamSynchronize)
 // the state of the single-pass scans (kernels.hip.h, ChainState): zero when allocated, left zero by every launch
-po_status chain_state(po_handle* h, uint32_t n_tiles, po::ChainState** out) {
+po_status chain_state(po_handle* h, uint32_t n_tiles, po::ChainState** out, hipStream_t on) {
     const size_t need = po::chain_state_bytes(n_tiles);
     if (need > h->d_chain_state.cap) {
         PO_TRY(ensure(h, h->d_chain_state, std::max<size_t>(need * 2, 1u << 16)));
-        HIP_TRY(h, hipMemsetAsync(h->d_chain_state.p, 0, h->d_chain_state.cap, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_chain_state.p, 0, h->d_chain_state.cap, on));
     }
     *out = h->d_chain_state.as<po::ChainState>();
     return PO_OK;
@@ -1435,11 +1464,13 @@ po_status chain_state(po_handle* h, uint32_t n_tiles, po::ChainState** out) {
 
 template <typename T>
 po_status prefix_sum(po_handle* h, const T* in, uint64_t n, uint32_t* out, volatile uint64_t* total_host,
-                     const uint64_t* also_src = nullptr, volatile uint64_t* also_host = nullptr, const uint32_t* extra = nullptr) {
+                     const uint64_t* also_src = nullptr, volatile uint64_t* also_host = nullptr, const uint32_t* extra = nullptr,
+                     hipStream_t on = nullptr, uint64_t* total_dev_at = nullptr) {
     *total_host = 0;
     if (n == 0) return PO_OK;
+    const hipStream_t ps = on ? on : h->stream;
     const uint32_t nblocks = cdiv(n, po::PS_TILE);
-    uint64_t* total_dev = h->d_scalars.as<uint64_t>();
+    uint64_t* total_dev = total_dev_at ? total_dev_at : h->d_scalars.as<uint64_t>();
     uint64_t* total_mapped = h->pinned_dev + (const_cast<uint64_t*>(total_host) - h->pinned);   // the slot as the device sees it
     uint64_t* also_mapped = also_host ? h->pinned_dev + (const_cast<uint64_t*>(also_host) - h->pinned) : nullptr;
     if (nblocks <= 64 && !getenv("PHASM_PS_CLASSIC")) {
@@ -1448,21 +1479,21 @@ po_status prefix_sum(po_handle* h, const T* in, uint64_t n, uint32_t* out, volat
         // XCDs are slower than three launches
 
         po::ChainState* cs = nullptr;
-        PO_TRY(chain_state(h, nblocks, &cs));
-        hipLaunchKernelGGL(po::k_ps_chain<T>, dim3(nblocks), dim3(po::PS_BLOCK), 0, h->stream, const_cast<T*>(in), extra, n, out, cs,
+        PO_TRY(chain_state(h, nblocks, &cs, ps));
+        hipLaunchKernelGGL(po::k_ps_chain<T>, dim3(nblocks), dim3(po::PS_BLOCK), 0, ps, const_cast<T*>(in), extra, n, out, cs,
                            nblocks, total_dev, total_mapped, also_src, also_mapped);
         HIP_TRY(h, hipGetLastError());
         return PO_OK;
     }
     if (extra) {   // (u32 inputs: add in place first, as a launch of its own)
-        hipLaunchKernelGGL(po::k_add_extra, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(in)),
+        hipLaunchKernelGGL(po::k_add_extra, dim3(cdiv(n, 256)), dim3(256), 0, ps, const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(in)),
                            extra, 0u, (uint32_t)n);
     }
     PO_TRY(ensure_piece(h, h->d_ps_blocks, (size_t)nblocks * 8));
     uint64_t* blocks = h->d_ps_blocks.as<uint64_t>();
-    hipLaunchKernelGGL(po::k_ps_reduce<T>, dim3(nblocks), dim3(po::PS_BLOCK), 0, h->stream, in, n, blocks);
-    hipLaunchKernelGGL(po::k_ps_spine, dim3(1), dim3(1024), 0, h->stream, blocks, nblocks, total_dev, total_mapped, also_src, also_mapped);
-    hipLaunchKernelGGL(po::k_ps_down<T>, dim3(nblocks), dim3(po::PS_BLOCK), 0, h->stream, in, n, blocks, out);
+    hipLaunchKernelGGL(po::k_ps_reduce<T>, dim3(nblocks), dim3(po::PS_BLOCK), 0, ps, in, n, blocks);
+    hipLaunchKernelGGL(po::k_ps_spine, dim3(1), dim3(1024), 0, ps, blocks, nblocks, total_dev, total_mapped, also_src, also_mapped);
+    hipLaunchKernelGGL(po::k_ps_down<T>, dim3(nblocks), dim3(po::PS_BLOCK), 0, ps, in, n, blocks, out);
     HIP_TRY(h, hipGetLastError());
     return PO_OK;
 }
@@ -1470,12 +1501,14 @@ po_status prefix_sum(po_handle* h, const T* in, uint64_t n, uint32_t* out, volat
 // one-workgroup form for short u32 inputs (kernels.hip.h, k_ps_small); `extra` is added into `in` first, `also_src`
 // (a device counter) lands in the pinned slot `also_host`
 po_status prefix_sum_small(po_handle* h, uint32_t* in, const uint32_t* extra, uint32_t n, uint32_t* out, volatile uint64_t* total_host,
-                           const uint64_t* also_src, volatile uint64_t* also_host) {
+                           const uint64_t* also_src, volatile uint64_t* also_host, hipStream_t on = nullptr, uint64_t* total_dev_at = nullptr) {
     *total_host = 0;
     if (n == 0) return PO_OK;
+    const hipStream_t ps = on ? on : h->stream;
+    uint64_t* total_dev = total_dev_at ? total_dev_at : h->d_scalars.as<uint64_t>();
     uint64_t* total_mapped = h->pinned_dev + (const_cast<uint64_t*>(total_host) - h->pinned);
     uint64_t* also_mapped = also_host ? h->pinned_dev + (const_cast<uint64_t*>(also_host) - h->pinned) : nullptr;
-    hipLaunchKernelGGL(po::k_ps_small, dim3(1), dim3(1024), 0, h->stream, in, extra, n, out, h->d_scalars.as<uint64_t>(), total_mapped,
+    hipLaunchKernelGGL(po::k_ps_small, dim3(1), dim3(1024), 0, ps, in, extra, n, out, total_dev, total_mapped,
                        also_src, also_mapped);
     HIP_TRY(h, hipGetLastError());
     return PO_OK;
@@ -1559,6 +1592,10 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     const uint32_t paired = (BITS == 2 && h->paired && dpE == 0) ? (streamed ? po::PAIRED_STREAM_ALL : nshards > 1 ? 2u : 1u) : 0u;
     const uint32_t paired_ver = streamed ? po::paired_stream(h->st_r_end) : paired;
     if (streamed && (!paired || want_cands)) return fail(h, PO_ERR_INVALID, "streamed step without strand pairs");
+    // two-stream pieces (po_handle::scan_stream): the counting pass of this piece runs on s1, beside the second half of the
+    // piece before it on st
+    const bool two = streamed && h->two_stream && !h->idx_only;
+    const hipStream_t s1 = two ? h->scan_stream : st;
     S.paired = paired ? 1u : 0u;
     S.max_diff = dpE;
     S.band = dpW;
@@ -1640,7 +1677,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     while (bloom_log2 < 20 && (1ull << bloom_log2) < 16 * n_elig) ++bloom_log2;
     const size_t bloom_bytes = (size_t)1 << (bloom_log2 - 3);
 
-    PO_TRY(ensure(h, h->d_scalars, 64));
+    PO_TRY(ensure(h, h->d_scalars, 128));
     const size_t n_entries = wide ? (size_t)n * W : (size_t)n;     // index entries (slots of read_slot / chain)
     const size_t chain_elem = wide ? 8 : 4;
     if (!ext_idx) {   // (a supplied index needs none of the build's workspaces)
@@ -1659,7 +1696,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     PO_TRY(ensure(h, h->d_bloom, bloom_bytes));
     PO_TRY(ensure(h, h->d_selfrep, (size_t)n * 4));
     PO_TRY(ensure(h, h->d_tile_count, ((size_t)h->n_tiles + 1) * 4));
-    PO_TRY(ensure(h, h->d_tile_off, ((size_t)h->n_tiles + 2) * 4));
+    PO_TRY(ensure(h, h->d_tile_off, ((size_t)h->n_tiles + 2) * 4 * 2));   // (twice: the pieces of a streamed step alternate)
     PO_TRY(ensure(h, h->d_truemask, ((size_t)h->n_tiles + 1) * po::WAVE * 4));
 
     const uint64_t* words = h->d_words.as<uint64_t>();
@@ -1673,7 +1710,11 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     uint32_t* chain = h->d_chain.as<uint32_t>();
     uint32_t* bloom = h->d_bloom.as<uint32_t>();
     uint32_t* selfrep = h->d_selfrep.as<uint32_t>();
-    unsigned long long* scalars = h->d_scalars.as<unsigned long long>();  // [0] scan total, [1] n_long, [4..6] emit counters
+    // The small state both halves of a piece touch exists twice, by the piece's parity: while the second half of piece k reads
+    // its candidate count and tile offsets, the counting pass of piece k + 1 writes its own (two-stream pieces, see po_handle)
+    const uint32_t parity = streamed ? (shard & 1u) : 0u;
+    unsigned long long* scalars = h->d_scalars.as<unsigned long long>() + 8 * parity;  // [0] scan total, [1] n_long, [3] rows, [4..7] emit counters
+    uint32_t* const tile_off_p = h->d_tile_off.as<uint32_t>() + (size_t)parity * ((size_t)h->n_tiles + 2);
     uint32_t* n_long = reinterpret_cast<uint32_t*>(scalars + 1);
 
     if (h->poison >= 0) {
@@ -1705,13 +1746,13 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     const bool fold_clear = reuse_index && !wide;
     if (fold_clear) {
     } else if (reuse_index || ext_idx) {
-        hipLaunchKernelGGL(po::k_call_reset, dim3(cdiv(std::max(n, 8u), 256)), dim3(256), 0, st, selfrep, n, scalars,
+        hipLaunchKernelGGL(po::k_call_reset, dim3(cdiv(std::max(n, 16u), 256)), dim3(256), 0, s1, selfrep, n, scalars, 8u,
                            (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, 0u);
     } else {
         const uint32_t bloom_words = (uint32_t)(bloom_bytes / 4);
         const uint32_t init_n = std::max(std::max(nslots, n), std::max(bloom_words, 8u));
         hipLaunchKernelGGL(po::k_call_init, dim3(cdiv(init_n, 256)), dim3(256), 0, st, table, nslots, slot_cnt, slot_cur, selfrep, n,
-                           bloom, bloom_words, scalars);
+                           bloom, bloom_words, h->d_scalars.as<unsigned long long>());
     }
     if (reuse_index || ext_idx) {
         // (nothing to build)
@@ -1771,6 +1812,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     if (h->idx_only) {
         // (streamed step: the index is built from the first words of every read while piece 0 is still on the wire; the
         // pieces find it valid -- same upload, min_length, flavour -- and reuse it)
+        if (h->ev_idx) HIP_TRY(h, hipEventRecord(h->ev_idx, st));
         h->idx_valid = true;
         h->idx_gen = h->upload_gen;
         h->idx_m = m;
@@ -1788,6 +1830,13 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     h->idx_bits = (uint32_t)BITS;
     h->idx_ww = ww;
 
+    if (two) {
+        // the counting pass needs the index (and the per-read tables and tiles queued before it), this piece's reads with their
+        // reverse complements, and the parity's small state free again: the second half of the piece two before this one
+        HIP_TRY(h, hipStreamWaitEvent(s1, h->ev_idx, 0));
+        HIP_TRY(h, hipStreamWaitEvent(s1, h->ev_rc[h->st_k], 0));
+        if (h->st_k >= 2) HIP_TRY(h, hipStreamWaitEvent(s1, h->ev[EV_DONE], 0));
+    }
     // ---- scan, counting pass
     po::ScanArgs A = {};
     A.words = words;
@@ -1806,7 +1855,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     A.selfrep = selfrep;
     A.n_selfrep = reinterpret_cast<uint32_t*>(scalars + 2);  // scalars[2] lo: reads with a self-repeating prefix
     A.tile_count = h->d_tile_count.as<uint32_t>();
-    A.tile_off = h->d_tile_off.as<uint32_t>();
+    A.tile_off = tile_off_p;
     A.truemask = h->d_truemask.as<uint32_t>();
 #ifdef PO_STAMPS
     PO_TRY(ensure(h, h->d_flag, (size_t)4096 * 64));
@@ -1839,11 +1888,11 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     WA.lane_slot = A.truemask;
     WA.tile_off = A.tile_off;
     if (wide) {
-        if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE0], st));
+        if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE0], s1));
         auto wscan = streamed ? po::k_wide_scan<BITS, false, BITS == 2, 1>
                      : ww == 16 ? po::k_wide_scan<BITS, false, false, 16> : ww == 4 ? po::k_wide_scan<BITS, false, false, 4> : po::k_wide_scan<BITS, false, false, 1>;
-        hipLaunchKernelGGL(wscan, dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA, po::CandGuard{nullptr, 0u});
-        if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
+        hipLaunchKernelGGL(wscan, dim3(cdiv(ntiles, 4)), dim3(256), 0, s1, WA, po::CandGuard{nullptr, 0u});
+        if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], s1));
     } else {
         const size_t scan_lds = (size_t)scan_waves * po::SCAN_LDS_PER_WAVE + bloom_bytes;
         if (scan_lds > h->lds_max) return fail(h, PO_ERR_HIP, "device LDS too small for the scan kernel");
@@ -1864,25 +1913,27 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             // nothing to launch
         } else if (fold_clear) {
             const uint32_t te0 = self_clean ? 0u : tile_begin, ten = self_clean ? h->n_tiles : ntiles;
-            hipLaunchKernelGGL(po::k_call_reset, dim3(cdiv(std::max(std::max(n, 8u), std::max(n_scan_waves, ten)), 256)), dim3(256), 0, st,
-                               selfrep, n, scalars, h->d_left_cnt.as<uint32_t>(), n_scan_waves, h->d_tile_extra.as<uint32_t>() + te0, ten);
+            // (a self-cleaning step's first piece zeroes both parities' scalars; any other reset only its own block)
+            hipLaunchKernelGGL(po::k_call_reset, dim3(cdiv(std::max(std::max(n, 16u), std::max(n_scan_waves, ten)), 256)), dim3(256), 0, s1,
+                               selfrep, n, self_clean ? h->d_scalars.as<unsigned long long>() : scalars, self_clean ? 16u : 8u,
+                               h->d_left_cnt.as<uint32_t>(), n_scan_waves, h->d_tile_extra.as<uint32_t>() + te0, ten);
         } else {
-            HIP_TRY(h, hipMemsetAsync(h->d_left_cnt.p, 0, (size_t)n_scan_waves * 4, st));
-            HIP_TRY(h, hipMemsetAsync(h->d_tile_extra.as<uint32_t>() + tile_begin, 0, (size_t)ntiles * 4, st));
+            HIP_TRY(h, hipMemsetAsync(h->d_left_cnt.p, 0, (size_t)n_scan_waves * 4, s1));
+            HIP_TRY(h, hipMemsetAsync(h->d_tile_extra.as<uint32_t>() + tile_begin, 0, (size_t)ntiles * 4, s1));
         }
         A.left = h->d_left.as<uint2>();
         A.left_cnt = h->d_left_cnt.as<uint32_t>();
         A.tile_extra = h->d_tile_extra.as<uint32_t>();
-        if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE0], st));
-        hipLaunchKernelGGL(K == W ? probe_full : probe_part, dim3(scan_grid), dim3(scan_waves * 64), scan_lds, st, A);
-        if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], st));
+        if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE0], s1));
+        hipLaunchKernelGGL(K == W ? probe_full : probe_part, dim3(scan_grid), dim3(scan_waves * 64), scan_lds, s1, A);
+        if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], s1));
         auto fixup = streamed ? po::k_scan_fixup<BITS, CAN_STREAM> : po::k_scan_fixup<BITS, false>;
-        hipLaunchKernelGGL(fixup, dim3(n_scan_waves), dim3(256), 0, st, A, n_scan_waves, self_clean ? 1u : 0u);
+        hipLaunchKernelGGL(fixup, dim3(n_scan_waves), dim3(256), 0, s1, A, n_scan_waves, self_clean ? 1u : 0u);
         // (the leftover counts, tile_extra, are added to the tile counts by the prefix sum below)
         if (getenv("PHASM_DEBUG_LEFT")) {  // how many positions did the scan waves defer to k_scan_fixup?
             PO_TRY(ensure_host(h, h->scratch_host, (size_t)n_scan_waves * 4));
-            HIP_TRY(h, hipMemcpyAsync(h->scratch_host.p, h->d_left_cnt.p, (size_t)n_scan_waves * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(h, hipStreamSynchronize(st));
+            HIP_TRY(h, hipMemcpyAsync(h->scratch_host.p, h->d_left_cnt.p, (size_t)n_scan_waves * 4, hipMemcpyDeviceToHost, s1));
+            HIP_TRY(h, hipStreamSynchronize(s1));
             const uint32_t* lc = static_cast<const uint32_t*>(h->scratch_host.p);
             uint64_t sum = 0;
             uint32_t mx = 0;
@@ -1933,14 +1984,18 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     volatile uint64_t* also_slot = async_count ? &h->pinned[zone + 9] : &h->pinned[8];
     if (ntiles <= po::PS_SMALL_MAX) {
         PO_TRY(prefix_sum_small(h, A.tile_count + tile_begin, wide ? nullptr : A.tile_extra + tile_begin, ntiles,
-                                h->d_tile_off.as<uint32_t>() + tile_begin, count_slot,
-                                reinterpret_cast<const uint64_t*>(scalars + 2), also_slot));
+                                tile_off_p + tile_begin, count_slot,
+                                reinterpret_cast<const uint64_t*>(scalars + 2), also_slot, s1, reinterpret_cast<uint64_t*>(scalars)));
     } else {
-        PO_TRY(prefix_sum<uint32_t>(h, A.tile_count + tile_begin, ntiles, h->d_tile_off.as<uint32_t>() + tile_begin, count_slot,
+        PO_TRY(prefix_sum<uint32_t>(h, A.tile_count + tile_begin, ntiles, tile_off_p + tile_begin, count_slot,
                                     reinterpret_cast<const uint64_t*>(scalars + 2), also_slot,
-                                    wide ? nullptr : A.tile_extra + tile_begin));
+                                    wide ? nullptr : A.tile_extra + tile_begin, s1, reinterpret_cast<uint64_t*>(scalars)));
     }
-    if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_COUNT], st));
+    if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_COUNT], s1));
+    if (two) {   // everything behind the counting pass runs on the handle's stream, after it
+        HIP_TRY(h, hipEventRecord(h->ev_s1[parity], s1));
+        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_s1[parity], 0));
+    }
     po::CandGuard G = {nullptr, 0u};
     uint64_t n_cand64;
     uint32_t n_selfrep_reads;
@@ -1959,7 +2014,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             HIP_TRY(h, hipEventSynchronize(h->st_pend.ev[EV_DONE]));
             PO_TRY(h->st_harvest());
         }
-        HIP_TRY(h, hipStreamSynchronize(st));
+        HIP_TRY(h, hipStreamSynchronize(s1));
         n_cand64 = h->pinned[1];
         n_selfrep_reads = (uint32_t)h->pinned[8];
     }
@@ -2125,7 +2180,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                     dfo.counter = h->d_defer.as<uint32_t>() + (size_t)h->st_defer_cap * 4;
                 }
                 hipLaunchKernelGGL(po::k_read_label, dim3(cdiv((uint64_t)n_a * 16, 256)), dim3(256), 0, st,
-                                   h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_b, r_begin, n_a, paired,
+                                   h->d_read_tile0.as<uint32_t>(), tile_off_p, A.cand_b, r_begin, n_a, paired,
                                    h->d_vlabel.as<uint32_t>(), dfo, G);
                 if (sort_lds > 48 * 1024)
                     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(po::k_read_sort),
@@ -2150,7 +2205,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                 HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(verify), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ver_lds));
             if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_VER0], st));
             hipLaunchKernelGGL(verify, dim3(ver_grid), dim3(po::VER_BLOCK), ver_lds, st,
-                               words, woff, len, h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_p,
+                               words, woff, len, h->d_read_tile0.as<uint32_t>(), tile_off_p, A.cand_p,
                                A.cand_b, r_begin, lds_words, paired_ver,
                                h->n_exc_uploaded ? h->d_exc_off.as<uint32_t>() : nullptr, h->d_exc_pos.as<uint32_t>(),
                                h->d_exc_byte.as<uint8_t>(), h->d_type.as<uint8_t>(), perm, n_a, G);
@@ -2176,7 +2231,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         if (nshards > 1 || streamed || wide || dpE) {
             static_assert(po::SEL_CAP == 512, "k_select_local hashes to 9 bits");
             hipLaunchKernelGGL(po::k_select_local, dim3(cdiv(r_end - r_begin, 256 / po::WAVE)), dim3(256), 0, st,
-                               h->d_read_tile0.as<uint32_t>(), h->d_tile_off.as<uint32_t>(), A.cand_p, A.cand_b, h->d_type.as<uint8_t>(),
+                               h->d_read_tile0.as<uint32_t>(), tile_off_p, A.cand_p, A.cand_b, h->d_type.as<uint8_t>(),
                                r_begin, r_end - r_begin, selfrep, n_deferred, G);
         }
         // A candidate gives at most 2 rows (4 with their mirrors: worst_rows).  When the row buffer kept from an earlier
@@ -2450,7 +2505,7 @@ po_status run_expand(po_handle* h, const void* d_cands, uint64_t n, po_result* r
     if (n >= 0xFFFFFF00ull) return fail(h, PO_ERR_CAPACITY, "candidate count exceeds one call's capacity (2^32)");
     const uint32_t nc = (uint32_t)n;
     const uint32_t paired = (h->bits == 2 && h->paired) ? 1u : 0u;
-    PO_TRY(ensure(h, h->d_scalars, 64));
+    PO_TRY(ensure(h, h->d_scalars, 128));
     PO_TRY(ensure(h, h->d_rowcnt, (size_t)nc));
     PO_TRY(ensure(h, h->d_row_off, ((size_t)nc + 1) * 4));
     unsigned long long* scalars = h->d_scalars.as<unsigned long long>();
@@ -2549,7 +2604,7 @@ po_status run_layout(po_handle* h, po_result* rows, const po_layout_params& prm,
     PO_TRY(rows_to_device(h, rows));
     PO_TRY(ensure(h, h->d_lay_len, ((size_t)n_nodes + 1) * 4));
     PO_TRY(ensure(h, h->d_lay_cnt, 128));
-    PO_TRY(ensure(h, h->d_scalars, 64));
+    PO_TRY(ensure(h, h->d_scalars, 128));
     PO_TRY(ensure(h, h->d_rflag, (size_t)n_rows + 1));
     PO_TRY(ensure(h, h->d_removed, (size_t)n_names + 1));
     if (n_nodes) HIP_TRY(h, hipMemcpyAsync(h->d_lay_len.p, h->len.data(), (size_t)n_nodes * 4, hipMemcpyHostToDevice, st));
@@ -2995,6 +3050,7 @@ void po_destroy(po_handle* h) {
         if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
         if (h->up_stream) (void)hipStreamSynchronize(h->up_stream);
         if (h->rc_stream) (void)hipStreamSynchronize(h->rc_stream);
+        if (h->scan_stream) (void)hipStreamSynchronize(h->scan_stream);
         for (DevBuf* b : bufs) b->release();
         const bool pooled = kit_give(h);
         if (!pooled) {
@@ -3030,9 +3086,17 @@ void po_destroy(po_handle* h) {
         if (h->ev_meta) (void)hipEventDestroy(h->ev_meta);
         if (h->rc_stream) {
             (void)hipStreamSynchronize(h->rc_stream);
+            if (h->scan_stream) (void)hipStreamSynchronize(h->scan_stream);
             (void)hipStreamDestroy(h->rc_stream);
         }
         if (h->ev_first) (void)hipEventDestroy(h->ev_first);
+        if (h->scan_stream) {
+            (void)hipStreamSynchronize(h->scan_stream);
+            (void)hipStreamDestroy(h->scan_stream);
+        }
+        for (hipEvent_t e : h->ev_s1)
+            if (e) (void)hipEventDestroy(e);
+        if (h->ev_idx) (void)hipEventDestroy(h->ev_idx);
         if (h->copy_stream) {
             (void)hipStreamSynchronize(h->copy_stream);
             (void)hipStreamDestroy(h->copy_stream);
@@ -3730,9 +3794,13 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
     // the index ahead of piece 0: it needs every read's first word(s) only, and at 400 k reads (wide index, 2.9 ms; 16 ms at
     // 2 M reads) building it inside piece 0 -- after the piece has landed -- kept every later piece 2-3 ms behind its data
     h->st_selfclean = false;
+    h->two_stream = false;
     h->st_early_index = P > 1 && h->poison < 0 && !getenv("PHASM_NO_INDEX_REUSE") && !getenv("PHASM_LATE_INDEX");
     PO_TRY(stream_begin(h, bounds));
     if (trace) std::fprintf(stderr, "[stream] %u pieces queued at %.3f ms\n", P, since());
+    // (two-stream pieces need the index built ahead -- its event is what the first counting pass waits for -- and no poison
+    // fills; PHASM_TWO_STREAM=0 keeps every piece on the handle's stream)
+    h->two_stream = h->st_early_index && h->scan_stream && h->ev_idx && !(getenv("PHASM_TWO_STREAM") && atoi(getenv("PHASM_TWO_STREAM")) == 0);
     if (h->st_early_index) {
         po_result part;
         part.h = h;
@@ -3748,6 +3816,7 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
             (void)hipStreamSynchronize(h->stream);
             (void)hipStreamSynchronize(h->up_stream);
             (void)hipStreamSynchronize(h->rc_stream);
+            if (h->scan_stream) (void)hipStreamSynchronize(h->scan_stream);
             h->dirty = true;
             return ist;
         }
@@ -3788,6 +3857,7 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
         // piece k has landed and its odd reads (reverse complements) have been written next to it (rc_stream, stream_begin)
         if (hipStreamWaitEvent(h->stream, h->ev_rc[k], 0) != hipSuccess) { st = fail(h, PO_ERR_HIP, "hipStreamWaitEvent"); break; }
         h->st_on = true;
+        h->st_k = k;
         h->st_r_begin = bounds[k];
         h->st_r_end = bounds[k + 1];
         // per-piece workspaces: sized for the largest piece when they are first needed.  A piece keeps the candidates
@@ -3826,6 +3896,7 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamSynchronize(h->up_stream);
         (void)hipStreamSynchronize(h->rc_stream);
+        if (h->scan_stream) (void)hipStreamSynchronize(h->scan_stream);
         h->dirty = true;
         h->st_tail_gave_up = true;
         h->st_pred_valid = false;
@@ -3835,6 +3906,7 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
     if (st != PO_OK) {
         (void)hipStreamSynchronize(h->up_stream);
         (void)hipStreamSynchronize(h->rc_stream);
+        if (h->scan_stream) (void)hipStreamSynchronize(h->scan_stream);
         h->dirty = true;   // (a piece may be missing on the device)
         h->st_pred_valid = false;
         return st;
@@ -3966,6 +4038,7 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
     if (h->dev_ready) (void)hipStreamSynchronize(h->stream);
     if (h->up_stream) (void)hipStreamSynchronize(h->up_stream);
     if (h->rc_stream) (void)hipStreamSynchronize(h->rc_stream);
+    if (h->scan_stream) (void)hipStreamSynchronize(h->scan_stream);
     if (h->copy_stream && hipStreamSynchronize(h->copy_stream) != hipSuccess && st == PO_OK) st = fail(h, PO_ERR_HIP, "row copy device->host");
     {
         // the helper threads have written every piece's rows before the array is handed out (or released)

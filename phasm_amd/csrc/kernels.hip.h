@@ -304,7 +304,7 @@ __device__ inline void table_probe(const Slot* __restrict__ tab, uint32_t tbits,
 // Everything a call starts from, in one launch: empty table, zero slot counters, "no self-repeat" for every
 // read, an empty filter and zero scalars (four small launches and memsets cost ~5 us each in a 2.6 ms step).
 __global__ void k_call_init(Slot* tab, uint32_t nslots, uint32_t* slot_cnt, uint32_t* slot_cur, uint32_t* selfrep,
-                            uint32_t n_reads, uint32_t* bloom, uint32_t bloom_words, unsigned long long* scalars) {
+                            uint32_t n_reads, uint32_t* bloom, uint32_t bloom_words, unsigned long long* scalars) {   // scalars: both blocks (16)
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nslots) {
         tab[i].key = KEY_EMPTY;
@@ -315,15 +315,15 @@ __global__ void k_call_init(Slot* tab, uint32_t nslots, uint32_t* slot_cnt, uint
     }
     if (i < n_reads) selfrep[i] = NO_SELFREP;
     if (i < bloom_words) bloom[i] = 0;
-    if (i < 8) scalars[i] = 0;
+    if (i < 16) scalars[i] = 0;
 }
 
 // the per-call part of k_call_init, for a call that reuses the index of the previous one
-__global__ void k_call_reset(uint32_t* selfrep, uint32_t n_reads, unsigned long long* scalars, uint32_t* clear_a, uint32_t n_a,
+__global__ void k_call_reset(uint32_t* selfrep, uint32_t n_reads, unsigned long long* scalars, uint32_t n_scalars, uint32_t* clear_a, uint32_t n_a,
                              uint32_t* clear_b, uint32_t n_b) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_reads) selfrep[i] = NO_SELFREP;
-    if (i < 8) scalars[i] = 0;
+    if (i < n_scalars) scalars[i] = 0;   // (8: this piece's block; 16: both blocks, from the base)
     // (two small per-call arrays of the narrow scan, cleared here instead of by two fill commands)
     if (i < n_a) clear_a[i] = 0;
     if (i < n_b) clear_b[i] = 0;
