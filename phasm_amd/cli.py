@@ -63,10 +63,12 @@ def overlap(args) -> int:
 
     args.output.write(gfa.gfa_header())
     overlapper = ExactOverlapper(device=getattr(args, "device", None))
+    mark("library loaded, handle made")
     logger.info("Packing reads and searching for pairwise overlaps on the GPU...")
     if isinstance(args.fasta_input, (str, bytes)) and not getattr(args, "python_ingest", False):
         # native parse + reverse complement + 2-bit pack in one pass (po_add_fasta)
         overlapper.add_fasta(args.fasta_input, both_strands=True)
+        mark("FASTA parsed, reverse-complemented, packed (the device comes up beside it)")
         try:
             args.output.fileno()
             overlapper.write_gfa_segments(args.output)       # S lines formatted in C, straight to the descriptor
@@ -79,7 +81,7 @@ def overlap(args) -> int:
             args.output.write(gfa.gfa_line("S", name, len(seq), "*"))
             overlapper.add_sequence(name + "+", seq)
             overlapper.add_sequence(name + "-", reverse_complement(seq))
-    mark("FASTA ingest + S lines")
+    mark("S lines")
     max_diff = int(getattr(args, "max_diff", 0) or 0)
     if max_diff > 0:
         # beyond the reference (which is exact, assembler.py:436-439): banded seed-extension DP, po_overlaps_ex

@@ -33,6 +33,8 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--max-diff", type=int, default=-1, help=">= 0: po_overlaps_ex (banded DP) with this many differences")
     ap.add_argument("--band", type=int, default=0)
+    ap.add_argument("--windows", default="", help="comma-separated PHASM_WIDE_WINDOW values: the resident call for each of them with the "
+                                                 "index rebuilt every time (PHASM_NO_INDEX_REUSE): index build and scan passes per window")
     ap.add_argument("--host", action="store_true", help="time one host-to-host call: invalidate + upload + po_overlaps_to_host + rows")
     a = ap.parse_args()
     cfg = synth.CONFIGS[a.config]
@@ -55,6 +57,20 @@ if __name__ == "__main__":
                                   "kernels_plus_d2h_ms": round((t2 - t1) * 1e3, 3), "step_ms": round((t2 - t0) * 1e3, 3),
                                   "overlaps_per_sec": round(n / (t2 - t0)), "kernel_ms_sum": round(st["ms_total"], 3),
                                   "index_ms": round(st["ms_index"], 3), "wide": st["wide_index"]}))
+        sys.exit(0)
+    if a.windows:
+        os.environ["PHASM_NO_INDEX_REUSE"] = "1"
+        for w in a.windows.split(","):
+            os.environ["PHASM_WIDE_WINDOW"] = w.strip()
+            for it in range(a.iters):
+                t0 = time.time()
+                res = ov.overlaps_result(a.min_length)
+                dt = time.time() - t0
+                st = ov.stats()
+                n = len(res)
+                res.free()
+                print(json.dumps({"window": int(w), "rows": n, "wall_ms": round(dt * 1e3, 3), "candidates": st["n_candidates"],
+                                  **{k: round(st[k], 3) for k in ("ms_index", "ms_scan_count", "ms_scan_probe", "ms_scan_fill", "ms_verify", "ms_select", "ms_emit", "ms_total")}}), flush=True)
         sys.exit(0)
     for it in range(a.iters):
         t0 = time.time()
