@@ -97,7 +97,12 @@ def measured_peaks() -> dict:
                 "valu_vop3_wave_insts_per_sec_chip": lib.ub_valu(0, 8, 40000) * 1024,   # v_alignbit_b32: VOP3 forms issue at half rate
                 "lds_random_b64_TBps": lib.ub_lds(8, 4000) / 1e12,
                 "l2_hit_TBps": lib.ub_l2(8, 2000, 2 << 20) / 1e12,
-                "fabric_TBps": lib.ub_l2(8, 1000, 64 << 20) / 1e12}
+                "fabric_TBps": lib.ub_l2(8, 1000, 64 << 20) / 1e12,
+                # random 64-byte lines per second beyond an XCD's L2 (a table probe that misses L2: one line per lane), from the
+                # Infinity Cache (64 MB table) and from HBM (2 GB table); and from L2 itself (4 MB table)
+                "random_lines_G_per_s": {"4_MB": lib.ub_rand_lines(4 << 20, 8, 300, 1, 8) / 1e9,
+                                         "64_MB": lib.ub_rand_lines(64 << 20, 8, 300, 1, 8) / 1e9,
+                                         "2048_MB": lib.ub_rand_lines(2048 << 20, 8, 300, 1, 8) / 1e9}}
     except Exception as e:  # noqa: BLE001 -- the bench line must come out even if the microbenchmarks cannot run
         return {"error": repr(e)}
 
@@ -659,6 +664,16 @@ def main() -> int:
             lim = {}
             if v["traffic"] and t > 0:
                 lim["hbm"] = {"GBps": v["traffic"] / t / 1e9, "peak_GBps": HBM_PEAK_GBS}
+            sp = tj.get(args.config + "_split", {}).get(name)
+            rl = peaks.get("random_lines_G_per_s") if isinstance(peaks, dict) else None
+            if sp and rl and t > 0:
+                # the scan's table probes that miss L2 are random 64-byte line requests (calibrated split of FETCH_SIZE,
+                # tools/pmc_to_traffic.py): priced against the rate this memory system gives such requests, measured above
+                # (the narrow table's misses are served by the Infinity Cache, the wide index's by HBM)
+                pk = rl["2048_MB"] if last["wide_index"] else rl["64_MB"]
+                lim["fabric_lines"] = {"G_lines_per_s": sp["random_64B_lines"] / t / 1e9, "peak_G_lines_per_s": pk,
+                                       "random_64B_lines_per_launch": sp["random_64B_lines"], "stream_bytes": sp["stream_bytes"]}
+                v["traffic_uncalibrated_2x_rule"] = sp.get("uncalibrated_2x_rule_bytes")
             if v.get("l2_bytes") and peaks.get("l2_hit_TBps") and t > 0:
                 lim["l2"] = {"GBps": v["l2_bytes"] / t / 1e9, "peak_GBps": peaks["l2_hit_TBps"] * 1e3}
             if v.get("lds_bytes") and peaks.get("lds_random_b64_TBps") and t > 0:
@@ -679,8 +694,8 @@ def main() -> int:
                                "sensitivity_note": "tools/pad_probe.sh: kernel cycles gained per full-rate VALU cycle added to the hot loop "
                                                    "(1 = VALU issue is what the kernel waits for, 0 = the pipe had room)"}
             for k2, x in lim.items():
-                ach = x.get("GBps", x.get("G_simd_cycles_per_s"))
-                pk = x.get("peak_GBps", x.get("peak_G_simd_cycles_per_s"))
+                ach = x.get("GBps", x.get("G_simd_cycles_per_s", x.get("G_lines_per_s")))
+                pk = x.get("peak_GBps", x.get("peak_G_simd_cycles_per_s", x.get("peak_G_lines_per_s")))
                 x["frac"] = ach / pk
             v["limits"] = lim
             if lim:
@@ -690,9 +705,10 @@ def main() -> int:
         d = kern[dom]
         bl = d["limits"].get(d.get("bound", ""), {})
         out["roofline"] = {"bound": d.get("bound"), "kernel": dom,
-                           "achieved": bl.get("GBps", bl.get("G_simd_cycles_per_s")),
-                           "peak": bl.get("peak_GBps", bl.get("peak_G_simd_cycles_per_s")),
-                           "unit": "G SIMD-cycles/s (VALU busy)" if d.get("bound") == "valu" else "GB/s",
+                           "achieved": bl.get("GBps", bl.get("G_simd_cycles_per_s", bl.get("G_lines_per_s"))),
+                           "peak": bl.get("peak_GBps", bl.get("peak_G_simd_cycles_per_s", bl.get("peak_G_lines_per_s"))),
+                           "unit": ("G SIMD-cycles/s (VALU busy)" if d.get("bound") == "valu" else
+                                    "G random 64-B lines/s" if d.get("bound") == "fabric_lines" else "GB/s"),
                            "valu_sensitivity": bl.get("sensitivity"),
                            "frac": d.get("frac"), "traffic": d["traffic"],
                            "hbm_frac": d["limits"].get("hbm", {}).get("frac"),

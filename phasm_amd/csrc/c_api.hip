@@ -3800,7 +3800,10 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
     if (trace) std::fprintf(stderr, "[stream] %u pieces queued at %.3f ms\n", P, since());
     // (two-stream pieces need the index built ahead -- its event is what the first counting pass waits for -- and no poison
     // fills; PHASM_TWO_STREAM=0 keeps every piece on the handle's stream)
-    h->two_stream = h->st_early_index && h->scan_stream && h->ev_idx && !(getenv("PHASM_TWO_STREAM") && atoi(getenv("PHASM_TWO_STREAM")) == 0);
+    // Measured, round 4 (config 2): 7.1-7.2 ms per step against 4.5 on one stream -- the persistent scan kernel takes every CU's
+    // LDS and registers, the verify workgroups of the piece before wait behind it, and both run slower side by side than one
+    // after the other.  Off unless PHASM_TWO_STREAM=1 asks for it.
+    h->two_stream = h->st_early_index && h->scan_stream && h->ev_idx && getenv("PHASM_TWO_STREAM") && atoi(getenv("PHASM_TWO_STREAM")) != 0;
     if (h->st_early_index) {
         po_result part;
         part.h = h;
