@@ -680,7 +680,9 @@ struct Pool {
     std::atomic<int> error{0};       // 1: counts disagree, 2: a record names an unknown read
     // the call's read set
     const uint32_t* len = nullptr;
-    uint32_t n_reads = 0, paired = 0;
+    uint32_t n_reads = 0, paired = 0, bits = 2;
+    // byte counters of po_stats over the call's records (k_emit / k_tail sum them on the device for rows emitted there)
+    std::atomic<uint64_t> sum_l{0}, sum_b{0}, sum_e{0};
     // the piece being expanded
     Job cur;
     po_row* part_next = nullptr;     // where the next part of the current piece starts
@@ -750,9 +752,31 @@ void run_phases(Pool& P, bool lead) {
         const uint32_t c = P.next_count.fetch_add(1, std::memory_order_relaxed);
         if (c >= nc) break;
         const uint64_t lo = (uint64_t)c * CHUNK, hi = std::min<uint64_t>(P.cur.n_rec, lo + CHUNK);
-        uint64_t n = 0;
-        for (uint64_t i = lo; i < hi; ++i) n += rows_of_rec(P.cur.rec[i], P.paired);
+        uint64_t n = 0, sl = 0, sb = 0, se = 0;
+        const uint32_t n_reads = P.n_reads, bits = P.bits, paired = P.paired;
+        auto pb = [bits](uint32_t l) -> uint64_t { return bits == 8u ? l : (l >> 2) + ((l & 3u) != 0u); };
+        for (uint64_t i = lo; i < hi; ++i) {
+            const po::Cand c = P.cur.rec[i];
+            n += rows_of_rec(c, paired);
+            if (c.a < n_reads && c.b < n_reads) {   // (write_rows' counters, kernels.hip.h)
+                const uint32_t la = P.len[c.a], lb = P.len[c.b];
+                se += 2 * pb((c.type & 1u) ? la - c.p : lb);
+                if (c.type & 1u) {
+                    const uint64_t k = (paired && c.a != (c.b ^ 1u)) ? 2 : 1;
+                    sl += k * (la - c.p);
+                    sb += k * 2 * pb(la - c.p);
+                }
+                if (c.type & 2u) {
+                    const uint64_t k = paired ? 2 : 1;
+                    sl += k * lb;
+                    sb += k * 2 * pb(lb);
+                }
+            }
+        }
         P.chunk_off[c + 1] = n;
+        P.sum_l.fetch_add(sl, std::memory_order_relaxed);
+        P.sum_b.fetch_add(sb, std::memory_order_relaxed);
+        P.sum_e.fetch_add(se, std::memory_order_relaxed);
         P.done_count.fetch_add(1, std::memory_order_release);
     }
     if (lead) {
@@ -871,6 +895,9 @@ void begin(Pool* P, const uint32_t* len, uint32_t n_reads, bool tracing) {
     P->error.store(0);
     P->submitted.store(0);
     P->finished.store(0);
+    P->sum_l.store(0);
+    P->sum_b.store(0);
+    P->sum_e.store(0);
     P->tracing = tracing;
     P->trace.clear();
     P->t0 = std::chrono::steady_clock::now();
@@ -2396,8 +2423,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             if (compact_tail) {
                 res->compact = true;
                 hipLaunchKernelGGL(po::k_tail_cands, dim3(n_tt), dim3(po::TAIL_BLOCK), 0, st, A.cand_a, A.cand_p, A.cand_b, h->d_type.as<uint8_t>(),
-                                   n_cand, len, res->d_rows.as<po::Cand>(), (uint32_t)BITS, paired, tgate, tile_rows, n_tt, tail_done,
-                                   scalars + 4, scalars + 3, h->pinned_dev + tail_zone, G);
+                                   n_cand, res->d_rows.as<po::Cand>(), paired, tgate, tile_rows, n_tt, tail_done,
+                                   scalars + 3, h->pinned_dev + tail_zone, G);
             } else
             hipLaunchKernelGGL(po::k_tail, dim3(n_tt), dim3(po::TAIL_BLOCK), 0, st, A.cand_a, A.cand_p, A.cand_b, h->d_type.as<uint8_t>(),
                                n_cand, len, res->d_rows.as<po::Row>(), (uint32_t)BITS, paired, tgate, tile_rows, n_tt, tail_done,
@@ -3497,11 +3524,16 @@ void home_wait(po_handle* h) {
 }
 
 // returns the pool's error code (0 = fine)
-int home_end(po_handle* h) {
+int home_end(po_handle* h, po_stats* sum = nullptr) {
     if (!h->home_on) return 0;
     home::Pool* P = home::g_pool;
     home::wait_all(P);
     const int err = P->error.load();
+    if (sum) {   // (the byte counters of the pieces that went home as records)
+        sum->sum_overlap_bases += P->sum_l.load();
+        sum->verify_bytes_algo += P->sum_b.load();
+        sum->verify_bytes_exec += P->sum_e.load();
+    }
     if (P->tracing)
         for (size_t i = 0; i < P->trace.size(); ++i)
             std::fprintf(stderr, "[home] piece %zu: records home at %.3f ms, %.0f rows written at %.3f ms (since the call set the pool up)\n", i,
@@ -3556,6 +3588,7 @@ po_status append_home(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t n_r
     if (k + 1 == n_chunks && n_rec >= 65536 && !getenv("PHASM_HOME_NO_SPLIT")) n_parts = 4;
     if (h->home_seq % N_EV + n_parts > N_EV) n_parts = 1;   // (not enough unused flag words left in this round)
     P->paired = (h->bits == 2 && h->paired) ? 1u : 0u;
+    P->bits = (uint32_t)h->bits;
     char* dst0 = static_cast<char*>(h->home_stage.p) + h->home_used;
     for (uint32_t part = 0; part < n_parts; ++part) {
         const uint64_t lo = n_rec * part / n_parts, hi = n_rec * (part + 1) / n_parts;
@@ -4017,6 +4050,11 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
                 // (rare: more containments of later reads than the list holds -- the reads are resident now)
                 overflowed = true;
                 home_wait(h);
+                if (h->home_on) {   // (the abandoned step's records are not part of the result)
+                    home::g_pool->sum_l.store(0);
+                    home::g_pool->sum_b.store(0);
+                    home::g_pool->sum_e.store(0);
+                }
                 if (hipStreamSynchronize(h->copy_stream) != hipSuccess) st = fail(h, PO_ERR_HIP, "copy stream");
                 R.total = 0;
                 sum = po_stats();
@@ -4045,7 +4083,7 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
     if (h->copy_stream && hipStreamSynchronize(h->copy_stream) != hipSuccess && st == PO_OK) st = fail(h, PO_ERR_HIP, "row copy device->host");
     {
         // the helper threads have written every piece's rows before the array is handed out (or released)
-        const int herr = home_end(h);
+        const int herr = home_end(h, &sum);
         if (herr && st == PO_OK)
             st = fail(h, PO_ERR_HIP, herr == 1 ? "internal: the host's row count of a piece differs from the device's"
                                      : herr == 2 ? "internal: a verified-candidate record names a read the handle does not hold"

@@ -2962,10 +2962,10 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail(const uint32_t* __restrict_
 // the call, compacted in candidate order as 16-byte records {a, p, b, type} -- one per strand-mirror pair in paired mode --
 // instead of their rows (24 bytes each, two to four per record).  Host threads expand them into the page-locked row array
 // as the pieces land (expand_records), bit for bit what write_rows writes: PCIe carries a third of the bytes.
-// tile_recs[] = verified candidates per tile (k_tile_rows<true>).  The row total and the byte counters are summed here
-// exactly as k_tail sums them.
-// host_out: [0] rows, [1] verified candidates = records written, [2] sum l, [3] algorithmic bytes, [4] compared bytes,
-// [7] fallback flag.  rows_ctr: a device counter, zero at launch (scalars[3]).
+// tile_recs[] = verified candidates per tile (k_tile_rows<true>).  The row total is summed here; the byte counters of
+// po_stats (sum l, algorithmic bytes, compared bytes) are taken on the host from the same records.
+// host_out: [0] rows, [1] verified candidates = records written, [2..4] zero, [7] fallback flag.
+// rows_ctr: a device counter, zero at launch (scalars[3]).
 // ----------------------------------------------------------------------------------------
 __device__ inline uint32_t row_sums(uint32_t t, uint32_t a, uint32_t p, uint32_t b, uint32_t la, uint32_t lb, uint32_t bits,
                                     uint32_t paired, uint64_t& suml, uint64_t& sumb, uint64_t& sume) {
@@ -2990,13 +2990,13 @@ __device__ inline uint32_t row_sums(uint32_t t, uint32_t a, uint32_t p, uint32_t
 
 __global__ __launch_bounds__(TAIL_BLOCK) void k_tail_cands(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
                                                            const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,
-                                                           uint32_t n_cand, const uint32_t* __restrict__ len, Cand* __restrict__ out,
-                                                           uint32_t bits, uint32_t paired, const uint32_t* __restrict__ gate,
-                                                           const uint32_t* __restrict__ tile_recs, uint32_t n_tiles, uint32_t* __restrict__ done,
-                                                           unsigned long long* __restrict__ counters, unsigned long long* __restrict__ rows_ctr,
+                                                           uint32_t n_cand, Cand* __restrict__ out, uint32_t paired,
+                                                           const uint32_t* __restrict__ gate, const uint32_t* __restrict__ tile_recs,
+                                                           uint32_t n_tiles, uint32_t* __restrict__ done, unsigned long long* __restrict__ rows_ctr,
                                                            uint64_t* __restrict__ host_out, const CandGuard G) {
     __shared__ uint32_t s_cnt[TAIL_ITEMS][TAIL_BLOCK / WAVE];
     __shared__ uint32_t s_pre[TAIL_BLOCK / WAVE];
+    __shared__ uint32_t s_rows[TAIL_BLOCK / WAVE];
     __shared__ uint32_t s_last;
     if ((gate && *gate != 0u) || G.overflow()) {   // (grid-uniform)
         if (blockIdx.x == 0 && threadIdx.x == 0) host_out[7] = G.overflow() ? 2 : 1;
@@ -3040,7 +3040,6 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail_cands(const uint32_t* __res
             pp[r] = cand_p[i];
         }
     }
-    uint64_t nver = 0, suml = 0, sumb = 0, sume = 0;
     uint32_t nrows = 0;
 #pragma unroll
     for (int r = 0; r < TAIL_ITEMS; ++r) {
@@ -3048,13 +3047,14 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail_cands(const uint32_t* __res
         const uint32_t inc = wave_incl_scan(cnt);
         excl[r] = inc - cnt;
         if (lane == WAVE - 1) s_cnt[r][wave] = inc;
-        if (t[r]) {
-            nver += 1;
-            nrows += row_sums(t[r], a[r], pp[r], b[r], len[a[r]], len[b[r]], bits, paired, suml, sumb, sume);
-        }
+        if (t[r]) nrows += rows_of(t[r], a[r], b[r], paired);
     }
     pre = wave_sum(pre);
-    if (lane == 0) s_pre[wave] = pre;
+    nrows = wave_sum(nrows);
+    if (lane == 0) {
+        s_pre[wave] = pre;
+        s_rows[wave] = nrows;
+    }
     __syncthreads();
     uint32_t pfx = 0, block_total = 0;
 #pragma unroll
@@ -3072,40 +3072,22 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail_cands(const uint32_t* __res
 #pragma unroll
     for (int r = 0; r < TAIL_ITEMS; ++r)
         if (t[r]) out[pfx + excl[r]] = Cand{a[r], pp[r], b[r], t[r]};
-    {
-        __shared__ uint64_t s_red[5][TAIL_BLOCK / WAVE];
-        nver = wave_sum64(nver);
-        suml = wave_sum64(suml);
-        sumb = wave_sum64(sumb);
-        sume = wave_sum64(sume);
-        const uint64_t nr = wave_sum64((uint64_t)nrows);
-        if (lane == 0) {
-            s_red[0][wave] = nver;
-            s_red[1][wave] = suml;
-            s_red[2][wave] = sumb;
-            s_red[3][wave] = sume;
-            s_red[4][wave] = nr;
-        }
-        __syncthreads();
-        if (threadIdx.x < 5) {
-            uint64_t v = 0;
-            for (int w = 0; w < TAIL_BLOCK / WAVE; ++w) v += s_red[threadIdx.x][w];
-            unsigned long long old = 0;   // (a RETURNING atomic: performed at the coherence point before the done count below, see k_tail)
-            if (v) old = atomicAdd(threadIdx.x < 4 ? &counters[threadIdx.x] : rows_ctr, (unsigned long long)v);
-            asm volatile("" :: "v"((uint32_t)old));
-        }
-    }
-    __syncthreads();
+    if (tile == n_tiles - 1u && threadIdx.x == 0) host_out[1] = (uint64_t)pfx + block_total;   // (the last tile: all records)
     if (threadIdx.x == 0) {
+        // ONE returning atomic per workgroup for the row total (the byte sums of po_stats are taken on the host while the
+        // records are expanded: five same-address atomics per workgroup were most of this kernel's 30 us per piece),
+        // performed at the coherence point before the done count below (see k_tail)
+        uint32_t rows = 0;
+        for (int w = 0; w < TAIL_BLOCK / WAVE; ++w) rows += s_rows[w];
+        unsigned long long old = 0;
+        if (rows) old = atomicAdd(rows_ctr, (unsigned long long)rows);
+        asm volatile("" :: "v"((uint32_t)old));
         s_last = atomicAdd(done, 1u) == n_tiles - 1u ? 1u : 0u;
         if (s_last) {
             *done = 0;
             host_out[0] = __hip_atomic_load(rows_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *rows_ctr = 0;
-            for (int k = 0; k < 4; ++k) {
-                host_out[1 + k] = __hip_atomic_load(&counters[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                counters[k] = 0;   // (zero again for the next piece)
-            }
+            *rows_ctr = 0;   // (zero again for the next piece)
+            host_out[2] = host_out[3] = host_out[4] = 0;
             host_out[7] = 0;
         }
     }

@@ -76,6 +76,8 @@ def test_classic_and_fused_tails_emit_the_same_array(home, monkeypatch):
     first = ov.overlaps_array(m)
     # (the record tail needs no kept worst-case row buffer: it runs from the first call on; the row tail from the second)
     assert ov.stats()["fused_tail"] == (1 if home == "1" else 0)
+    counters = {k: ov.stats()[k] for k in ("n_rows", "n_verified", "sum_overlap_bases", "verify_bytes_algo", "verify_bytes_exec")}
+    assert counters["n_rows"] == len(want) and counters["sum_overlap_bases"] == int(want[:, 5].sum())   # (bend = l, bstart = 0)
     second = ov.overlaps_array(m)
     assert ov.stats()["fused_tail"] == 1 and ov.stats()["tail_fallback"] == 0
     monkeypatch.setenv("PHASM_TAIL_CLASSIC", "1")
@@ -86,6 +88,8 @@ def test_classic_and_fused_tails_emit_the_same_array(home, monkeypatch):
     monkeypatch.delenv("PHASM_PS_CLASSIC")
     monkeypatch.setenv("PHASM_HOME", "0" if home == "1" else "1")     # ... and the other transfer form on the same handle
     fourth = ov.overlaps_array(m)
+    # the byte counters of po_stats are the same whether the device summed them (rows) or the host did (records)
+    assert {k: ov.stats()[k] for k in counters} == counters
     dev = ov.overlaps_result(m)                                       # the device-resident form (po_overlaps + po_result_rows)
     fifth = dev.rows()
     dev.free()
