@@ -868,7 +868,28 @@ Pool* pool() {
         // (a GPU box gives one GPU's process a share of the host's cores: the pool stays well inside it -- the caller's
         // thread and the HIP runtime's own threads need cores too, and threads beyond the share would stall everyone)
         unsigned n = std::thread::hardware_concurrency();
-        n = std::max(1u, std::min(n ? n / 2 : 4u, 10u));
+        n = n ? n : 4u;
+        {
+            // the container's CPU quota, where there is one (cgroup v2 cpu.max "quota period", v1 cpu.cfs_quota_us / _period_us):
+            // hardware_concurrency() says 256 on a box whose process may use 16
+            long long q = -1, per = 100000;
+            if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+                char buf[64] = {0};
+                if (std::fscanf(f, "%63s %lld", buf, &per) >= 1 && std::strcmp(buf, "max") != 0) q = atoll(buf);
+                std::fclose(f);
+            } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+                if (std::fscanf(g, "%lld", &q) != 1) q = -1;
+                std::fclose(g);
+                if (FILE* g2 = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                    if (std::fscanf(g2, "%lld", &per) != 1) per = 100000;
+                    std::fclose(g2);
+                }
+            }
+            if (q > 0 && per > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, q / per));
+        }
+        // three quarters of what the process may use, 12 at most (measured at config 2 on a 16-CPU share: 4 threads 5.57 ms per
+        // step, 7: 5.09, 10: 4.68, 12: 4.64; 14 leave the caller's thread and the runtime's threads without a CPU: 5.75)
+        n = std::max(1u, std::min(n * 3 / 4, 12u));
         if (const char* e = getenv("PHASM_HOME_THREADS")) n = (unsigned)std::max(1, std::min(64, atoi(e)));
         try {
             P->thr.emplace_back(leader, P);
@@ -2059,6 +2080,9 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     const uint32_t* gate = nullptr;
     const uint64_t worst_rows = (uint64_t)n_cand * (paired ? 4u : 2u);
     std::function<po_status()> classic_tail;
+    // the longest-only selection inside each read's list runs in the verify kernel's epilogue where the exact verify runs
+    // (not the DP kernels, which have no per-read workgroup); PHASM_SELECT_KERNEL=1 keeps the separate launch (tests compare)
+    const bool sel_in_verify = (nshards > 1 || streamed || wide) && !dp && !getenv("PHASM_SELECT_KERNEL");
     if (n_cand) {
         PO_TRY(ensure_piece(h, h->d_cand_a, (size_t)n_cand * 4));
         PO_TRY(ensure_piece(h, h->d_cand_p, (size_t)n_cand * 4));
@@ -2235,7 +2259,8 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                                words, woff, len, h->d_read_tile0.as<uint32_t>(), tile_off_p, A.cand_p,
                                A.cand_b, r_begin, lds_words, paired_ver,
                                h->n_exc_uploaded ? h->d_exc_off.as<uint32_t>() : nullptr, h->d_exc_pos.as<uint32_t>(),
-                               h->d_exc_byte.as<uint8_t>(), h->d_type.as<uint8_t>(), perm, n_a, G);
+                               h->d_exc_byte.as<uint8_t>(), h->d_type.as<uint8_t>(), perm, n_a, G,
+                               sel_in_verify ? selfrep : nullptr, sel_in_verify ? n_deferred : nullptr);
             if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_VER1], st));
             ver_timed = true;
         }
@@ -2255,7 +2280,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
 #endif
         if (h->phase_events) HIP_TRY(h, hipEventRecord(h->ev[EV_VERIFY], st));
         // ---- select + row offsets
-        if (nshards > 1 || streamed || wide || dpE) {
+        if ((nshards > 1 || streamed || wide || dpE) && !sel_in_verify) {
             static_assert(po::SEL_CAP == 512, "k_select_local hashes to 9 bits");
             hipLaunchKernelGGL(po::k_select_local, dim3(cdiv(r_end - r_begin, 256 / po::WAVE)), dim3(256), 0, st,
                                h->d_read_tile0.as<uint32_t>(), tile_off_p, A.cand_p, A.cand_b, h->d_type.as<uint8_t>(),
@@ -3582,10 +3607,13 @@ po_status append_home(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t n_r
             PO_TRY(ensure_host(h, h->home_stage, std::max<size_t>({bytes * 2, (size_t)(h->home_last_bytes + h->home_last_bytes / 8), (size_t)8 << 20})));
     }
     // behind a copy, on the same stream: a one-thread kernel writes a number into a page-locked word of the handle's landing
-    // zone (slots 96 ..) -- what the pool's first thread polls.  The LAST piece of a call travels in up to four parts, so
-    // that its first rows are being written while its last records are still on the wire.
+    // zone (slots 96 ..) -- what the pool's first thread polls.  The LAST piece of a call can travel in parts, so that its
+    // first rows are being written while its last records are still on the wire.
     uint32_t n_parts = 1;
-    if (k + 1 == n_chunks && n_rec >= 65536 && !getenv("PHASM_HOME_NO_SPLIT")) n_parts = 4;
+    // (measured, round 4: interleaved A/B at config 2, 4.68 ms with the split against 4.64 without -- the three extra copies
+    // and their words cost what the overlap gains; PHASM_HOME_SPLIT=n asks for n parts)
+    if (const char* e = getenv("PHASM_HOME_SPLIT"))
+        if (k + 1 == n_chunks && n_rec >= 65536) n_parts = (uint32_t)std::max(1, std::min(8, atoi(e)));
     if (h->home_seq % N_EV + n_parts > N_EV) n_parts = 1;   // (not enough unused flag words left in this round)
     P->paired = (h->bits == 2 && h->paired) ? 1u : 0u;
     P->bits = (uint32_t)h->bits;
@@ -3734,29 +3762,52 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
     const uint32_t n = (uint32_t)h->len.size();
     const uint32_t P = (uint32_t)bounds.size() - 1;
     bool generate = false;
-    PO_TRY(upload_meta(h, &generate));
-    if (!generate) return fail(h, PO_ERR_INVALID, "streamed step on reads that are not (x, reverse complement of x) pairs");
     if (!h->up_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
     for (uint32_t k = 0; k < P; ++k)
         if (!h->ev_piece[k]) HIP_TRY(h, hipEventCreate(&h->ev_piece[k]));
+    uint64_t piece0_bytes = 0;
+    auto queue_piece = [&](uint32_t k) -> po_status {
+        uint64_t* dw = h->d_words.as<uint64_t>();
+        const uint64_t wb = bounds[k] < n ? h->woff[bounds[k]] : h->words[0].size();
+        const uint64_t we = bounds[k + 1] < n ? h->woff[bounds[k + 1]] : h->words[0].size();
+        if (we > wb) {
+            HIP_TRY(h, hipMemcpyAsync(dw + wb, h->words[0].data() + wb, (we - wb) * 8, hipMemcpyHostToDevice, h->up_stream));
+            h->upload_bytes += (we - wb) * 8;
+            if (k == 0) piece0_bytes = (we - wb) * 8;
+        }
+        HIP_TRY(h, hipEventRecord(h->ev_piece[k], h->up_stream));
+        return PO_OK;
+    };
+    // The first piece goes on the wire BEFORE anything else of the step is prepared (per-read tables, tiles, first words:
+    // ~0.1 ms of host time and small commands) whenever the device buffer it lands in exists already -- every call but the
+    // first on a handle: the whole pipeline behind it starts that much earlier.
+    bool early0 = false;
+    {
+        const uint64_t base1 = (h->words[0].size() + 1) & ~uint64_t(1);
+        const uint64_t nwords = base1 + h->words[1].size() + 72;
+        if (h->poison < 0 && h->d_words.p && h->d_words.cap >= nwords * 8 && h->bits == 2 && h->all_pairs_rcx && !getenv("PHASM_FULL_UPLOAD")) {
+            HIP_TRY(h, hipEventRecord(h->ev_up0, h->up_stream));
+            PO_TRY(queue_piece(0));
+            early0 = true;
+        }
+    }
+    PO_TRY(upload_meta(h, &generate));   // (sets upload_bytes to what the tables weigh)
+    if (!generate) {
+        if (early0) (void)hipStreamSynchronize(h->up_stream);
+        return fail(h, PO_ERR_INVALID, "streamed step on reads that are not (x, reverse complement of x) pairs");
+    }
     uint64_t* dw = h->d_words.as<uint64_t>();
     if (h->poison >= 0) {
         // (PHASM_POISON fills a fresh device buffer on the handle's stream: the pieces must not land under that fill)
         HIP_TRY(h, hipEventRecord(h->ev_up1, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(h->up_stream, h->ev_up1, 0));
     }
-    HIP_TRY(h, hipEventRecord(h->ev_up0, h->up_stream));
-    auto queue_piece = [&](uint32_t k) -> po_status {
-        const uint64_t wb = bounds[k] < n ? h->woff[bounds[k]] : h->words[0].size();
-        const uint64_t we = bounds[k + 1] < n ? h->woff[bounds[k + 1]] : h->words[0].size();
-        if (we > wb) {
-            HIP_TRY(h, hipMemcpyAsync(dw + wb, h->words[0].data() + wb, (we - wb) * 8, hipMemcpyHostToDevice, h->up_stream));
-            h->upload_bytes += (we - wb) * 8;
-        }
-        HIP_TRY(h, hipEventRecord(h->ev_piece[k], h->up_stream));
-        return PO_OK;
-    };
-    PO_TRY(queue_piece(0));
+    if (early0) {
+        h->upload_bytes += piece0_bytes;
+    } else {
+        HIP_TRY(h, hipEventRecord(h->ev_up0, h->up_stream));
+        PO_TRY(queue_piece(0));
+    }
     if (P > 1) {
         // first words of the reads of the later pieces (both strands: the host packed the odd store too, it just does
         // not travel), put in place on the handle's stream while piece 0 is crossing; the later pieces' copies are

@@ -1646,6 +1646,13 @@ __device__ unsigned long long g_vstamps[64 * 8];
 // a two-deep prefetch of four dependent global loads (the start/finish code is half of this kernel's
 // instructions, and the kernel is issue bound).
 constexpr int VREC_CAP = 512;  // records per staging batch (8 KB of LDS)
+// (longest-only selection inside a read's candidate list, defined with k_select_local below: k_verify_a can run it in its
+// epilogue -- the workgroup that verified a read's candidates owns the list)
+constexpr uint32_t SEL_CAP = 512;  // LDS table entries per wave (load <= 1/2)
+__device__ __forceinline__ void select_read_list(uint32_t seg0, uint32_t seg1, const uint32_t* __restrict__ cand_p,
+                                                 const uint32_t* __restrict__ cand_b, uint8_t* __restrict__ type,
+                                                 uint32_t* __restrict__ selfrep, uint32_t* __restrict__ n_deferred,
+                                                 uint32_t* key, uint32_t* mn, uint32_t lane);
 struct __attribute__((aligned(16))) VRec {
     uint32_t pk;  // p | (keep & 1) << 31        p, n < 2^31: the top bits carry `keep` (which rows the candidate can
     uint32_t b;   //                             give, keep_bits) -- worked out once by the staging thread instead of by
@@ -1866,7 +1873,8 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
                                                          const uint32_t* __restrict__ exc_pos,
                                                          const uint8_t* __restrict__ exc_byte,
                                                          uint8_t* __restrict__ type,
-                                                         const uint32_t* __restrict__ perm, uint32_t n_a, const CandGuard G) {
+                                                         const uint32_t* __restrict__ perm, uint32_t n_a, const CandGuard G,
+                                                         uint32_t* __restrict__ sel_selfrep, uint32_t* __restrict__ sel_deferred) {
     constexpr int W = 64 / BITS;
     extern __shared__ __attribute__((aligned(16))) uint64_t s_a64[];
     if (G.overflow()) return;
@@ -1942,6 +1950,17 @@ __global__ __launch_bounds__(VER_BLOCK) void k_verify_a(const uint64_t* __restri
             verify_run<BITS, SCRAMBLED, false, false, STREAM>(words, woff, len, cand_p, cand_b, paired, exc_off, exc_pos, exc_byte, type,
                                                       s_a, ga32, s_rec, s_next, a, la, seg0, seg1 VST(, vt_start, vt));
     }
+    // sel_deferred != nullptr: the longest-only selection inside this read's list (k_select_local's work) right here -- the
+    // workgroup has just written every type of the list; one launch less per piece of a streamed step.  The records' LDS is
+    // free now: 2 x SEL_CAP words of it hold the wave's table.
+    if (sel_deferred) {
+        static_assert((size_t)VREC_CAP * sizeof(VRec) >= 2 * SEL_CAP * sizeof(uint32_t), "the record area holds the selection table");
+        __syncthreads();   // (every group is done: all types of [seg0, seg1) are written and visible to the workgroup)
+        if (threadIdx.x < WAVE) {
+            uint32_t* key = reinterpret_cast<uint32_t*>(s_rec);
+            select_read_list(seg0, seg1, cand_p, cand_b, type, sel_selfrep, sel_deferred, key, key + SEL_CAP, threadIdx.x);
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1976,20 +1995,11 @@ __device__ inline uint32_t pair_slot(uint32_t a, uint32_t b, uint32_t tbits) {
 // another position -- (a, p, b) is found once, so the position names the candidate.  No global table, no
 // device-scope atomics (9.3 M of them cost 1.3 ms at config 3).  A read with more verified A candidates than the
 // table takes (tandem repeats) marks its b's as suspects instead and leaves them to the global table below.
-constexpr uint32_t SEL_CAP = 512;  // LDS table entries per wave (load <= 1/2)
-__global__ __launch_bounds__(256) void k_select_local(const uint32_t* __restrict__ read_tile0, const uint32_t* __restrict__ tile_off,
-                                                      const uint32_t* __restrict__ cand_p,
-                                                      const uint32_t* __restrict__ cand_b, uint8_t* __restrict__ type,
-                                                      uint32_t r_begin, uint32_t n_reads, uint32_t* __restrict__ selfrep,
-                                                      uint32_t* __restrict__ n_deferred, const CandGuard G) {
-    __shared__ uint32_t s_key[256 / WAVE][SEL_CAP];  // b + 1, 0 = empty
-    if (G.overflow()) return;
-    __shared__ uint32_t s_min[256 / WAVE][SEL_CAP];
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    const uint32_t i = blockIdx.x * (256 / WAVE) + wave;
-    if (i >= n_reads) return;  // whole wave
-    const uint32_t a = r_begin + i;
-    const uint32_t seg0 = tile_off[read_tile0[a]], seg1 = tile_off[read_tile0[a + 1]];
+// one wave, one read's candidate list [seg0, seg1): key / mn = SEL_CAP words of LDS each
+__device__ __forceinline__ void select_read_list(uint32_t seg0, uint32_t seg1, const uint32_t* __restrict__ cand_p,
+                                                 const uint32_t* __restrict__ cand_b, uint8_t* __restrict__ type,
+                                                 uint32_t* __restrict__ selfrep, uint32_t* __restrict__ n_deferred,
+                                                 uint32_t* key, uint32_t* mn, uint32_t lane) {
     if (seg1 - seg0 < 2) return;
     uint32_t n_a = 0;
     for (uint32_t c0 = seg0; c0 < seg1; c0 += WAVE) {
@@ -2003,8 +2013,6 @@ __global__ __launch_bounds__(256) void k_select_local(const uint32_t* __restrict
         if (lane == 0) atomicAdd(n_deferred, 1u);   // (the global table is only filled and looked at when this is non-zero)
         return;
     }
-    uint32_t* key = s_key[wave];
-    uint32_t* mn = s_min[wave];
     for (uint32_t k = lane; k < SEL_CAP; k += WAVE) {
         key[k] = 0;
         mn[k] = ~0u;
@@ -2030,6 +2038,21 @@ __global__ __launch_bounds__(256) void k_select_local(const uint32_t* __restrict
         while (key[s] != b + 1u) s = (s + 1u) & (SEL_CAP - 1u);
         if (mn[s] != cand_p[c]) type[c] = (uint8_t)(t & ~1u);  // a longer overlap of the same pair exists
     }
+}
+
+__global__ __launch_bounds__(256) void k_select_local(const uint32_t* __restrict__ read_tile0, const uint32_t* __restrict__ tile_off,
+                                                      const uint32_t* __restrict__ cand_p,
+                                                      const uint32_t* __restrict__ cand_b, uint8_t* __restrict__ type,
+                                                      uint32_t r_begin, uint32_t n_reads, uint32_t* __restrict__ selfrep,
+                                                      uint32_t* __restrict__ n_deferred, const CandGuard G) {
+    __shared__ uint32_t s_key[256 / WAVE][SEL_CAP];  // b + 1, 0 = empty
+    if (G.overflow()) return;
+    __shared__ uint32_t s_min[256 / WAVE][SEL_CAP];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * (256 / WAVE) + wave;
+    if (i >= n_reads) return;  // whole wave
+    const uint32_t a = r_begin + i;
+    select_read_list(tile_off[read_tile0[a]], tile_off[read_tile0[a + 1]], cand_p, cand_b, type, selfrep, n_deferred, s_key[wave], s_min[wave], lane);
 }
 
 __global__ __launch_bounds__(256) void k_count_suspects(const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,
