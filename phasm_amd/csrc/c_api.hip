@@ -3778,11 +3778,11 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
         HIP_TRY(h, hipEventRecord(h->ev_piece[k], h->up_stream));
         return PO_OK;
     };
-    // The first piece goes on the wire BEFORE anything else of the step is prepared (per-read tables, tiles, first words:
-    // ~0.1 ms of host time and small commands) whenever the device buffer it lands in exists already -- every call but the
-    // first on a handle: the whole pipeline behind it starts that much earlier.
+    // (Measured and not kept, round 4: the first piece on the wire BEFORE the step's preparation.  The per-read tables and the
+    // first words are host->device copies too and queue behind the piece's 20 MB on the same engine, so the index -- built
+    // from them while piece 0 is on the wire -- is late by what the piece takes to land.  PHASM_EARLY_PIECE0=1 brings it back.)
     bool early0 = false;
-    {
+    if (getenv("PHASM_EARLY_PIECE0")) {
         const uint64_t base1 = (h->words[0].size() + 1) & ~uint64_t(1);
         const uint64_t nwords = base1 + h->words[1].size() + 72;
         if (h->poison < 0 && h->d_words.p && h->d_words.cap >= nwords * 8 && h->bits == 2 && h->all_pairs_rcx && !getenv("PHASM_FULL_UPLOAD")) {

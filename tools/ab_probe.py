@@ -23,8 +23,14 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--with-torch", action="store_true", help="import torch and initialise its CUDA context first (what bench.py's process looks like)")
     args = ap.parse_args()
     cfg = synth.CONFIGS[args.config]
+    if args.with_torch:
+        import torch
+        torch.cuda.set_device(0)
+        torch.cuda.synchronize()
+        print("torch threads", torch.get_num_threads(), flush=True)
     ov = ExactOverlapper(device=0)
     for name, seq in synth.oriented(synth.generate_reads(cfg)):
         ov.add_sequence(name, seq)
