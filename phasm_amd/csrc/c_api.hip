@@ -3618,13 +3618,23 @@ po_status append_home(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t n_r
     P->paired = (h->bits == 2 && h->paired) ? 1u : 0u;
     P->bits = (uint32_t)h->bits;
     char* dst0 = static_cast<char*>(h->home_stage.p) + h->home_used;
+    const char* copy_env = getenv("PHASM_HOME_COPY_WGS");
+    const int copy_wgs = copy_env ? std::max(0, std::min(4096, atoi(copy_env))) : 0;
     for (uint32_t part = 0; part < n_parts; ++part) {
         const uint64_t lo = n_rec * part / n_parts, hi = n_rec * (part + 1) / n_parts;
         const uint32_t slot = (uint32_t)(h->home_seq % N_EV);
         const uint32_t want = ++h->home_gen;
         char* dst = dst0 + lo * sizeof(po::Cand);
-        HIP_TRY(h, hipMemcpyAsync(dst, static_cast<const char*>(dev.p) + lo * sizeof(po::Cand), (hi - lo) * sizeof(po::Cand),
-                                  hipMemcpyDeviceToHost, h->copy_stream));
+        if (copy_wgs > 0) {
+            hipLaunchKernelGGL(po::k_copy_out, dim3((uint32_t)copy_wgs), dim3(256), 0, h->copy_stream, reinterpret_cast<po::copy_v4*>(dst),
+                               reinterpret_cast<const po::copy_v4*>(static_cast<const char*>(dev.p) + lo * sizeof(po::Cand)), (uint64_t)(hi - lo));
+            HIP_TRY(h, hipGetLastError());
+        } else {
+            size_t nb = (hi - lo) * sizeof(po::Cand);
+            if (const char* e = getenv("PHASM_HOME_HACK_SHRINK")) nb = std::max<size_t>(16, nb * (size_t)atoi(e) / 100);   // TIMING EXPERIMENT ONLY
+            HIP_TRY(h, hipMemcpyAsync(dst, static_cast<const char*>(dev.p) + lo * sizeof(po::Cand), nb,
+                                      hipMemcpyDeviceToHost, h->copy_stream));
+        }
         hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->copy_stream, reinterpret_cast<uint32_t*>(h->pinned_dev + 96 + slot), (uint64_t)1, want);
         HIP_TRY(h, hipGetLastError());
         home::Job j;
@@ -3771,7 +3781,17 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
         const uint64_t wb = bounds[k] < n ? h->woff[bounds[k]] : h->words[0].size();
         const uint64_t we = bounds[k + 1] < n ? h->woff[bounds[k + 1]] : h->words[0].size();
         if (we > wb) {
-            HIP_TRY(h, hipMemcpyAsync(dw + wb, h->words[0].data() + wb, (we - wb) * 8, hipMemcpyHostToDevice, h->up_stream));
+            const char* up_env = getenv("PHASM_UP_COPY_WGS");
+            const int up_wgs = up_env ? std::max(0, std::min(4096, atoi(up_env))) : 0;
+            void* dsrc = nullptr;
+            if (up_wgs > 0 && hipHostGetDevicePointer(&dsrc, const_cast<uint64_t*>(h->words[0].data() + wb), 0) == hipSuccess && dsrc &&
+                ((reinterpret_cast<uintptr_t>(dsrc) ^ reinterpret_cast<uintptr_t>(dw + wb)) & 15u) == 0) {
+                hipLaunchKernelGGL(po::k_copy_in, dim3((uint32_t)up_wgs), dim3(256), 0, h->up_stream, dw + wb, static_cast<const uint64_t*>(dsrc), we - wb);
+                HIP_TRY(h, hipGetLastError());
+            } else {
+                (void)hipGetLastError();   // (a store that is not registered has no device address: not an error of this call)
+                HIP_TRY(h, hipMemcpyAsync(dw + wb, h->words[0].data() + wb, (we - wb) * 8, hipMemcpyHostToDevice, h->up_stream));
+            }
             h->upload_bytes += (we - wb) * 8;
             if (k == 0) piece0_bytes = (we - wb) * 8;
         }
