@@ -352,6 +352,10 @@ po_status po_get_layout_stats(const po_handle* h, po_layout_stats* out);
  * the faulting thread to `fd`, then runs whatever handler was installed before it (a store into a read-only input mapping
  * by a thread that has no Python frames -- a runtime thread -- is named this way).  Returns 0 on success. */
 uint64_t po_debug_host_ranges(uint64_t* out, uint64_t cap_entries);
+/* po_debug_store_words: the packed host store `store` (0: reads of even index, 1: odd) as it stands -- *words points into the
+ * handle (valid until the next call that adds reads), returns the number of 8-byte words.  Tests compare the stores the
+ * parallel FASTA ingest writes with the ones po_add_sequence builds. */
+uint64_t po_debug_store_words(const po_handle* h, int store, const uint64_t** words);
 /* The host half of po_overlaps_to_host's compact row transfer on its own, for tests without a GPU: the rows of `n`
  * verified-candidate records (po_cand; one per strand-mirror pair when paired != 0), written by the library's helper
  * threads in the order po_overlaps emits them -- A row, [its mirror], B row, [its mirror] per record (row fields:

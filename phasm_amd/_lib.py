@@ -126,6 +126,7 @@ SYMBOLS = [
     ("po_get_stats", ctypes.c_int, [_P, ctypes.POINTER(PoStats)]),
     ("po_last_error", ctypes.c_char_p, [_P]),
     ("po_debug_fault_backtrace", ctypes.c_int, [ctypes.c_int]),
+    ("po_debug_store_words", ctypes.c_uint64, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     ("po_debug_expand_records", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                                ctypes.c_void_p, ctypes.c_uint64]),
     ("po_debug_host_ranges", ctypes.c_uint64, [ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64]),

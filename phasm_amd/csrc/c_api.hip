@@ -128,6 +128,7 @@ struct RegHeader {
     int registered;
 };
 constexpr size_t REG_PAGE = 4096;
+thread_local bool g_reg_defer = false;   // (see RegAlloc::reg_now)
 template <class T>
 struct RegAlloc {
     using value_type = T;
@@ -141,15 +142,27 @@ struct RegAlloc {
         hd->bytes = bytes;
         hd->registered = 0;
         char* data = static_cast<char*>(base) + REG_PAGE;
-        if (bytes >= (1u << 20) && !getenv("PHASM_NO_PIN")) {
-            if (hipHostRegister(data, bytes, hipHostRegisterPortable) == hipSuccess) {
-                hd->registered = 1;
-                pin_note(data, bytes, 2u);
-            } else {
-                (void)hipGetLastError();
-            }
-        }
+        if (getenv("PHASM_POISON_HOST")) std::memset(data, 0xA5, bytes);   // (tests: a word nobody wrote shows)
+        if (!g_reg_defer) reg_now(data);
         return reinterpret_cast<T*>(data);
+    }
+    // page-lock the block behind `data` (allocate() does it at once, unless the caller has asked to do it later: po_add_fasta
+    // registers the stores on a thread of its own WHILE the packing threads fill them -- the call blocks until the runtime is
+    // up and pins 4 KB pages one by one, 40-60 ms per 190 MB store, which used to sit in front of the packing)
+    static void reg_now(void* data) {
+        RegHeader* hd = reinterpret_cast<RegHeader*>(static_cast<char*>(data) - REG_PAGE);
+        if (hd->registered || hd->bytes < (1u << 20) || getenv("PHASM_NO_PIN")) return;
+        if (hipHostRegister(data, hd->bytes, hipHostRegisterPortable) == hipSuccess) {
+            hd->registered = 1;
+            pin_note(data, hd->bytes, 2u);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    // vector::resize(n) (no value) leaves the new words as they are: the caller writes every one of them
+    template <class U> void construct(U*) noexcept {}
+    template <class U, class A0, class... Args> void construct(U* q, A0&& a0, Args&&... args) {
+        ::new (static_cast<void*>(q)) U(std::forward<A0>(a0), std::forward<Args>(args)...);
     }
     void deallocate(T* p, size_t) {
         char* base = reinterpret_cast<char*>(p) - REG_PAGE;
@@ -647,6 +660,32 @@ bool kit_give(po_handle* h) {
 // calls and spin while a call is active -- a call lasts milliseconds).  Thread 0 takes the pieces in order: it waits for the
 // event behind the piece's device->host copy, then all threads count the rows of the piece's chunks (8192 records each),
 // thread 0 turns the counts into offsets -- and checks the total against what the device counted --, and all threads write.
+// CPUs this process may use: the hardware's count, cut to the container's CPU quota where there is one (cgroup v2 cpu.max
+// "quota period", v1 cpu.cfs_quota_us / _period_us) -- hardware_concurrency() says 256 on a box whose process may use 16, and
+// threads beyond the share only get the whole process throttled
+unsigned cpu_share() {
+    static const unsigned share = [] {
+        unsigned n = std::thread::hardware_concurrency();
+        n = n ? n : 4u;
+        long long q = -1, per = 100000;
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char buf[64] = {0};
+            if (std::fscanf(f, "%63s %lld", buf, &per) >= 1 && std::strcmp(buf, "max") != 0) q = atoll(buf);
+            std::fclose(f);
+        } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (std::fscanf(g, "%lld", &q) != 1) q = -1;
+            std::fclose(g);
+            if (FILE* g2 = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(g2, "%lld", &per) != 1) per = 100000;
+                std::fclose(g2);
+            }
+        }
+        if (q > 0 && per > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, q / per));
+        return n;
+    }();
+    return share;
+}
+
 namespace home {
 
 constexpr uint32_t CHUNK = 4096;
@@ -867,26 +906,7 @@ Pool* pool() {
         Pool* P = new Pool();
         // (a GPU box gives one GPU's process a share of the host's cores: the pool stays well inside it -- the caller's
         // thread and the HIP runtime's own threads need cores too, and threads beyond the share would stall everyone)
-        unsigned n = std::thread::hardware_concurrency();
-        n = n ? n : 4u;
-        {
-            // the container's CPU quota, where there is one (cgroup v2 cpu.max "quota period", v1 cpu.cfs_quota_us / _period_us):
-            // hardware_concurrency() says 256 on a box whose process may use 16
-            long long q = -1, per = 100000;
-            if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
-                char buf[64] = {0};
-                if (std::fscanf(f, "%63s %lld", buf, &per) >= 1 && std::strcmp(buf, "max") != 0) q = atoll(buf);
-                std::fclose(f);
-            } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
-                if (std::fscanf(g, "%lld", &q) != 1) q = -1;
-                std::fclose(g);
-                if (FILE* g2 = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-                    if (std::fscanf(g2, "%lld", &per) != 1) per = 100000;
-                    std::fclose(g2);
-                }
-            }
-            if (q > 0 && per > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, q / per));
-        }
+        unsigned n = cpu_share();
         // three quarters of what the process may use, 12 at most (measured at config 2 on a 16-CPU share: 4 threads 5.57 ms per
         // step, 7: 5.09, 10: 4.68, 12: 4.64; 14 leave the caller's thread and the runtime's threads without a CPU: 5.75)
         n = std::max(1u, std::min(n * 3 / 4, 12u));
@@ -946,8 +966,13 @@ po_status init_device(po_handle* h) {
         return PO_OK;
     }
     AllocTrace tr("init_device", 0);
+    const auto ti0 = std::chrono::steady_clock::now();
+    auto imark = [&](const char* what) {
+        if (tr.on) std::fprintf(stderr, "[init] %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count());
+    };
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
+    imark("runtime up (hipGetDeviceCount)");
     if (e != hipSuccess || n == 0)
         return fail(h, PO_ERR_HIP, "no HIP device available (libphasm_overlap has no CPU fallback)");
     if (h->device < 0 || h->device >= n) return fail(h, PO_ERR_INVALID, "device ordinal out of range");
@@ -965,19 +990,25 @@ po_status init_device(po_handle* h) {
         h->dev_ready = true;
         return PO_OK;
     }
+    imark("device selected, properties read");
     HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    imark("first stream made");
     for (int i = 0; i < 2 * EV_N; ++i) HIP_TRY(h, hipEventCreate(&h->ev_sets[i / EV_N][i % EV_N]));
     HIP_TRY(h, hipEventCreate(&h->ev_up0));
     HIP_TRY(h, hipEventCreate(&h->ev_up1));
+    imark("first events made");
     HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->pinned), 1024, hipHostMallocDefault));   // 128 slots
     pin_note(h->pinned, 1024, 1u);
     HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pinned_dev), h->pinned, 0));
+    imark("landing zone made");
     if (const char* e = getenv("PHASM_POISON")) h->poison = (int)(strtol(e, nullptr, 0) & 0xFF);
     // the streams and events of the host-to-host call: created here (a few tenths of a millisecond each), not in its first call
     HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    imark("copy stream made");
     HIP_TRY(h, hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
     HIP_TRY(h, hipStreamCreateWithFlags(&h->rc_stream, hipStreamNonBlocking));
     HIP_TRY(h, hipStreamCreateWithFlags(&h->scan_stream, hipStreamNonBlocking));
+    imark("other streams made");
     HIP_TRY(h, hipEventCreateWithFlags(&h->ev_s1[0], hipEventDisableTiming));
     HIP_TRY(h, hipEventCreateWithFlags(&h->ev_s1[1], hipEventDisableTiming));
     HIP_TRY(h, hipEventCreateWithFlags(&h->ev_idx, hipEventDisableTiming));
@@ -987,9 +1018,11 @@ po_status init_device(po_handle* h) {
     }
     HIP_TRY(h, hipEventCreateWithFlags(&h->ev_first, hipEventDisableTiming));
     HIP_TRY(h, hipEventCreateWithFlags(&h->ev_meta, hipEventDisableTiming));
+    imark("streams and events made");
     // the library's code object is loaded by the first launch out of it (15 ms in a fresh process): here, not in a call
     hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->stream, reinterpret_cast<uint32_t*>(h->pinned_dev + 63), (uint64_t)1, 0u);
     (void)hipGetLastError();
+    imark("first launch queued (code object loaded)");
     // ... and so are the hardware queues behind the three other streams and the runtime's copy paths: a stream's queue is made
     // by the first command it gets, the host->device / device->host machinery by the first copy in each direction -- 15 ms
     // of the first call of a process (`8 pieces queued at 15.056 ms`, tools/cold_probe.py) when left to the call.  One
@@ -1016,6 +1049,7 @@ po_status init_device(po_handle* h) {
             (void)hipFree(w);
         }
         (void)hipGetLastError();
+        imark("queues and copy paths warmed");
         // every kernel of a 2-bit call is looked up in the code object now (the runtime resolves a kernel at its first launch:
         // ~35 of them at 0.1-0.3 ms each inside the first call otherwise)
         static const void* const warm_kernels[] = {
@@ -1042,6 +1076,7 @@ po_status init_device(po_handle* h) {
             (void)hipFuncGetAttributes(&fa, k);
         }
         (void)hipGetLastError();
+        imark("kernels looked up");
     }
     h->dev_ready = true;
     return PO_OK;
@@ -2895,8 +2930,9 @@ bool add_fasta_parallel(po_handle* h, const char* data, size_t size, uint64_t* n
     {   // pass A: records, in file order.  The file is cut into ranges; a range's thread takes the records whose header
         // line STARTS inside the range and follows its last record to the next header (or the end of the file) -- one
         // thread over the 715 MB of config 2 was 0.15 s of the command's 0.19 s of ingest
-        unsigned hw = std::thread::hardware_concurrency();
-        unsigned n_rng = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(hw ? hw : 4u, 16u), size >> 22));
+        // (threads: the process's CPU share less the two that bring the device up and register the stores beside this)
+        const unsigned hw = std::max(1u, cpu_share() > 3 ? cpu_share() - 2 : cpu_share());
+        unsigned n_rng = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(hw, 16u), size >> 22));
         if (const char* e = getenv("PHASM_FASTA_RANGES")) n_rng = (unsigned)std::max(1, std::min(64, atoi(e)));   // (tests: many ranges on small files)
         if ((size_t)n_rng > size) n_rng = 1;
         std::vector<std::vector<FastaRec>> part(n_rng);
@@ -2944,6 +2980,7 @@ bool add_fasta_parallel(po_handle* h, const char* data, size_t size, uint64_t* n
         recs.reserve(total);
         for (auto& v : part) recs.insert(recs.end(), v.begin(), v.end());
     }
+    if (getenv("PHASM_FASTA_TRACE")) std::fprintf(stderr, "[fasta] %zu records found\n", recs.size());
     if (recs.empty()) {
         if (n_records) *n_records = 0;
         return true;
@@ -2965,9 +3002,44 @@ bool add_fasta_parallel(po_handle* h, const char* data, size_t size, uint64_t* n
             cur[k] = o + nw + 1;
         }
     }
-    h->words[0].resize(cur[0], 0);
-    h->words[1].resize(cur[1], 0);
+    const bool ftrace = getenv("PHASM_FASTA_TRACE") != nullptr;
+    const auto ft0 = std::chrono::steady_clock::now();
+    auto fmark = [&](const char* what) {
+        if (ftrace) std::fprintf(stderr, "[fasta] %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ft0).count());
+    };
+    // the stores grow WITHOUT being zero-filled and without being page-locked here: the packing threads below write every
+    // word (first touch in parallel), and the registration runs beside them on a thread of its own (RegAlloc::reg_now)
+    g_reg_defer = true;
+    try {
+        h->words[0].resize(cur[0]);
+        h->words[1].resize(cur[1]);
+    } catch (...) {
+        g_reg_defer = false;
+        throw;
+    }
+    g_reg_defer = false;
+    fmark("stores sized");
     uint64_t* words[2] = {h->words[0].data(), h->words[1].data()};
+    std::thread reg_thread;
+    try {
+        uint64_t* blocks[2] = {h->words[0].capacity() ? words[0] : nullptr, h->words[1].capacity() ? words[1] : nullptr};
+        reg_thread = std::thread([blocks, &fmark] {
+            for (int k = 0; k < 2; ++k)
+                if (blocks[k]) RegAlloc<uint64_t>::reg_now(blocks[k]);
+            fmark("stores registered");
+        });
+    } catch (const std::system_error&) {
+    }
+    struct RegJoin {
+        std::thread& t;
+        po_handle* h;
+        ~RegJoin() {
+            if (t.joinable()) t.join();
+            else   // (no thread: register here)
+                for (int k = 0; k < 2; ++k)
+                    if (h->words[k].capacity()) RegAlloc<uint64_t>::reg_now(h->words[k].data());
+        }
+    } reg_join{reg_thread, h};
     const uint8_t* lut = g_lut.v;
     const unsigned char* comp = comp_table();
     std::atomic<size_t> next{0};
@@ -3023,6 +3095,13 @@ bool add_fasta_parallel(po_handle* h, const char* data, size_t size, uint64_t* n
                 }
                 rc.resize(n);
                 for (size_t k = 0; k < n; ++k) rc[k] = (char)comp[(unsigned char)seq[n - 1 - k]];
+                // (the words between the reads: the alignment gap in front, if there is one, and the spare word behind)
+                const size_t nw = (n + 31) / 32;
+                for (int k = 0; k < 2; ++k) {
+                    const size_t prev_end = i ? off[2 * (i - 1) + k] + (recs[i - 1].seq_len + 31) / 32 + 1 : old_words[k];
+                    if (off[2 * i + k] > prev_end) words[k][off[2 * i + k] - 1] = 0;
+                    words[k][off[2 * i + k] + nw] = 0;
+                }
                 uint8_t b = pack(reinterpret_cast<const unsigned char*>(seq.data()), n, words[0] + off[2 * i]);
                 b |= pack(reinterpret_cast<const unsigned char*>(rc.data()), n, words[1] + off[2 * i + 1]);
                 if (n != r.seq_len || (b & 0x80)) {
@@ -3036,8 +3115,8 @@ bool add_fasta_parallel(po_handle* h, const char* data, size_t size, uint64_t* n
       }
     };
     {
-        unsigned hw = std::thread::hardware_concurrency();
-        const unsigned n_thr = std::max(1u, std::min(hw ? hw : 4u, 16u));
+        const unsigned hw = std::max(1u, cpu_share() > 3 ? cpu_share() - 2 : cpu_share());
+        const unsigned n_thr = std::max(1u, std::min(hw, 16u));
         std::vector<std::thread> thr;
         try {
             for (unsigned t = 1; t < n_thr; ++t) thr.emplace_back(worker);
@@ -3047,6 +3126,7 @@ bool add_fasta_parallel(po_handle* h, const char* data, size_t size, uint64_t* n
         worker();
         for (auto& th : thr) th.join();
     }
+    fmark("packed");
     if (bad.load()) {  // something other than upper-case ACGT: let the sequential path deal with it
         h->words[0].resize(old_words[0]);
         h->words[1].resize(old_words[1]);
@@ -3069,6 +3149,7 @@ bool add_fasta_parallel(po_handle* h, const char* data, size_t size, uint64_t* n
     h->dirty = true;
     h->ids_paired = -1;
     if (n_records) *n_records = recs.size();
+    fmark("ids and tables appended");
     return true;
 }
 
@@ -3243,7 +3324,14 @@ po_status po_add_fasta(po_handle* h, const char* path, int both_strands, uint64_
                     }
                 } joiner{warm};
                 try {
+                    const auto tf0 = std::chrono::steady_clock::now();
                     done = add_fasta_parallel(h, static_cast<const char*>(m), (size_t)sb.st_size, n_records);
+                    if (getenv("PHASM_FASTA_TRACE")) {
+                        const double t_parse = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf0).count();
+                        if (warm.joinable()) warm.join();
+                        std::fprintf(stderr, "[fasta] parsed and packed in %.1f ms; the device and the result pool were ready %.1f ms after the start\n", t_parse,
+                                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf0).count());
+                    }
                 } catch (const std::bad_alloc&) {
                     ::munmap(m, (size_t)sb.st_size);
                     ::close(fd);
@@ -3618,23 +3706,19 @@ po_status append_home(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t n_r
     P->paired = (h->bits == 2 && h->paired) ? 1u : 0u;
     P->bits = (uint32_t)h->bits;
     char* dst0 = static_cast<char*>(h->home_stage.p) + h->home_used;
-    const char* copy_env = getenv("PHASM_HOME_COPY_WGS");
-    const int copy_wgs = copy_env ? std::max(0, std::min(4096, atoi(copy_env))) : 0;
     for (uint32_t part = 0; part < n_parts; ++part) {
         const uint64_t lo = n_rec * part / n_parts, hi = n_rec * (part + 1) / n_parts;
         const uint32_t slot = (uint32_t)(h->home_seq % N_EV);
         const uint32_t want = ++h->home_gen;
         char* dst = dst0 + lo * sizeof(po::Cand);
-        if (copy_wgs > 0) {
-            hipLaunchKernelGGL(po::k_copy_out, dim3((uint32_t)copy_wgs), dim3(256), 0, h->copy_stream, reinterpret_cast<po::copy_v4*>(dst),
-                               reinterpret_cast<const po::copy_v4*>(static_cast<const char*>(dev.p) + lo * sizeof(po::Cand)), (uint64_t)(hi - lo));
-            HIP_TRY(h, hipGetLastError());
-        } else {
-            size_t nb = (hi - lo) * sizeof(po::Cand);
-            if (const char* e = getenv("PHASM_HOME_HACK_SHRINK")) nb = std::max<size_t>(16, nb * (size_t)atoi(e) / 100);   // TIMING EXPERIMENT ONLY
-            HIP_TRY(h, hipMemcpyAsync(dst, static_cast<const char*>(dev.p) + lo * sizeof(po::Cand), nb,
-                                      hipMemcpyDeviceToHost, h->copy_stream));
-        }
+        // (Measured and not kept, round 4 -- profiles/r04_copy_kernels.txt.  The kernel trace shows the counting pass of the
+        // NEXT piece at 200-230 us instead of 90 while this copy is in flight (the runtime copies with a kernel of its own).
+        // A copy kernel of ours writing the page-locked block with 1 .. 256 workgroups: 5.1, 5.0, 5.1, 5.3, 5.4, 5.5 ms per step
+        // against 4.7 -- the fewer waves the better, and the runtime's copy better than all of them; the same for the upload,
+        // 6.8-7.8 ms.  Copying 50 % / 10 % of the bytes (timing only, the host reading the previous step's identical records):
+        // 4.57 / 4.49 ms -- all of the interference is worth 0.2 ms, 8-byte records would buy 0.13.)
+        HIP_TRY(h, hipMemcpyAsync(dst, static_cast<const char*>(dev.p) + lo * sizeof(po::Cand), (hi - lo) * sizeof(po::Cand),
+                                  hipMemcpyDeviceToHost, h->copy_stream));
         hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->copy_stream, reinterpret_cast<uint32_t*>(h->pinned_dev + 96 + slot), (uint64_t)1, want);
         HIP_TRY(h, hipGetLastError());
         home::Job j;
@@ -3781,17 +3865,7 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
         const uint64_t wb = bounds[k] < n ? h->woff[bounds[k]] : h->words[0].size();
         const uint64_t we = bounds[k + 1] < n ? h->woff[bounds[k + 1]] : h->words[0].size();
         if (we > wb) {
-            const char* up_env = getenv("PHASM_UP_COPY_WGS");
-            const int up_wgs = up_env ? std::max(0, std::min(4096, atoi(up_env))) : 0;
-            void* dsrc = nullptr;
-            if (up_wgs > 0 && hipHostGetDevicePointer(&dsrc, const_cast<uint64_t*>(h->words[0].data() + wb), 0) == hipSuccess && dsrc &&
-                ((reinterpret_cast<uintptr_t>(dsrc) ^ reinterpret_cast<uintptr_t>(dw + wb)) & 15u) == 0) {
-                hipLaunchKernelGGL(po::k_copy_in, dim3((uint32_t)up_wgs), dim3(256), 0, h->up_stream, dw + wb, static_cast<const uint64_t*>(dsrc), we - wb);
-                HIP_TRY(h, hipGetLastError());
-            } else {
-                (void)hipGetLastError();   // (a store that is not registered has no device address: not an error of this call)
-                HIP_TRY(h, hipMemcpyAsync(dw + wb, h->words[0].data() + wb, (we - wb) * 8, hipMemcpyHostToDevice, h->up_stream));
-            }
+            HIP_TRY(h, hipMemcpyAsync(dw + wb, h->words[0].data() + wb, (we - wb) * 8, hipMemcpyHostToDevice, h->up_stream));
             h->upload_bytes += (we - wb) * 8;
             if (k == 0) piece0_bytes = (we - wb) * 8;
         }
@@ -4521,8 +4595,8 @@ po_status po_write_gfa_edges(po_result* r, int fd, uint64_t* lines_out) {
         return (long long)(q - buf);
     };
     try {
-        unsigned hw = std::thread::hardware_concurrency();
-        const unsigned n_thr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw ? hw : 4, 16), n_chunks));
+        const unsigned hw = cpu_share();
+        const unsigned n_thr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw, 16), n_chunks));
         // off[c] = file offset of chunk c (-1 until chunk c - 1 has been formatted); off[n_chunks] = the end
         std::unique_ptr<std::atomic<long long>[]> off(new std::atomic<long long>[n_chunks + 1]);
         for (uint64_t c = 0; c <= n_chunks; ++c) off[c].store(-1, std::memory_order_relaxed);
@@ -4770,8 +4844,8 @@ po_status po_add_gfa(po_handle* h, const char* path, uint64_t* n_segments, po_re
             }
         };
         if (st == PO_OK && size) {
-            unsigned hw = std::thread::hardware_concurrency();
-            const unsigned n_parts = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(hw ? hw : 4u, 12u), size >> 22));
+            const unsigned hw = cpu_share();
+            const unsigned n_parts = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(hw, 12u), size >> 22));
             std::vector<size_t> cut(n_parts + 1, size);
             cut[0] = 0;
             for (unsigned k = 1; k < n_parts; ++k) {  // a range starts right after a newline
@@ -4869,6 +4943,12 @@ uint64_t po_debug_host_ranges(uint64_t* out, uint64_t cap_entries) {
         out[3 * i + 2] = g_pins[i].kind;
     }
     return g_pins.size();
+}
+
+uint64_t po_debug_store_words(const po_handle* h, int store, const uint64_t** words) {
+    if (!h || store < 0 || store > 1) return 0;
+    if (words) *words = h->words[store].data();
+    return h->words[store].size();
 }
 
 // The host half of "rows home in compact form" on its own (no GPU): `n` records -> rows through the helper threads, exactly

@@ -334,48 +334,6 @@ __global__ void k_fill_u32(uint32_t* p, uint64_t n, uint32_t v) {
     if (i < n) p[i] = v;
 }
 
-// Device -> host copy by a FEW waves (dst: page-locked host memory the device can address).  The runtime's own copy kernel
-// covers the chip with waves whose stores all wait for PCIe: the memory system's queues fill with them, and a kernel running
-// beside it nearly stops (the counting pass of a streamed piece: 90 us alone, 200-230 us beside the copy of the previous
-// piece's records -- its end follows the copy's end).  The link needs ~128 KB in flight, not megabytes.
-typedef uint32_t copy_v4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_copy_out(copy_v4* __restrict__ dst, const copy_v4* __restrict__ src, uint64_t n16) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const copy_v4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
-        __builtin_nontemporal_store(v0, &dst[i]);
-        __builtin_nontemporal_store(v1, &dst[i + stride]);
-        __builtin_nontemporal_store(v2, &dst[i + 2 * stride]);
-        __builtin_nontemporal_store(v3, &dst[i + 3 * stride]);
-    }
-    for (; i < n16; i += stride) __builtin_nontemporal_store(src[i], &dst[i]);
-}
-
-// Host -> device: the same handful of waves, reading page-locked host memory (8-byte words; dst and src have the same
-// alignment modulo 16, the odd word at either end goes separately).
-__global__ __launch_bounds__(256) void k_copy_in(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, uint64_t n_words) {
-    const uint64_t head = ((reinterpret_cast<uintptr_t>(dst) & 15u) && n_words) ? 1u : 0u;
-    const uint64_t n16 = (n_words - head) / 2;
-    const copy_v4* s = reinterpret_cast<const copy_v4*>(src + head);
-    copy_v4* d = reinterpret_cast<copy_v4*>(dst + head);
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) {
-        if (head) dst[0] = src[0];
-        if (head + 2 * n16 < n_words) dst[n_words - 1] = src[n_words - 1];
-    }
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const copy_v4 v0 = __builtin_nontemporal_load(&s[i]), v1 = __builtin_nontemporal_load(&s[i + stride]),
-                      v2 = __builtin_nontemporal_load(&s[i + 2 * stride]), v3 = __builtin_nontemporal_load(&s[i + 3 * stride]);
-        d[i] = v0;
-        d[i + stride] = v1;
-        d[i + 2 * stride] = v2;
-        d[i + 3 * stride] = v3;
-    }
-    for (; i < n16; i += stride) d[i] = __builtin_nontemporal_load(&s[i]);
-}
-
 // One thread per read: claim the slot of its K-base prefix, count it, set its Bloom bits.
 // Reads shorter than min_length can never be a `b` (they are never at a pushed node or a
 // contained leaf, overlapper.cpp:40,:95) and are left out of the index.

@@ -81,6 +81,19 @@ def test_native_fasta_ingest_matches_python_reader(tmp_path):
     single.close()
 
 
+def _stores(ov):
+    """Both packed host stores of a handle, as bytes (po_debug_store_words)."""
+    import ctypes
+    from phasm_amd import _lib
+    lib = _lib.load()
+    out = []
+    for k in (0, 1):
+        ptr = ctypes.c_void_p()
+        n = lib.po_debug_store_words(ov._h, k, ctypes.byref(ptr))
+        out.append(ctypes.string_at(ptr.value, n * 8) if n else b"")
+    return out
+
+
 def test_parallel_and_sequential_fasta_ingest_agree(tmp_path, monkeypatch):
     """po_add_fasta packs pure-ACGT files with several threads from the mapped file and falls back to the
     record-by-record path for anything else: both must give the same reads (names, lengths -- and, on the GPU,
@@ -115,9 +128,12 @@ def test_parallel_and_sequential_fasta_ingest_agree(tmp_path, monkeypatch):
                 monkeypatch.delenv("PHASM_FASTA_SEQUENTIAL", raising=False)
                 if mode.startswith("ranges"):
                     monkeypatch.setenv("PHASM_FASTA_RANGES", mode[6:])
+            # (fresh store blocks are filled with 0xA5: the parallel path grows the stores without zero-filling them and writes
+            # every word itself -- the reads' words, the alignment gaps, the spare word behind each read)
+            monkeypatch.setenv("PHASM_POISON_HOST", "1")
             ov = ExactOverlapper()
             assert ov.add_fasta(str(p)) == len(recs)
-            got[mode] = (ov.ids(), ov.lengths().tolist())
+            got[mode] = (ov.ids(), ov.lengths().tolist(), _stores(ov))
             ov.close()
         assert got["parallel"] == got["sequential"] == got["ranges3"] == got["ranges7"] == got["ranges64"]
         assert got["parallel"][0] == [n + s for n, _ in recs for s in "+-"]
