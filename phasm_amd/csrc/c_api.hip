@@ -3711,8 +3711,9 @@ po_status append_home(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t n_r
         const uint32_t slot = (uint32_t)(h->home_seq % N_EV);
         const uint32_t want = ++h->home_gen;
         char* dst = dst0 + lo * sizeof(po::Cand);
-        // (Measured and not kept, round 4 -- profiles/r04_copy_kernels.txt.  The kernel trace shows the counting pass of the
-        // NEXT piece at 200-230 us instead of 90 while this copy is in flight (the runtime copies with a kernel of its own).
+        // (Measured and not kept, round 4 -- profiles/r04_copy_kernels.txt.  Under the tracer the counting pass of the NEXT
+        // piece shows 200-230 us instead of 90 while this copy is in flight (the runtime copies with a kernel of its own);
+        // the HIP events of an untraced step do not (91 us per piece), and tools/copy_beside_kernel.py finds x 1.04-1.08.
         // A copy kernel of ours writing the page-locked block with 1 .. 256 workgroups: 5.1, 5.0, 5.1, 5.3, 5.4, 5.5 ms per step
         // against 4.7 -- the fewer waves the better, and the runtime's copy better than all of them; the same for the upload,
         // 6.8-7.8 ms.  Copying 50 % / 10 % of the bytes (timing only, the host reading the previous step's identical records):
