@@ -612,10 +612,10 @@ bool kit_take(po_handle* h) {
 
 // true: the handle's streams / events / landing zone went back to the pool (the caller must not destroy them)
 bool kit_give(po_handle* h) {
-    if (getenv("PHASM_NO_KIT_POOL") || !h->stream || !h->copy_stream || !h->up_stream || !h->rc_stream || !h->scan_stream || !h->pinned) return false;
+    if (getenv("PHASM_NO_KIT_POOL") || !h->stream || !h->copy_stream || !h->up_stream || !h->rc_stream || !h->pinned) return false;
     if (hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->copy_stream) != hipSuccess ||
         hipStreamSynchronize(h->up_stream) != hipSuccess || hipStreamSynchronize(h->rc_stream) != hipSuccess ||
-        hipStreamSynchronize(h->scan_stream) != hipSuccess) {
+        (h->scan_stream && hipStreamSynchronize(h->scan_stream) != hipSuccess)) {
         (void)hipGetLastError();
         return false;
     }
@@ -1007,7 +1007,9 @@ po_status init_device(po_handle* h) {
     imark("copy stream made");
     HIP_TRY(h, hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
     HIP_TRY(h, hipStreamCreateWithFlags(&h->rc_stream, hipStreamNonBlocking));
-    HIP_TRY(h, hipStreamCreateWithFlags(&h->scan_stream, hipStreamNonBlocking));
+    // (four streams = the runtime's four hardware queues, one each.  A fifth stream shares a queue with one of these, and
+    // whatever it launches waits behind everything queued there -- rc_stream's kernels are all queued up front behind the
+    // pieces' arrival events: profiles/r04_two_stream.txt.  The opt-in two-stream pieces make theirs when first asked for.)
     imark("other streams made");
     HIP_TRY(h, hipEventCreateWithFlags(&h->ev_s1[0], hipEventDisableTiming));
     HIP_TRY(h, hipEventCreateWithFlags(&h->ev_s1[1], hipEventDisableTiming));
@@ -1036,14 +1038,13 @@ po_status init_device(po_handle* h) {
             hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->up_stream, wd + 8, (uint64_t)1, 0u);
             (void)hipMemcpyAsync(wd + 16, h->pinned + 62, 8, hipMemcpyHostToDevice, h->stream);
             hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->rc_stream, wd + 24, (uint64_t)1, 0u);
-            hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->scan_stream, wd + 40, (uint64_t)1, 0u);
+            if (h->scan_stream) hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->scan_stream, wd + 40, (uint64_t)1, 0u);
             hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->copy_stream, wd + 32, (uint64_t)1, 0u);
             (void)hipMemcpyAsync(h->pinned + 61, wd + 32, 8, hipMemcpyDeviceToHost, h->copy_stream);
             (void)hipMemcpyAsync(h->pinned + 60, wd + 16, 8, hipMemcpyDeviceToHost, h->stream);
             (void)hipStreamSynchronize(h->up_stream);
             (void)hipStreamSynchronize(h->rc_stream);
             if (h->scan_stream) (void)hipStreamSynchronize(h->scan_stream);
-            (void)hipStreamSynchronize(h->scan_stream);
             (void)hipStreamSynchronize(h->copy_stream);
             (void)hipStreamSynchronize(h->stream);
             (void)hipFree(w);
@@ -3982,7 +3983,12 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
     // Measured, round 4 (config 2): 7.1-7.2 ms per step against 4.5 on one stream -- the persistent scan kernel takes every CU's
     // LDS and registers, the verify workgroups of the piece before wait behind it, and both run slower side by side than one
     // after the other.  Off unless PHASM_TWO_STREAM=1 asks for it.
-    h->two_stream = h->st_early_index && h->scan_stream && h->ev_idx && getenv("PHASM_TWO_STREAM") && atoi(getenv("PHASM_TWO_STREAM")) != 0;
+    const bool want_two = getenv("PHASM_TWO_STREAM") && atoi(getenv("PHASM_TWO_STREAM")) != 0;
+    if (want_two && !h->scan_stream && hipStreamCreateWithFlags(&h->scan_stream, hipStreamNonBlocking) != hipSuccess) {
+        h->scan_stream = nullptr;
+        (void)hipGetLastError();
+    }
+    h->two_stream = h->st_early_index && h->scan_stream && h->ev_idx && want_two;
     if (h->st_early_index) {
         po_result part;
         part.h = h;

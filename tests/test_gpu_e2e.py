@@ -32,11 +32,13 @@ def test_cli_overlap_writes_reference_lines(tmp_path):
     assert out.read_bytes() == out_py.read_bytes()   # native ingest == Python ingest, byte for byte
     import os
     os.environ["PHASM_FASTA_RANGES"] = "5"            # the parallel record scan cut into ranges (a 160 kB file is one range otherwise)
+    os.environ["PHASM_POISON_HOST"] = "1"             # ... into stores that start as 0xA5: the ingest writes every word itself
     try:
         out_r = tmp_path / "out_ranges.gfa"
         assert cli.main(["overlap", str(fa), "-l", str(m), "-o", str(out_r)]) == 0
     finally:
         del os.environ["PHASM_FASTA_RANGES"]
+        del os.environ["PHASM_POISON_HOST"]
     assert out_r.read_bytes() == out.read_bytes()
     lines = out.read_text().splitlines(keepends=True)
     assert lines[0] == "H\tVN:z:2.0\n"
