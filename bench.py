@@ -369,8 +369,8 @@ def main() -> int:
     ap.add_argument("--no-tuples", action="store_true", help="skip the Python tuple materialisation leg")
     ap.add_argument("--no-stream", action="store_true", help="N=1: upload the whole read set first (po_upload), then call po_overlaps_to_host (the unstreamed form of the step)")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the config-4 leg (exact path + banded DP)")
-    ap.add_argument("--other-configs", default="cfg3", help="comma-separated BASELINE configs run after the headline legs on one GPU "
-                                                           "(host-to-host step and kernels alone; '' = none; cfg5 needs ~60 GB of host memory and ~4 minutes)")
+    ap.add_argument("--other-configs", default="cfg3,cfg5", help="comma-separated BASELINE configs run after the headline legs on one GPU "
+                                                           "(host-to-host step and kernels alone; '' = none; cfg5 adds ~35 s and tens of GB of host memory)")
     ap.add_argument("--no-cli", action="store_true", help="skip the `overlap` command leg (a child process: FASTA file in, GFA2 file out)")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-call leg (first call on fresh handles)")
     ap.add_argument("--dist-path", action="store_true",
