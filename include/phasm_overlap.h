@@ -103,7 +103,9 @@ typedef struct {
     uint32_t tail_fallback;      /*    (k_tail: needs a kept row buffer that holds the worst case); tail_fallback = how   */
                                  /*    often that kernel met tandem-repeat reads and the classic kernels ran instead      */
     uint32_t n_predicted;        /* streamed step: pieces whose candidate count was predicted from the previous call on   */
-    uint32_t reserved0;          /*    the same reads (no host round trip between the counting pass and the rest)         */
+    uint32_t home_record_bytes;  /*    the same reads (no host round trip between the counting pass and the rest).        */
+                                 /* home_record_bytes (po_overlaps_to_host): what crossed PCIe per strand-mirror pair of  */
+                                 /*    rows -- 8 or 16 (a verified-candidate record, the host wrote the rows), 0 = the rows */
 } po_stats;
 
 /* ExactOverlapper()  -- src/overlapper.cpp:19, py::init at src/phasm.cpp:13. */
@@ -363,6 +365,10 @@ uint64_t po_debug_store_words(const po_handle* h, int store, const uint64_t** wo
  * n_rows_expected (nothing reliable was written); 2 = a record names a read >= n_reads; -1 = no helper thread. */
 int po_debug_expand_records(const po_cand* records, uint64_t n, const uint32_t* lengths, uint32_t n_reads, uint32_t paired,
                             po_row* rows_out, uint64_t n_rows_expected);
+/* ... and of `n` records of EIGHT bytes, a | b << sh_b | p << sh_p | type << 62 (what po_overlaps_to_host sends when the
+ * read set fits: 2 ceil(log2 reads) + ceil(log2 (longest read + 1)) <= 62); -2 = shifts out of range. */
+int po_debug_expand_packed(const uint64_t* records, uint64_t n, uint32_t sh_b, uint32_t sh_p, const uint32_t* lengths, uint32_t n_reads,
+                           uint32_t paired, po_row* rows_out, uint64_t n_rows_expected);
 int po_debug_fault_backtrace(int fd);
 int po_debug_pointer_info(const void* p, int32_t* hip_type, int32_t* hsa_type, uint64_t* base, uint64_t* bytes);
 

@@ -64,7 +64,7 @@ class PoStats(ctypes.Structure):
         ("dp_lanes", ctypes.c_uint32), ("upload_bytes", ctypes.c_uint64),
         ("streamed", ctypes.c_uint32), ("n_deferred", ctypes.c_uint32),
         ("fused_tail", ctypes.c_uint32), ("tail_fallback", ctypes.c_uint32),
-        ("n_predicted", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
+        ("n_predicted", ctypes.c_uint32), ("home_record_bytes", ctypes.c_uint32),
     ]
 
     def as_dict(self) -> dict:
@@ -127,6 +127,8 @@ SYMBOLS = [
     ("po_last_error", ctypes.c_char_p, [_P]),
     ("po_debug_fault_backtrace", ctypes.c_int, [ctypes.c_int]),
     ("po_debug_store_words", ctypes.c_uint64, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    ("po_debug_expand_packed", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32,
+                                              ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64]),
     ("po_debug_expand_records", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                                ctypes.c_void_p, ctypes.c_uint64]),
     ("po_debug_host_ranges", ctypes.c_uint64, [ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64]),

@@ -268,6 +268,11 @@ struct po_handle {
     size_t home_used = 0;
     uint64_t home_seq = 0;         // pieces submitted to the helper threads by this call
     uint32_t home_gen = 0;         // number written behind a piece's copy (never repeats on a handle's landing zone)
+    // records of 8 bytes instead of 16 where the read set allows it (po::pack_record): the shifts of this call (0 = 16-byte
+    // records), and the state of the read set they were worked out for
+    uint32_t home_sh_b = 0, home_sh_p = 0;
+    uint64_t home_pack_n = ~0ull, home_pack_bases = ~0ull;
+    uint32_t home_pack_b = 0, home_pack_p = 0;
     uint64_t home_last_bytes = 0;  // record bytes of the previous call (sizes home_stage)
 
     // streamed step (po_overlaps_to_host on a changed read set): the packed reads cross PCIe piece by piece on
@@ -691,7 +696,8 @@ namespace home {
 constexpr uint32_t CHUNK = 4096;
 
 struct Job {
-    const po::Cand* rec = nullptr;   // page-locked staging memory
+    const void* rec = nullptr;       // page-locked staging memory: po::Cand records, or (sh_b != 0) packed 8-byte records
+    uint32_t sh_b = 0, sh_p = 0;     // po::pack_record's shifts
     uint64_t n_rec = 0;
     po_row* out = nullptr;           // where this piece's rows start in the result array
     uint64_t n_rows = 0;             // what the device counted for the piece
@@ -747,6 +753,11 @@ inline void cpu_pause() {
 #endif
 }
 
+inline po::Cand load_rec(const Job& j, uint64_t i) {
+    if (!j.sh_b) return static_cast<const po::Cand*>(j.rec)[i];
+    return po::unpack_record(static_cast<const uint64_t*>(j.rec)[i], j.sh_b, j.sh_p);
+}
+
 inline uint32_t rows_of_rec(const po::Cand& c, uint32_t paired) {
     if (!paired) return (c.type & 1u) + ((c.type >> 1) & 1u);
     return ((c.type & 1u) ? (c.a == (c.b ^ 1u) ? 1u : 2u) : 0u) + ((c.type & 2u) ? 2u : 0u);
@@ -763,11 +774,11 @@ inline void put_row(uint64_t*& o, uint32_t a, uint32_t b, uint32_t astart, uint3
 // rows of records [lo, hi) -> out; returns false when a record names a read the handle does not hold
 bool expand_records(const Pool& P, uint64_t lo, uint64_t hi, po_row* out) {
     uint64_t* o = reinterpret_cast<uint64_t*>(out);
-    const po::Cand* rec = P.cur.rec;
+    const Job& job = P.cur;
     const uint32_t* len = P.len;
     const uint32_t paired = P.paired, n_reads = P.n_reads;
     for (uint64_t i = lo; i < hi; ++i) {
-        const po::Cand c = rec[i];
+        const po::Cand c = load_rec(job, i);
         if (c.a >= n_reads || c.b >= n_reads) return false;
         const uint32_t la = len[c.a], lb = len[c.b];
         if (c.type & 1u) {
@@ -795,7 +806,7 @@ void run_phases(Pool& P, bool lead) {
         const uint32_t n_reads = P.n_reads, bits = P.bits, paired = P.paired;
         auto pb = [bits](uint32_t l) -> uint64_t { return bits == 8u ? l : (l >> 2) + ((l & 3u) != 0u); };
         for (uint64_t i = lo; i < hi; ++i) {
-            const po::Cand c = P.cur.rec[i];
+            const po::Cand c = load_rec(P.cur, i);
             n += rows_of_rec(c, paired);
             if (c.a < n_reads && c.b < n_reads) {   // (write_rows' counters, kernels.hip.h)
                 const uint32_t la = P.len[c.a], lb = P.len[c.b];
@@ -2485,7 +2496,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
                 res->compact = true;
                 hipLaunchKernelGGL(po::k_tail_cands, dim3(n_tt), dim3(po::TAIL_BLOCK), 0, st, A.cand_a, A.cand_p, A.cand_b, h->d_type.as<uint8_t>(),
                                    n_cand, res->d_rows.as<po::Cand>(), paired, tgate, tile_rows, n_tt, tail_done,
-                                   scalars + 3, h->pinned_dev + tail_zone, G);
+                                   scalars + 3, h->pinned_dev + tail_zone, G, h->home_sh_b, h->home_sh_p);
             } else
             hipLaunchKernelGGL(po::k_tail, dim3(n_tt), dim3(po::TAIL_BLOCK), 0, st, A.cand_a, A.cand_p, A.cand_b, h->d_type.as<uint8_t>(),
                                n_cand, len, res->d_rows.as<po::Row>(), (uint32_t)BITS, paired, tgate, tile_rows, n_tt, tail_done,
@@ -3629,6 +3640,24 @@ bool home_begin(po_handle* h) {
     h->home_on = true;
     h->home_used = 0;
     h->home_seq = 0;
+    // a and b in ceil(log2(reads)) bits each, p in ceil(log2(longest read + 1)), type in the top two: one 64-bit word when
+    // that fits (100 k reads of 15 kb: 17 + 17 + 14; 2 M reads of 12 kb: 21 + 21 + 14), the 16-byte record otherwise
+    if (h->home_pack_n != h->len.size() || h->home_pack_bases != h->total_bases) {
+        uint32_t longest = 0;
+        for (uint32_t l : h->len) longest = std::max(longest, l);
+        uint32_t br = 1, bp = 1;
+        while ((1ull << br) < (uint64_t)h->len.size()) ++br;
+        while ((1ull << bp) < (uint64_t)longest + 1ull) ++bp;
+        const bool fits = 2 * br + bp <= 62;
+        h->home_pack_b = fits ? br : 0u;
+        h->home_pack_p = fits ? 2 * br : 0u;
+        h->home_pack_n = h->len.size();
+        h->home_pack_bases = h->total_bases;
+    }
+    const char* pk = getenv("PHASM_HOME_PACK");
+    const bool pack = !(pk && atoi(pk) == 0);
+    h->home_sh_b = pack ? h->home_pack_b : 0u;
+    h->home_sh_p = pack ? h->home_pack_p : 0u;
     return true;
 }
 
@@ -3685,7 +3714,8 @@ po_status append_home(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t n_r
     if (nk == 0) return PO_OK;
     home::Pool* P = home::g_pool;
     PO_TRY(rows_room(h, R, nk, k, n_chunks, seen_share));
-    const size_t bytes = (size_t)n_rec * sizeof(po::Cand);
+    const size_t elem = h->home_sh_b ? sizeof(uint64_t) : sizeof(po::Cand);
+    const size_t bytes = (size_t)n_rec * elem;
     constexpr uint64_t N_EV = 32;   // flag words: slots 96 .. 127 of the landing zone
     if (h->home_used + bytes > h->home_stage.cap || (h->home_seq && h->home_seq % N_EV == 0)) {
         // the block is full (or every flag word has been used once): wait for the helper threads, start over at its beginning
@@ -3711,7 +3741,7 @@ po_status append_home(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t n_r
         const uint64_t lo = n_rec * part / n_parts, hi = n_rec * (part + 1) / n_parts;
         const uint32_t slot = (uint32_t)(h->home_seq % N_EV);
         const uint32_t want = ++h->home_gen;
-        char* dst = dst0 + lo * sizeof(po::Cand);
+        char* dst = dst0 + lo * elem;
         // (Measured and not kept, round 4 -- profiles/r04_copy_kernels.txt.  Under the tracer the counting pass of the NEXT
         // piece shows 200-230 us instead of 90 while this copy is in flight (the runtime copies with a kernel of its own);
         // the HIP events of an untraced step do not (91 us per piece), and tools/copy_beside_kernel.py finds x 1.04-1.08.
@@ -3719,12 +3749,13 @@ po_status append_home(po_handle* h, HostRows& R, const DevBuf& dev, uint64_t n_r
         // against 4.7 -- the fewer waves the better, and the runtime's copy better than all of them; the same for the upload,
         // 6.8-7.8 ms.  Copying 50 % / 10 % of the bytes (timing only, the host reading the previous step's identical records):
         // 4.57 / 4.49 ms -- all of the interference is worth 0.2 ms, 8-byte records would buy 0.13.)
-        HIP_TRY(h, hipMemcpyAsync(dst, static_cast<const char*>(dev.p) + lo * sizeof(po::Cand), (hi - lo) * sizeof(po::Cand),
-                                  hipMemcpyDeviceToHost, h->copy_stream));
+        HIP_TRY(h, hipMemcpyAsync(dst, static_cast<const char*>(dev.p) + lo * elem, (hi - lo) * elem, hipMemcpyDeviceToHost, h->copy_stream));
         hipLaunchKernelGGL(po::k_fill_u32, dim3(1), dim3(64), 0, h->copy_stream, reinterpret_cast<uint32_t*>(h->pinned_dev + 96 + slot), (uint64_t)1, want);
         HIP_TRY(h, hipGetLastError());
         home::Job j;
-        j.rec = reinterpret_cast<const po::Cand*>(dst);
+        j.rec = dst;
+        j.sh_b = h->home_sh_b;
+        j.sh_p = h->home_sh_p;
         j.n_rec = hi - lo;
         j.out = static_cast<po_row*>(R.hb.p) + R.total;
         j.n_rows = nk;
@@ -4267,6 +4298,7 @@ po_status po_overlaps_to_host(po_handle* h, uint32_t min_length, po_result** out
     S.ms_verify_kernel = sum.ms_verify_kernel;
     S.fused_tail = sum.fused_tail;
     S.n_predicted = sum.n_predicted;
+    S.home_record_bytes = h->home_last_bytes ? (h->home_sh_b ? 8u : 16u) : 0u;
     S.tail_fallback = sum.tail_fallback + (h->st_tail_gave_up ? 1u : 0u);
     h->st_tail_gave_up = false;
     S.streamed = streamed ? 1u : 0u;
@@ -4974,6 +5006,33 @@ int po_debug_expand_records(const po_cand* records, uint64_t n, const uint32_t* 
         const uint64_t lo = n * jn / n_jobs, hi = n * (jn + 1) / n_jobs;
         home::Job j;
         j.rec = reinterpret_cast<const po::Cand*>(records) + lo;
+        j.n_rec = hi - lo;
+        j.out = rows_out;
+        j.n_rows = n_rows_expected;
+        j.cont = jn > 0;
+        j.more = jn + 1 < n_jobs;
+        home::submit(P, j);
+    }
+    home::wait_all(P);
+    return P->error.load();
+}
+
+// ... the same for records of 8 bytes (po::pack_record with the shifts sh_b, sh_p: a | b << sh_b | p << sh_p | type << 62)
+int po_debug_expand_packed(const uint64_t* records, uint64_t n, uint32_t sh_b, uint32_t sh_p, const uint32_t* lengths, uint32_t n_reads,
+                           uint32_t paired, po_row* rows_out, uint64_t n_rows_expected) {
+    if (!sh_b || sh_p < sh_b || sh_p >= 62) return -2;
+    home::Pool* P = home::pool();
+    if (!P) return -1;
+    std::lock_guard<std::mutex> call(P->call_mu);
+    home::begin(P, lengths, n_reads, false);
+    P->paired = paired ? 1u : 0u;
+    const uint64_t n_jobs = n ? std::min<uint64_t>(5, (n + 2999) / 3000) : 0;
+    for (uint64_t jn = 0; jn < n_jobs; ++jn) {
+        const uint64_t lo = n * jn / n_jobs, hi = n * (jn + 1) / n_jobs;
+        home::Job j;
+        j.rec = records + lo;
+        j.sh_b = sh_b;
+        j.sh_p = sh_p;
         j.n_rec = hi - lo;
         j.out = rows_out;
         j.n_rows = n_rows_expected;

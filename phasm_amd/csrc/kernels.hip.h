@@ -2230,6 +2230,16 @@ struct Cand {
     uint32_t a, p, b, type;
 };
 
+// A verified-candidate record in 8 bytes, when the read set allows it: a and b below 2^sh_b, p below 2^(62 - sh_p),
+// sh_p = 2 sh_b.  (rows home in compact form)
+__host__ __device__ inline uint64_t pack_record(uint32_t a, uint32_t p, uint32_t b, uint32_t type, uint32_t sh_b, uint32_t sh_p) {
+    return (uint64_t)a | ((uint64_t)b << sh_b) | ((uint64_t)p << sh_p) | ((uint64_t)type << 62);
+}
+__host__ __device__ inline Cand unpack_record(uint64_t v, uint32_t sh_b, uint32_t sh_p) {
+    const uint64_t mr = (1ull << sh_b) - 1ull;
+    return Cand{(uint32_t)(v & mr), (uint32_t)((v >> sh_p) & ((1ull << (62u - sh_p)) - 1ull)), (uint32_t)((v >> sh_b) & mr), (uint32_t)(v >> 62)};
+}
+
 __global__ void k_compact(const uint32_t* __restrict__ cand_a, const uint32_t* __restrict__ cand_p,
                           const uint32_t* __restrict__ cand_b, const uint8_t* __restrict__ type,
                           const uint8_t* __restrict__ flag, const uint32_t* __restrict__ flag_off, uint32_t n_cand,
@@ -3016,7 +3026,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail_cands(const uint32_t* __res
                                                            uint32_t n_cand, Cand* __restrict__ out, uint32_t paired,
                                                            const uint32_t* __restrict__ gate, const uint32_t* __restrict__ tile_recs,
                                                            uint32_t n_tiles, uint32_t* __restrict__ done, unsigned long long* __restrict__ rows_ctr,
-                                                           uint64_t* __restrict__ host_out, const CandGuard G) {
+                                                           uint64_t* __restrict__ host_out, const CandGuard G, uint32_t sh_b, uint32_t sh_p) {
     __shared__ uint32_t s_cnt[TAIL_ITEMS][TAIL_BLOCK / WAVE];
     __shared__ uint32_t s_pre[TAIL_BLOCK / WAVE];
     __shared__ uint32_t s_rows[TAIL_BLOCK / WAVE];
@@ -3092,9 +3102,18 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail_cands(const uint32_t* __res
         }
         excl[r] += before;
     }
+    // sh_b != 0: the record in EIGHT bytes -- a | b << sh_b | p << sh_p | type << 62 (pack_record; the host chose the widths
+    // from the number of reads and the longest read, c_api.hip: home_pack_shifts) -- half the bytes on the wire again
+    if (sh_b) {
+        uint64_t* out8 = reinterpret_cast<uint64_t*>(out);
 #pragma unroll
-    for (int r = 0; r < TAIL_ITEMS; ++r)
-        if (t[r]) out[pfx + excl[r]] = Cand{a[r], pp[r], b[r], t[r]};
+        for (int r = 0; r < TAIL_ITEMS; ++r)
+            if (t[r]) out8[pfx + excl[r]] = pack_record(a[r], pp[r], b[r], t[r], sh_b, sh_p);
+    } else {
+#pragma unroll
+        for (int r = 0; r < TAIL_ITEMS; ++r)
+            if (t[r]) out[pfx + excl[r]] = Cand{a[r], pp[r], b[r], t[r]};
+    }
     if (tile == n_tiles - 1u && threadIdx.x == 0) host_out[1] = (uint64_t)pfx + block_total;   // (the last tile: all records)
     if (threadIdx.x == 0) {
         // ONE returning atomic per workgroup for the row total (the byte sums of po_stats are taken on the host while the

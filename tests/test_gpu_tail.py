@@ -62,12 +62,16 @@ def test_fused_tail_gives_the_golden_rows(form, monkeypatch):
         assert n_fallback > 0                            # ... and the tandem-repeat reads of repeats.npz sent it back
 
 
-@pytest.mark.parametrize("home", ["1", "0"])
+@pytest.mark.parametrize("home", ["1", "1 with 16-byte records", "0"])
 def test_classic_and_fused_tails_emit_the_same_array(home, monkeypatch):
     """Same emission order, not just the same multiset: the prefix sums are exact either way -- and so is the host's
-    expansion of the compact records (home = 1: po_overlaps_to_host brings one 16-byte record per verified candidate home
-    and helper threads write the rows; home = 0: the device writes the rows and every one of them crosses PCIe).  The
-    row array is the same bytes in all forms."""
+    expansion of the compact records (home = 1: po_overlaps_to_host brings one record per verified candidate home -- 8 bytes
+    where the read set fits one word, 16 otherwise or with PHASM_HOME_PACK=0 -- and helper threads write the rows; home = 0:
+    the device writes the rows and every one of them crosses PCIe).  The row array is the same bytes in all forms."""
+    wide_records = home.endswith("16-byte records")
+    home = home[0]
+    if wide_records:
+        monkeypatch.setenv("PHASM_HOME_PACK", "0")
     monkeypatch.setenv("PHASM_HOME", home)
     _, seqs, m, want = gu.ladder_case("cfg2_1k")
     ov = ExactOverlapper()
@@ -76,6 +80,7 @@ def test_classic_and_fused_tails_emit_the_same_array(home, monkeypatch):
     first = ov.overlaps_array(m)
     # (the record tail needs no kept worst-case row buffer: it runs from the first call on; the row tail from the second)
     assert ov.stats()["fused_tail"] == (1 if home == "1" else 0)
+    assert ov.stats()["home_record_bytes"] == (0 if home == "0" else 16 if wide_records else 8)
     counters = {k: ov.stats()[k] for k in ("n_rows", "n_verified", "sum_overlap_bases", "verify_bytes_algo", "verify_bytes_exec")}
     assert counters["n_rows"] == len(want) and counters["sum_overlap_bases"] == int(want[:, 5].sum())   # (bend = l, bstart = 0)
     second = ov.overlaps_array(m)

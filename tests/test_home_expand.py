@@ -32,20 +32,68 @@ def expand_py(recs, lens, paired):
     return out
 
 
+def pack_shifts(n_reads, longest):
+    """The widths po_overlaps_to_host picks (c_api.hip, home_begin): a and b in ceil(log2 reads) bits, p above them."""
+    br = 1
+    while (1 << br) < n_reads:
+        br += 1
+    bp = 1
+    while (1 << bp) < longest + 1:
+        bp += 1
+    assert 2 * br + bp <= 62
+    return br, 2 * br
+
+
+PACKED = False   # (set by the fixture below: every test of this file runs with both record forms)
+
+
+@pytest.fixture(autouse=True, params=["16-byte records", "8-byte records"])
+def record_form(request):
+    global PACKED
+    PACKED = request.param.startswith("8")
+    yield
+    PACKED = False
+
+
 def expand_lib(recs, lens, paired, n_rows=None):
     lib = _lib.load()
+    L = np.ascontiguousarray(lens, dtype=np.uint32)
+    want = len(expand_py(recs, lens, paired)) if n_rows is None else n_rows
+    out = np.empty(want + 2, dtype=ROW_DTYPE)
+    out.view(np.uint8)[:] = 0x5A
+    if PACKED:
+        # (a foreign read index must still fit its field to travel at all: widths from the largest index named)
+        top = max([len(L)] + [max(a, b) + 1 for a, _, b, _ in recs])
+        sh_b, sh_p = pack_shifts(top, int(L.max()) if len(L) else 1)
+        r8 = np.array([a | (b << sh_b) | (p << sh_p) | (t << 62) for a, p, b, t in recs], dtype=np.uint64)
+        rc = lib.po_debug_expand_packed(r8.ctypes.data_as(ctypes.c_void_p), len(r8), sh_b, sh_p, L.ctypes.data_as(ctypes.c_void_p), len(L),
+                                        1 if paired else 0, out.ctypes.data_as(ctypes.c_void_p), want)
+        return rc, out
     r = np.zeros(len(recs), dtype=CAND_DTYPE)
     if len(recs):
         arr = np.asarray(recs, dtype=np.uint32).reshape(-1, 4)
         for k, name in enumerate(CAND_DTYPE.names):
             r[name] = arr[:, k]
-    L = np.ascontiguousarray(lens, dtype=np.uint32)
-    want = len(expand_py(recs, lens, paired)) if n_rows is None else n_rows
-    out = np.empty(want + 2, dtype=ROW_DTYPE)
-    out.view(np.uint8)[:] = 0x5A
     rc = lib.po_debug_expand_records(r.ctypes.data_as(ctypes.c_void_p), len(r), L.ctypes.data_as(ctypes.c_void_p), len(L),
                                      1 if paired else 0, out.ctypes.data_as(ctypes.c_void_p), want)
     return rc, out
+
+
+def test_packed_records_keep_full_width_fields():
+    """The widest read set one word can hold: 2^24 reads of up to 2^14 - 1 bases, and 2^17 reads of up to 2^28 - 1."""
+    lib = _lib.load()
+    for n_reads, longest in ((1 << 24, (1 << 14) - 1), (1 << 17, (1 << 28) - 1)):
+        sh_b, sh_p = pack_shifts(n_reads, longest)
+        lens = np.full(n_reads, longest, dtype=np.uint32)
+        a, b, p = n_reads - 2, n_reads - 1, longest - 7
+        r8 = np.array([a | (b << sh_b) | (p << sh_p) | (1 << 62)], dtype=np.uint64)
+        out = np.empty(2, dtype=ROW_DTYPE)
+        rc = lib.po_debug_expand_packed(r8.ctypes.data_as(ctypes.c_void_p), 1, sh_b, sh_p, lens.ctypes.data_as(ctypes.c_void_p), n_reads, 0,
+                                        out.ctypes.data_as(ctypes.c_void_p), 1)
+        assert rc == 0
+        assert rows_list(out[:1]) == [(a, b, p, longest, 0, 7)]
+    assert lib.po_debug_expand_packed(r8.ctypes.data_as(ctypes.c_void_p), 1, 0, 0, lens.ctypes.data_as(ctypes.c_void_p), n_reads, 0,
+                                      out.ctypes.data_as(ctypes.c_void_p), 1) == -2
 
 
 def rows_list(arr):
