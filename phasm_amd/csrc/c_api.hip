@@ -651,20 +651,6 @@ bool kit_give(po_handle* h) {
 }
 
 
-// ---- rows home in compact form -------------------------------------------------------------------------------------------
-// po_overlaps_to_host used to bring every 24-byte row across PCIe: 168 MB at BASELINE config 2, and the step ended when that
-// copy ended.  Half of those rows are strand mirrors of the other half, and every exact row is a function of {a, p, b, type}
-// and the two read lengths -- the 16-byte verified-candidate record the multi-GPU exchange already uses (po_cand).  So the
-// device hands out one record per strand-mirror pair (k_tail_cands), the records cross PCIe (56 MB at config 2), and host
-// threads write the rows into the page-locked result array while later pieces are still on the device: the same array, byte
-// for byte, that k_tail / k_emit write on the device (rows per record in write_rows' order: A row, [its mirror], B row,
-// [its mirror]; records in candidate order).  SURVEY.md section 8c has the mirror rules; the row fields are those of
-// src/overlapper.cpp:77-82,104-110.
-//
-// One pool per process, threads started at the first use (PHASM_HOME_THREADS, default min(cores, 16); they sleep between
-// calls and spin while a call is active -- a call lasts milliseconds).  Thread 0 takes the pieces in order: it waits for the
-// event behind the piece's device->host copy, then all threads count the rows of the piece's chunks (8192 records each),
-// thread 0 turns the counts into offsets -- and checks the total against what the device counted --, and all threads write.
 // CPUs this process may use: the hardware's count, cut to the container's CPU quota where there is one (cgroup v2 cpu.max
 // "quota period", v1 cpu.cfs_quota_us / _period_us) -- hardware_concurrency() says 256 on a box whose process may use 16, and
 // threads beyond the share only get the whole process throttled
@@ -691,6 +677,21 @@ unsigned cpu_share() {
     return share;
 }
 
+// ---- rows home in compact form -------------------------------------------------------------------------------------------
+// po_overlaps_to_host used to bring every 24-byte row across PCIe: 168 MB at BASELINE config 2, and the step ended when that
+// copy ended.  Half of those rows are strand mirrors of the other half, and every exact row is a function of {a, p, b, type}
+// and the two read lengths -- the verified-candidate record the multi-GPU exchange already uses (po_cand, 16 bytes), or ONE
+// 64-bit word where the read set allows it (po::pack_record: 23 MB at config 2).  So the device hands out one record per
+// strand-mirror pair (k_tail_cands), the records cross PCIe, and host threads write the rows into the page-locked result
+// array while later pieces are still on the device: the same array, byte for byte, that k_tail / k_emit write on the device
+// (rows per record in write_rows' order: A row, [its mirror], B row, [its mirror]; records in candidate order).  SURVEY.md
+// section 8c has the mirror rules; the row fields are those of src/overlapper.cpp:77-82,104-110.
+//
+// One pool per process, threads started at the first use (three quarters of the process's CPU share, 12 at most;
+// PHASM_HOME_THREADS).  Helpers sleep between pieces and spin inside one (a piece is 50-400 us of work).  Thread 0 takes the
+// pieces in order: it polls the page-locked word a one-thread kernel writes behind the piece's device->host copy, then all
+// threads count the rows of the piece's chunks (CHUNK records each), thread 0 turns the counts into offsets -- and checks the
+// total against what the device counted --, and all threads write.
 namespace home {
 
 constexpr uint32_t CHUNK = 4096;
