@@ -512,6 +512,10 @@ def main() -> int:
             dist.barrier()
             torch.cuda.synchronize()
 
+    # (loading the reads used every core the process may have: on a box with a CPU quota the scheduler may still owe the
+    # process a throttled period -- cpu.stat nr_throttled counts them --, and a period that starts inside the timed loop
+    # stops every thread of the step for milliseconds.  Let it pass before the clock starts.)
+    time.sleep(0.3)
     for _ in range(args.warmup):
         step(False)
     fence()

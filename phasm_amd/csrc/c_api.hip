@@ -754,6 +754,19 @@ inline void cpu_pause() {
 #endif
 }
 
+// Spin until pred() holds.  The waits of a piece are microseconds long when every thread has a core; on a host whose cores
+// are busy with other people's work a thread can spin through the time slice of the very thread it waits for (a box like
+// that gave 5.2-5.5 ms per step instead of 4.7), so after a few thousand pauses the waiter offers its core.
+std::atomic<uint32_t> g_spin_limit{4096};   // pauses before a waiter starts yielding (PHASM_HOME_SPIN; 0 = never yield)
+template <class Pred>
+inline void spin_until(Pred pred) {
+    const uint32_t limit = g_spin_limit.load(std::memory_order_relaxed);
+    for (uint32_t n = 0; !pred(); ++n) {
+        if (limit == 0 || n < limit) cpu_pause();
+        else std::this_thread::yield();
+    }
+}
+
 inline po::Cand load_rec(const Job& j, uint64_t i) {
     if (!j.sh_b) return static_cast<const po::Cand*>(j.rec)[i];
     return po::unpack_record(static_cast<const uint64_t*>(j.rec)[i], j.sh_b, j.sh_p);
@@ -831,7 +844,7 @@ void run_phases(Pool& P, bool lead) {
         P.done_count.fetch_add(1, std::memory_order_release);
     }
     if (lead) {
-        while (P.done_count.load(std::memory_order_acquire) < nc) cpu_pause();
+        spin_until([&] { return P.done_count.load(std::memory_order_acquire) >= nc; });
         P.chunk_off[0] = 0;
         for (uint32_t c = 0; c < nc; ++c) P.chunk_off[c + 1] += P.chunk_off[c];
         P.part_rows += P.chunk_off[nc];
@@ -839,7 +852,7 @@ void run_phases(Pool& P, bool lead) {
         P.part_next = P.cur.out + P.chunk_off[nc];
         P.phase.store(P.error.load() ? 0 : 2, std::memory_order_release);
     } else {
-        while (P.phase.load(std::memory_order_acquire) == 1) cpu_pause();
+        spin_until([&] { return P.phase.load(std::memory_order_acquire) != 1; });
     }
     if (P.phase.load(std::memory_order_acquire) != 2) return;
     for (;;) {   // write
@@ -880,12 +893,12 @@ void leader(Pool* Pp) {
             P.queue.pop_front();
         }
         if (j.flag)   // the records are home when the word behind their copy has arrived
-            while (*j.flag != j.want) cpu_pause();
+            spin_until([&] { return *j.flag == j.want; });
         std::atomic_thread_fence(std::memory_order_acquire);
         const double t_ready = P.tracing ? std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - P.t0).count() : 0.0;
         if (P.error.load() == 0 && j.n_rec) {
             // (no helper is inside the previous piece's loops any more: the counters may be reset)
-            while (P.inside.load(std::memory_order_acquire) != 0) cpu_pause();
+            spin_until([&] { return P.inside.load(std::memory_order_acquire) == 0; });
             if (j.cont) j.out = P.part_next;
             else P.part_rows = 0;
             P.cur = j;
@@ -903,7 +916,7 @@ void leader(Pool* Pp) {
             P.cv_job.notify_all();
             run_phases(P, true);
             if (P.phase.load() == 2)
-                while (P.done_write.load(std::memory_order_acquire) < P.n_chunks) cpu_pause();
+                spin_until([&] { return P.done_write.load(std::memory_order_acquire) >= P.n_chunks; });
             P.phase.store(0, std::memory_order_release);
             std::atomic_thread_fence(std::memory_order_seq_cst);
         }
@@ -942,6 +955,8 @@ Pool* pool() {
 }
 
 void begin(Pool* P, const uint32_t* len, uint32_t n_reads, bool tracing) {
+    if (const char* e = getenv("PHASM_HOME_SPIN")) g_spin_limit.store((uint32_t)std::max(0, atoi(e)));
+    else g_spin_limit.store(4096);
     P->len = len;
     P->n_reads = n_reads;
     P->paired = 0;
@@ -967,7 +982,7 @@ void submit(Pool* P, const Job& j) {
 
 void wait_all(Pool* P) {
     // (the caller has nothing else to do: it spins -- the last piece's rows are what the call is waiting for)
-    while (P->finished.load(std::memory_order_acquire) < P->submitted.load(std::memory_order_acquire)) cpu_pause();
+    spin_until([&] { return P->finished.load(std::memory_order_acquire) >= P->submitted.load(std::memory_order_acquire); });
 }
 
 }  // namespace home
