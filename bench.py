@@ -228,6 +228,15 @@ def cli_overlap_leg(reads, m: int) -> dict:
         shutil.rmtree(d, ignore_errors=True)
 
 
+def cpu_throttled():
+    """(nr_throttled, throttled_usec) of this process's cgroup (v2 cpu.stat), or None."""
+    try:
+        kv = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat"))
+        return int(kv["nr_throttled"]), int(kv["throttled_usec"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def other_config_leg(dev_idx: int, name: str, m: int, steps: int = 3) -> dict:
     """Another BASELINE config on ONE GPU, outside the headline's timed region: the host-to-host step (a changed
     read set: streamed upload, kernels, rows home -- what `value` measures at config 2) and the kernels alone (reads resident,
@@ -519,6 +528,7 @@ def main() -> int:
     for _ in range(args.warmup):
         step(False)
     fence()
+    throttled0 = cpu_throttled()
     t0 = time.perf_counter()
     n_rows = 0
     step_ms = []
@@ -528,6 +538,7 @@ def main() -> int:
         step_ms.append((time.perf_counter() - t_s) * 1e3)   # (a step ends with its rows in host memory: nothing is in flight here)
     fence()
     dt = time.perf_counter() - t0
+    throttled1 = cpu_throttled()
     if world > 1 or args.dist_path:
         t = torch.tensor([dt], dtype=torch.float64, device=merge_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -587,7 +598,10 @@ def main() -> int:
             # (this rank's steps one by one: ms_per_step is the mean the contract asks for; a box whose host cores are busy
             # with someone else's work shows as a max far from the median -- the step's last stage runs on host threads)
             "steps_ms": {"median": sorted(step_ms)[len(step_ms) // 2], "min": min(step_ms), "max": max(step_ms),
-                         "p90": sorted(step_ms)[min(len(step_ms) - 1, (len(step_ms) * 9) // 10)]},
+                         "p90": sorted(step_ms)[min(len(step_ms) - 1, (len(step_ms) * 9) // 10)],
+                         # (CPU-quota periods in which the scheduler stopped this process, and for how long, inside the timed loop)
+                         "cpu_quota_throttled_periods": None if throttled0 is None or throttled1 is None else throttled1[0] - throttled0[0],
+                         "cpu_quota_throttled_ms": None if throttled0 is None or throttled1 is None else (throttled1[1] - throttled0[1]) / 1e3},
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%s: %d x %d b error-free reads, %d b %d-ploid genome (snp %.3f, seed %d), "
