@@ -755,11 +755,18 @@ def main() -> int:
                            "h2d_ms": pcie["h2d_s"] / K * 1e3,
                            "h2d_GBps": h2d_bytes / (pcie["h2d_s"] / K) / 1e9 if pcie["h2d_s"] > 0 else None,
                            "d2h_bytes_per_step": int(d2h_bytes),
+                           # what really crossed device -> host: one record per strand-mirror pair (8 or 16 bytes), the rows are
+                           # written by the library's host threads (po_stats.home_record_bytes; 0 = the rows themselves crossed)
+                           "d2h_record_bytes": int(incl_last.get("home_record_bytes", 0)),
+                           "d2h_wire_bytes_per_step": int(incl_last.get("home_record_bytes", 0) * incl_last.get("n_verified", 0)
+                                                          if incl_last.get("home_record_bytes", 0) else d2h_bytes),
+                           "link_h2d_GBps_measured": 57.0,   # (tools/h2d_source_probe.hip: one 188 MB copy; 54.5 in 11 pieces with events)
                            "kernels_plus_d2h_ms": (dt - pcie["h2d_s"]) / K * 1e3,
                            "d2h_alone_ms_at_measured_h2d_rate": d2h_bytes / (h2d_bytes / (pcie["h2d_s"] / K)) * 1e3 if pcie["h2d_s"] > 0 else None,
                            "peak_GBps_per_direction": 64.0,
                            "pcie_floor_ms": (h2d_bytes + d2h_bytes) / 64e9 * 1e3,
                            "pcie_floor_duplex_ms": max(h2d_bytes, d2h_bytes) / 64e9 * 1e3,
+                           "upload_floor_ms_at_measured_link_rate": h2d_bytes / 57.0e9 * 1e3,
                            "streamed": bool(pcie.get("streamed_steps")),
                            "deferred_containments": int(incl_last.get("n_deferred", 0)),
                            "predicted_pieces": int(incl_last.get("n_predicted", 0)), "fused_tails": int(incl_last.get("fused_tail", 0)),
