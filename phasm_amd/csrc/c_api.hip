@@ -300,6 +300,11 @@ struct po_handle {
     // them ahead of the pieces straight from here); first_n = reads it covers (a bulk ingest fills it in afterwards)
     WordStore first_words;
     uint32_t first_n = 0;
+    // ... and the first LEAD_WORDS words of every read, made when a streamed step first wants them (large read sets: the wide
+    // index with windows of 4, whose K-mers reach into the fifth word); st_lead = words per read travelling ahead this step
+    WordStore lead_words;
+    uint32_t lead_n = 0;
+    uint32_t st_lead = 2;
     // per-read metadata of the upload, kept page-locked while the read set is unchanged (reads are only ever appended):
     // [woff x n | len x n | first tile x (n + 1)]; meta_n = reads it covers, meta_bits = encoding it was counted for
     HostBuf meta_host;
@@ -1208,6 +1213,8 @@ void widen_to_bytes(po_handle* h) {
     h->all_pairs_rcx = false;
     h->first_n = 0;
     h->first_words.clear();
+    h->lead_n = 0;
+    h->lead_words.clear();
     h->exc_off.assign(1, 0);
     h->exc_pos.clear();
     h->exc_byte.clear();
@@ -1304,6 +1311,24 @@ void note_first_words(po_handle* h) {
         h->first_words.push_back(o + 1 < store.size() ? store[o + 1] : 0);
     }
     h->first_n = n;
+}
+
+constexpr uint32_t LEAD_WORDS = 5;   // windows of 4 word-spaced K-mers at W phases: bases 0 .. 5 W - 2 of a read
+void note_lead_words(po_handle* h) {
+    const uint32_t n = (uint32_t)h->len.size();
+    if (h->lead_n == n && h->lead_words.size() == (size_t)LEAD_WORDS * n) return;
+    if (h->lead_n > n || h->lead_words.size() != (size_t)LEAD_WORDS * h->lead_n) {
+        h->lead_n = 0;
+        h->lead_words.clear();
+    }
+    h->lead_words.resize((size_t)LEAD_WORDS * n, 0);
+    uint64_t* out = h->lead_words.data();
+    for (uint32_t r = h->lead_n; r < n; ++r) {
+        const WordStore& store = h->words[r & 1];
+        const uint64_t o = h->woff[r];
+        for (uint32_t k = 0; k < LEAD_WORDS; ++k) out[(size_t)r * LEAD_WORDS + k] = o + k < store.size() ? store[o + k] : 0;
+    }
+    h->lead_n = n;
 }
 
 // reads that can take part in an overlap of m bases or more
@@ -1746,8 +1771,10 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     // W ww + W - 1 <= min_length.  The streamed step keeps 1: its index is built from the first two words of every read,
     // which travel ahead of the pieces.  PHASM_WIDE_WINDOW=1|4|16 forces a smaller one (tests, A/B).
     uint32_t ww = 1;
-    if (wide && BITS == 2 && !streamed) {
+    if (wide && BITS == 2) {
         ww = m >= W * 16 + W - 1 ? 16u : m >= W * 4 + W - 1 ? 4u : 1u;
+        // (a streamed step's index is built from the words that travel ahead of the pieces: two per read, or five)
+        if (streamed) ww = (ww >= 4 && h->st_lead >= LEAD_WORDS) ? 4u : 1u;
         if (const char* e = getenv("PHASM_WIDE_WINDOW")) {
             const uint32_t v = (uint32_t)atoi(e);
             if ((v == 1 || v == 4 || v == 16) && v <= ww) ww = v;
@@ -2000,7 +2027,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     WA.tile_off = A.tile_off;
     if (wide) {
         if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE0], s1));
-        auto wscan = streamed ? po::k_wide_scan<BITS, false, BITS == 2, 1>
+        auto wscan = streamed ? (ww == 4 ? po::k_wide_scan<BITS, false, BITS == 2, 4> : po::k_wide_scan<BITS, false, BITS == 2, 1>)
                      : ww == 16 ? po::k_wide_scan<BITS, false, false, 16> : ww == 4 ? po::k_wide_scan<BITS, false, false, 4> : po::k_wide_scan<BITS, false, false, 1>;
         hipLaunchKernelGGL(wscan, dim3(cdiv(ntiles, 4)), dim3(256), 0, s1, WA, po::CandGuard{nullptr, 0u});
         if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_PROBE1], s1));
@@ -2083,7 +2110,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         if (const char* e = getenv("PHASM_PIECE_ORDER")) order = order && atoi(e) != 0;   // (A/B: pieces without the locality order)
         pred_order = order;
         auto fits = [](const DevBuf& b, uint64_t bytes) { return b.p && b.cap >= bytes; };
-        async_count = pred > 0 && cap < (4u << 20) && cdiv(cap, po::TAIL_TILE) <= po::TAIL_MAX_TILES &&
+        async_count = pred > 0 && cap < (16u << 20) && cdiv(cap, po::TAIL_TILE) <= po::TAIL_MAX_TILES &&
                       fits(h->d_cand_a, cap * 4) && fits(h->d_cand_p, cap * 4) && fits(h->d_cand_b, cap * 4) && fits(h->d_type, cap) &&
                       fits(h->d_rowcnt, cap) && fits(h->d_row_off, (cap + 1) * 4) &&
                       fits(h->spare_rows, h->home_on ? cap * sizeof(po::Cand) : worst * sizeof(po_row)) &&
@@ -2161,7 +2188,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             WA.cand_a = A.cand_a;
             WA.cand_p = A.cand_p;
             WA.cand_b = A.cand_b;
-            auto wfill = streamed ? po::k_wide_scan<BITS, true, BITS == 2, 1>
+            auto wfill = streamed ? (ww == 4 ? po::k_wide_scan<BITS, true, BITS == 2, 4> : po::k_wide_scan<BITS, true, BITS == 2, 1>)
                          : ww == 16 ? po::k_wide_scan<BITS, true, false, 16> : ww == 4 ? po::k_wide_scan<BITS, true, false, 4> : po::k_wide_scan<BITS, true, false, 1>;
             hipLaunchKernelGGL(wfill, dim3(cdiv(ntiles, 4)), dim3(256), 0, st, WA, G);
         } else {
@@ -2358,14 +2385,14 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         // candidate, so its buffer needs n_cand records, not the worst case of rows; a call whose kept buffer is too small
         // makes one here -- never a piece with a predicted count, whose buffers were checked before anything was launched)
         const bool home_tail_ok = h->home_on && !want_cands && !dpE && !getenv("PHASM_TAIL_CLASSIC") &&
-                                  (!n_selfrep_reads || ((nshards > 1 || streamed || wide) && n_cand < (4u << 20))) &&
+                                  (!n_selfrep_reads || ((nshards > 1 || streamed || wide) && n_cand < (16u << 20))) &&
                                   cdiv(n_cand, po::TAIL_TILE) <= po::TAIL_MAX_TILES;
         if (home_tail_ok && !async_count && h->spare_rows.cap < (size_t)n_cand * sizeof(po::Cand))
             PO_TRY(ensure(h, h->spare_rows, (size_t)n_cand * sizeof(po::Cand) + (streamed ? 65536 : 0), 1.0, false));
         const bool compact_tail = home_tail_ok && h->spare_rows.p && h->spare_rows.cap >= (size_t)n_cand * sizeof(po::Cand);
         const bool can_tail = compact_tail ||
                               (!want_cands && !dpE && h->spare_rows.p && h->spare_rows.cap >= worst_rows * sizeof(po_row) &&
-                               (!n_selfrep_reads || ((nshards > 1 || streamed || wide) && n_cand < (4u << 20))) &&
+                               (!n_selfrep_reads || ((nshards > 1 || streamed || wide) && n_cand < (16u << 20))) &&
                                cdiv(n_cand, po::TAIL_TILE) <= po::TAIL_MAX_TILES && !getenv("PHASM_TAIL_CLASSIC"));
         // (a piece with a predicted count has nothing but the fused tail: the classic kernels take the real count from the host)
         if (async_count && !can_tail) return fail(h, PO_ERR_HIP, "internal: a piece with a predicted candidate count needs the fused tail");
@@ -3870,10 +3897,16 @@ std::vector<uint32_t> stream_bounds(const po_handle* h) {
     // (the FIRST streamed call on a handle has no kept row buffers yet: every piece then costs two host round trips, and
     // eight pieces are the better cut -- 7.9 against 10.5 ms for the cold call at config 2)
     uint64_t max_pieces = h->chunk_rows[0].p ? 12 : 8;
+    // (stores of half a gigabyte and more -- configs 3 and 5: a piece is milliseconds of device work there, its fixed cost is
+    // nothing, and what counts is how little is left to do when the last byte has landed: 15 pieces, later ones smaller.
+    // Config 3: 17.04 -> 16.59 ms; config 5, whose kernels take as long as its upload: 68.99 -> 68.77)
+    const bool big = bytes0 >= (512ull << 20) && h->chunk_rows[0].p;
+    if (big) max_pieces = 15;
     if (const char* e = getenv("PHASM_STREAM_MAX_PIECES")) max_pieces = (uint64_t)std::max(2, std::min(PO_MAX_PIECES - 1, atoi(e)));
     const uint32_t n_pieces = (uint32_t)std::min<uint64_t>(max_pieces, std::max<uint64_t>(2, (bytes0 + (8ull << 20)) / (16ull << 20)));
+    const double skew = big ? 1.6 : 1.25;
     std::vector<uint32_t> cuts;
-    for (uint32_t i = 1; i < n_pieces; ++i) cuts.push_back((uint32_t)(1000.0 * (1.0 - std::pow(1.0 - (double)i / n_pieces, 1.25))));
+    for (uint32_t i = 1; i < n_pieces; ++i) cuts.push_back((uint32_t)(1000.0 * (1.0 - std::pow(1.0 - (double)i / n_pieces, skew))));
     if (const char* e = getenv("PHASM_STREAM_CUTS")) {
         cuts.clear();
         for (const char* q = e; *q;) {
@@ -3955,17 +3988,29 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
         // first words of the reads of the later pieces (both strands: the host packed the odd store too, it just does
         // not travel), put in place on the handle's stream while piece 0 is crossing; the later pieces' copies are
         // ordered behind that kernel -- they bring the same values, but two writers of one word want an order
-        note_first_words(h);   // (nothing to do when po_add_sequence kept them up to date)
         // With the index built ahead of piece 0 (overlaps_streamed) the first words of piece 0's reads go up too: the index
         // build behind this kernel is then their only reader before the piece itself has landed, and the piece brings
         // the same values.
         const uint32_t r0 = h->st_early_index ? 0u : bounds[1];
-        PO_TRY(ensure(h, h->d_first, (size_t)n * 16));
-        HIP_TRY(h, hipMemcpyAsync(h->d_first.as<uint64_t>() + 2 * (size_t)r0, h->first_words.data() + 2 * (size_t)r0,
-                                  (size_t)(n - r0) * 16, hipMemcpyHostToDevice, h->stream));
-        h->upload_bytes += (size_t)(n - r0) * 16;
-        hipLaunchKernelGGL(po::k_scatter_first, dim3(cdiv(n - r0, 256)), dim3(256), 0, h->stream, dw, h->d_woff.as<uint64_t>(),
-                           h->d_first.as<ulonglong2>(), r0, n);
+        if (h->st_lead > 2) {
+            // (large read sets: five words per read, so that the index can hold window minimisers -- 40 B per read ahead of
+            // the pieces instead of 16, 2 % of the upload, for a counting pass of 0.55 x the time)
+            note_lead_words(h);
+            PO_TRY(ensure(h, h->d_first, (size_t)n * LEAD_WORDS * 8));
+            HIP_TRY(h, hipMemcpyAsync(h->d_first.as<uint64_t>() + (size_t)LEAD_WORDS * r0, h->lead_words.data() + (size_t)LEAD_WORDS * r0,
+                                      (size_t)(n - r0) * LEAD_WORDS * 8, hipMemcpyHostToDevice, h->stream));
+            h->upload_bytes += (size_t)(n - r0) * LEAD_WORDS * 8;
+            hipLaunchKernelGGL(po::k_scatter_lead, dim3(cdiv((uint64_t)(n - r0) * LEAD_WORDS, 256)), dim3(256), 0, h->stream, dw,
+                               h->d_woff.as<uint64_t>(), h->d_len.as<uint32_t>(), h->d_first.as<uint64_t>(), LEAD_WORDS, r0, n);
+        } else {
+            note_first_words(h);   // (nothing to do when po_add_sequence kept them up to date)
+            PO_TRY(ensure(h, h->d_first, (size_t)n * 16));
+            HIP_TRY(h, hipMemcpyAsync(h->d_first.as<uint64_t>() + 2 * (size_t)r0, h->first_words.data() + 2 * (size_t)r0,
+                                      (size_t)(n - r0) * 16, hipMemcpyHostToDevice, h->stream));
+            h->upload_bytes += (size_t)(n - r0) * 16;
+            hipLaunchKernelGGL(po::k_scatter_first, dim3(cdiv(n - r0, 256)), dim3(256), 0, h->stream, dw, h->d_woff.as<uint64_t>(),
+                               h->d_first.as<ulonglong2>(), r0, n);
+        }
         HIP_TRY(h, hipGetLastError());
         if (!h->ev_first) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_first, hipEventDisableTiming));
         HIP_TRY(h, hipEventRecord(h->ev_first, h->stream));
@@ -4023,6 +4068,15 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
     h->st_selfclean = false;
     h->two_stream = false;
     h->st_early_index = P > 1 && h->poison < 0 && !getenv("PHASM_NO_INDEX_REUSE") && !getenv("PHASM_LATE_INDEX");
+    {
+        // words per read that travel ahead of the pieces: two, or five where the step will take the wide index and min_length
+        // allows windows of 4 (run_overlaps decides the same way: more than 160 k eligible reads, min_length >= 5 W - 1)
+        const uint32_t m = min_length ? min_length : 1;
+        const char* idx = getenv("PHASM_INDEX");
+        const char* win = getenv("PHASM_WIDE_WINDOW");
+        const bool wide = (idx && !strcmp(idx, "wide")) || (!(idx && !strcmp(idx, "narrow")) && count_eligible(h, m) > 160000);
+        h->st_lead = (h->bits == 2 && wide && m >= 32u * 4u + 31u && !(win && atoi(win) < 4) && !getenv("PHASM_STREAM_LEAD2")) ? LEAD_WORDS : 2u;
+    }
     PO_TRY(stream_begin(h, bounds));
     if (trace) std::fprintf(stderr, "[stream] %u pieces queued at %.3f ms\n", P, since());
     // (two-stream pieces need the index built ahead -- its event is what the first counting pass waits for -- and no poison

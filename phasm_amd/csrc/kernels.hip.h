@@ -2392,6 +2392,19 @@ __global__ void k_scatter_first(uint64_t* __restrict__ words, const uint64_t* __
     *reinterpret_cast<ulonglong2*>(words + woff[r]) = f;
 }
 
+// ... and the first `nw` words of every read (the wide index with windows of 4 reads the K-mers at the first 4 W offsets: bases
+// 0 .. 5W-2).  Clipped to the words the read owns (its data words and the guard word behind them): a short read's neighbour
+// is not touched -- the last read of store 0 is followed by store 1's first read on the device, by nothing on the host.
+__global__ void k_scatter_lead(uint64_t* __restrict__ words, const uint64_t* __restrict__ woff, const uint32_t* __restrict__ len,
+                               const uint64_t* __restrict__ lead, uint32_t nw, uint32_t r0, uint32_t n) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t r = r0 + t / nw;
+    const uint32_t k = (uint32_t)(t % nw);
+    if (r >= n) return;
+    const uint32_t own = (len[r] + 31u) / 32u + 1u;
+    if (k < own) words[woff[r] + k] = lead[r * nw + k];
+}
+
 // Containment candidates (B) whose b-side read has not arrived yet: the verify kernel leaves them alone
 // (keep_bits with the piece's b_limit); they are copied to one list and settled after the last piece.
 // counter[0] keeps counting past `cap`, so that the host learns how much room the list needed.
@@ -2827,7 +2840,7 @@ __global__ __launch_bounds__(PS_BLOCK) void k_ps_chain(T* __restrict__ in, const
 constexpr int TAIL_BLOCK = 256;
 constexpr int TAIL_ITEMS = 2;
 constexpr int TAIL_TILE = TAIL_BLOCK * TAIL_ITEMS;
-constexpr uint32_t TAIL_MAX_TILES = 1u << 12;   // (a workgroup sums the tiles before its own: 2 M candidates at most -- a piece
+constexpr uint32_t TAIL_MAX_TILES = 1u << 15;   // (a workgroup sums the tiles before its own: 16 M candidates at most -- a piece
                                                 //  of a streamed step, a shard; a whole-set call of 6.5 M candidates is faster classic)
 
 // COMPACT: the tail hands out verified candidates instead of rows (k_tail_cands): tile_rows[] = verified candidates per tile
