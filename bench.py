@@ -525,6 +525,11 @@ def main() -> int:
     # process a throttled period -- cpu.stat nr_throttled counts them --, and a period that starts inside the timed loop
     # stops every thread of the step for milliseconds.  Let it pass before the clock starts.)
     time.sleep(0.3)
+    # (the process holds a few hundred thousand Python objects -- the generated reads --: a generation-2 pass of the cyclic
+    # collector inside a 4.7 ms step is a pause of milliseconds that has nothing to do with the step)
+    import gc
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):
         step(False)
     fence()
@@ -539,6 +544,7 @@ def main() -> int:
     fence()
     dt = time.perf_counter() - t0
     throttled1 = cpu_throttled()
+    gc.enable()
     if world > 1 or args.dist_path:
         t = torch.tensor([dt], dtype=torch.float64, device=merge_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -599,6 +605,7 @@ def main() -> int:
             # with someone else's work shows as a max far from the median -- the step's last stage runs on host threads)
             "steps_ms": {"median": sorted(step_ms)[len(step_ms) // 2], "min": min(step_ms), "max": max(step_ms),
                          "p90": sorted(step_ms)[min(len(step_ms) - 1, (len(step_ms) * 9) // 10)],
+                         "all": [round(x, 3) for x in step_ms],
                          # (CPU-quota periods in which the scheduler stopped this process, and for how long, inside the timed loop)
                          "cpu_quota_throttled_periods": None if throttled0 is None or throttled1 is None else throttled1[0] - throttled0[0],
                          "cpu_quota_throttled_ms": None if throttled0 is None or throttled1 is None else (throttled1[1] - throttled0[1]) / 1e3},
