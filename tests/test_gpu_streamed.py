@@ -225,9 +225,12 @@ def test_streamed_step_with_empty_and_tiny_reads(monkeypatch):
     monkeypatch.setenv("PHASM_STREAM_CUTS", "300,600,900")
     base = _nested_reads(3, 30, 1500, 40, 400)
     tiny = [b"", b"", b"ACG", b"CGT", b"A", b"T"]
-    for index, m in (("narrow", 1), ("narrow", 30), ("wide", 64)):
+    # (wide, 160: min_length >= 5 W - 1, so FIVE words per read travel ahead of the pieces and the index holds windows of 4 --
+    # k_scatter_lead must stop at the words a short read owns: the reads of 33 .. 130 bases own two to five of them)
+    mid = [b"ACGTTGCA" * 5 + b"G", (b"ACGTTGCA" * 5 + b"G").translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1]]
+    for index, m in (("narrow", 1), ("narrow", 30), ("wide", 64), ("wide", 160)):
         monkeypatch.setenv("PHASM_INDEX", index)
-        for seqs in (base[:20] + tiny + base[20:], base + tiny, tiny[:2] + base + tiny[:2]):
+        for seqs in (base[:20] + tiny + base[20:], base + tiny, tiny[:2] + base + tiny[:2], base[:10] + mid + tiny + base[10:] + mid):
             want = ck.oracle_overlaps(seqs, m)
             (got, st), (got2, _) = streamed_rows(seqs, m, calls=2)
             assert st["streamed"] == 1
