@@ -292,7 +292,10 @@ struct po_handle {
     hipStream_t scan_stream = nullptr;
     hipEvent_t ev_s1[2] = {};
     hipEvent_t ev_idx = nullptr;     // the step's index (and everything queued before it on the handle's stream) is complete
-    bool two_stream = false;         // this streamed step runs its pieces that way
+    int two_stream = 0;              // this streamed step runs its pieces that way: 1 = on scan_stream; 2 = on rc_stream, and the
+                                     // counting pass of piece k + 1 does not start before the verify kernel of piece k has
+    hipEvent_t ev_gate[2] = {};      // (ev_gate[k & 1]: recorded on the handle's stream right in front of piece k's verify kernel)
+    int want_two = 0;                // what the step asked for (stream_begin queues no reverse complements up front for 2)
     uint32_t st_k = 0;               // the piece run_overlaps is working on (its event in ev_rc)
     hipEvent_t ev_meta = nullptr;
     hipEvent_t ev_first = nullptr;   // the first words of the later pieces are in place
@@ -1731,7 +1734,9 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     // two-stream pieces (po_handle::scan_stream): the counting pass of this piece runs on s1, beside the second half of the
     // piece before it on st
     const bool two = streamed && h->two_stream && !h->idx_only;
-    const hipStream_t s1 = two ? h->scan_stream : st;
+    const bool gated = two && h->two_stream == 2;
+    bool gate_recorded = false;
+    const hipStream_t s1 = two ? (gated ? h->rc_stream : h->scan_stream) : st;
     S.paired = paired ? 1u : 0u;
     S.max_diff = dpE;
     S.band = dpW;
@@ -1972,7 +1977,25 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
         // the counting pass needs the index (and the per-read tables and tiles queued before it), this piece's reads with their
         // reverse complements, and the parity's small state free again: the second half of the piece two before this one
         HIP_TRY(h, hipStreamWaitEvent(s1, h->ev_idx, 0));
-        HIP_TRY(h, hipStreamWaitEvent(s1, h->ev_rc[h->st_k], 0));
+        if (gated) {
+            // (this stream IS the one that writes the odd reads: piece k's reverse complements are queued here, in front of
+            // its counting pass, not all up front -- a stream's commands run in order, and the pass of piece k must not sit
+            // behind the reverse complements of pieces that have not landed)
+            const uint32_t p0 = r_begin / 2, p1 = r_end / 2;
+            HIP_TRY(h, hipStreamWaitEvent(s1, h->ev_piece[h->st_k], 0));
+            if (p1 > p0)
+                hipLaunchKernelGGL(po::k_revcomp_store, dim3(cdiv((uint64_t)(p1 - p0) * 64, 256)), dim3(256), 0, s1, h->d_words.as<uint64_t>(),
+                                   h->d_woff.as<uint64_t>(), h->d_len.as<uint32_t>(), p0, p1,
+                                   h->n_exc_uploaded ? h->d_exc_off.as<uint32_t>() : nullptr, h->d_exc_pos.as<uint32_t>());
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipEventRecord(h->ev_rc[h->st_k], s1));
+            // ... and the pass starts when the verify kernel of the piece before does: its one persistent workgroup per CU
+            // needs a whole CU, so it moves in as the verify workgroups drain -- the tail of one big kernel under the start
+            // of the next -- instead of taking the chip away from the small kernels in front of that verify kernel
+            if (h->st_k >= 1) HIP_TRY(h, hipStreamWaitEvent(s1, h->ev_gate[(h->st_k - 1) & 1], 0));
+        } else {
+            HIP_TRY(h, hipStreamWaitEvent(s1, h->ev_rc[h->st_k], 0));
+        }
         if (h->st_k >= 2) HIP_TRY(h, hipStreamWaitEvent(s1, h->ev[EV_DONE], 0));
     }
     // ---- scan, counting pass
@@ -2345,6 +2368,10 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
             if (ver_lds > 48 * 1024)
                 HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(verify), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ver_lds));
             if (h->pair_events) HIP_TRY(h, hipEventRecord(h->ev[EV_VER0], st));
+            if (gated) {
+                HIP_TRY(h, hipEventRecord(h->ev_gate[h->st_k & 1], st));
+                gate_recorded = true;
+            }
             hipLaunchKernelGGL(verify, dim3(ver_grid), dim3(po::VER_BLOCK), ver_lds, st,
                                words, woff, len, h->d_read_tile0.as<uint32_t>(), tile_off_p, A.cand_p,
                                A.cand_b, r_begin, lds_words, paired_ver,
@@ -2570,6 +2597,7 @@ po_status run_overlaps(po_handle* h, uint32_t min_length, uint32_t shard, uint32
     uint64_t* counters = h->pinned + 4;
     if (!used_tail) HIP_TRY(h, hipMemcpyAsync(counters, scalars + 4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     res->unique_twins = !want_cands && paired != 0 && !dpE;
+    if (gated && !gate_recorded) HIP_TRY(h, hipEventRecord(h->ev_gate[h->st_k & 1], st));   // (a piece without candidates: nothing to wait behind)
     HIP_TRY(h, hipEventRecord(h->ev[EV_DONE], st));
     h->st_selfclean = streamed && self_clean && used_tail && !wide;   // (the next piece of this step may skip its reset)
     if (async_count && h->st_pend.valid) {
@@ -3263,6 +3291,11 @@ void po_destroy(po_handle* h) {
         h->stage_host.release();
         for (void* c : h->arena_chunks) (void)hipFree(c);
         h->arena_chunks.clear();
+        for (hipEvent_t& e : h->ev_gate)   // (the handle's own, never part of the pooled kit)
+            if (e) {
+                (void)hipEventDestroy(e);
+                e = nullptr;
+            }
         if (!pooled) {
         if (h->up_stream) {
             (void)hipStreamSynchronize(h->up_stream);
@@ -4027,6 +4060,7 @@ po_status stream_begin(po_handle* h, const std::vector<uint32_t>& bounds) {
     HIP_TRY(h, hipStreamWaitEvent(h->rc_stream, h->ev_meta, 0));
     for (uint32_t k = 0; k < P; ++k) {
         if (!h->ev_rc[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_rc[k], hipEventDisableTiming));
+        if (h->want_two == 2) continue;   // (gated two-stream pieces queue their reverse complements themselves: run_overlaps)
         HIP_TRY(h, hipStreamWaitEvent(h->rc_stream, h->ev_piece[k], 0));
         const uint32_t p0 = bounds[k] / 2, p1 = bounds[k + 1] / 2;
         if (p1 > p0)
@@ -4067,7 +4101,8 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
     // the index ahead of piece 0: it needs every read's first word(s) only, and at 400 k reads (wide index, 2.9 ms; 16 ms at
     // 2 M reads) building it inside piece 0 -- after the piece has landed -- kept every later piece 2-3 ms behind its data
     h->st_selfclean = false;
-    h->two_stream = false;
+    h->two_stream = 0;
+    h->want_two = 0;
     h->st_early_index = P > 1 && h->poison < 0 && !getenv("PHASM_NO_INDEX_REUSE") && !getenv("PHASM_LATE_INDEX");
     {
         // words per read that travel ahead of the pieces: two, or five where the step will take the wide index and min_length
@@ -4078,6 +4113,18 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
         const bool wide = (idx && !strcmp(idx, "wide")) || (!(idx && !strcmp(idx, "narrow")) && count_eligible(h, m) > 160000);
         h->st_lead = (h->bits == 2 && wide && m >= 32u * 4u + 31u && !(win && atoi(win) < 4) && !getenv("PHASM_STREAM_LEAD2")) ? LEAD_WORDS : 2u;
     }
+    {
+        // PHASM_TWO_STREAM=1: counting passes on a stream of their own (scan_stream); 2: on rc_stream, gated by the verify kernel
+        // of the piece before.  Both need the index built ahead of piece 0 (its event is what the first pass waits for).
+        const char* e2 = getenv("PHASM_TWO_STREAM");
+        const int asked = e2 ? atoi(e2) : 0;
+        h->want_two = (h->st_early_index && h->ev_idx && (asked == 1 || asked == 2)) ? asked : 0;
+        for (int g = 0; g < 2 && h->want_two == 2; ++g)
+            if (!h->ev_gate[g] && hipEventCreateWithFlags(&h->ev_gate[g], hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                h->want_two = 0;
+            }
+    }
     PO_TRY(stream_begin(h, bounds));
     if (trace) std::fprintf(stderr, "[stream] %u pieces queued at %.3f ms\n", P, since());
     // (two-stream pieces need the index built ahead -- its event is what the first counting pass waits for -- and no poison
@@ -4085,12 +4132,11 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
     // Measured, round 4 (config 2): 7.1-7.2 ms per step against 4.5 on one stream -- the persistent scan kernel takes every CU's
     // LDS and registers, the verify workgroups of the piece before wait behind it, and both run slower side by side than one
     // after the other.  Off unless PHASM_TWO_STREAM=1 asks for it.
-    const bool want_two = getenv("PHASM_TWO_STREAM") && atoi(getenv("PHASM_TWO_STREAM")) != 0;
-    if (want_two && !h->scan_stream && hipStreamCreateWithFlags(&h->scan_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (h->want_two == 1 && !h->scan_stream && hipStreamCreateWithFlags(&h->scan_stream, hipStreamNonBlocking) != hipSuccess) {
         h->scan_stream = nullptr;
         (void)hipGetLastError();
     }
-    h->two_stream = h->st_early_index && h->scan_stream && h->ev_idx && want_two;
+    h->two_stream = h->want_two == 2 ? 2 : (h->want_two == 1 && h->scan_stream) ? 1 : 0;
     if (h->st_early_index) {
         po_result part;
         part.h = h;
@@ -4145,7 +4191,9 @@ po_status overlaps_streamed(po_handle* h, uint32_t min_length, HostRows& R, po_s
     if (getenv("PHASM_STREAM_SYNC")) h->st_harvest = nullptr;   // (developer switch: every piece waits for its own end)
     for (uint32_t k = 0; k < P && st == PO_OK; ++k) {
         // piece k has landed and its odd reads (reverse complements) have been written next to it (rc_stream, stream_begin)
-        if (hipStreamWaitEvent(h->stream, h->ev_rc[k], 0) != hipSuccess) { st = fail(h, PO_ERR_HIP, "hipStreamWaitEvent"); break; }
+        // (gated two-stream pieces: the reverse complements are queued inside run_overlaps, in front of the counting pass the
+        // handle's stream then waits for -- ev_rc[k] has not been recorded yet at this point)
+        if (h->two_stream != 2 && hipStreamWaitEvent(h->stream, h->ev_rc[k], 0) != hipSuccess) { st = fail(h, PO_ERR_HIP, "hipStreamWaitEvent"); break; }
         h->st_on = true;
         h->st_k = k;
         h->st_r_begin = bounds[k];
