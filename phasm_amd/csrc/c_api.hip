@@ -794,25 +794,40 @@ inline void put_row(uint64_t*& o, uint32_t a, uint32_t b, uint32_t astart, uint3
 }
 
 // rows of records [lo, hi) -> out; returns false when a record names a read the handle does not hold
-bool expand_records(const Pool& P, uint64_t lo, uint64_t hi, po_row* out) {
+// (the byte counters of po_stats -- write_rows' counters, kernels.hip.h -- are taken here, where the two lengths are at hand:
+// the counting pass in front of this one then needs nothing but the records)
+bool expand_records(Pool& P, uint64_t lo, uint64_t hi, po_row* out) {
     uint64_t* o = reinterpret_cast<uint64_t*>(out);
     const Job& job = P.cur;
     const uint32_t* len = P.len;
-    const uint32_t paired = P.paired, n_reads = P.n_reads;
+    const uint32_t paired = P.paired, n_reads = P.n_reads, bits = P.bits;
+    auto pb = [bits](uint32_t l) -> uint64_t { return bits == 8u ? l : (l >> 2) + ((l & 3u) != 0u); };
+    uint64_t sl = 0, sb = 0, se = 0;
     for (uint64_t i = lo; i < hi; ++i) {
         const po::Cand c = load_rec(job, i);
         if (c.a >= n_reads || c.b >= n_reads) return false;
         const uint32_t la = len[c.a], lb = len[c.b];
+        se += 2 * pb((c.type & 1u) ? la - c.p : lb);
         if (c.type & 1u) {
             const uint32_t l = la - c.p;
+            const bool twin = paired && c.a != (c.b ^ 1u);
             put_row(o, c.a, c.b, c.p, la, l);
-            if (paired && c.a != (c.b ^ 1u)) put_row(o, c.b ^ 1u, c.a ^ 1u, lb - l, lb, l);
+            if (twin) put_row(o, c.b ^ 1u, c.a ^ 1u, lb - l, lb, l);
+            const uint64_t k = twin ? 2 : 1;
+            sl += k * l;
+            sb += k * 2 * pb(l);
         }
         if (c.type & 2u) {
             put_row(o, c.a, c.b, c.p, c.p + lb, lb);
             if (paired) put_row(o, c.a ^ 1u, c.b ^ 1u, la - c.p - lb, la - c.p, lb);
+            const uint64_t k = paired ? 2 : 1;
+            sl += k * lb;
+            sb += k * 2 * pb(lb);
         }
     }
+    P.sum_l.fetch_add(sl, std::memory_order_relaxed);
+    P.sum_b.fetch_add(sb, std::memory_order_relaxed);
+    P.sum_e.fetch_add(se, std::memory_order_relaxed);
     return true;
 }
 
@@ -824,31 +839,10 @@ void run_phases(Pool& P, bool lead) {
         const uint32_t c = P.next_count.fetch_add(1, std::memory_order_relaxed);
         if (c >= nc) break;
         const uint64_t lo = (uint64_t)c * CHUNK, hi = std::min<uint64_t>(P.cur.n_rec, lo + CHUNK);
-        uint64_t n = 0, sl = 0, sb = 0, se = 0;
-        const uint32_t n_reads = P.n_reads, bits = P.bits, paired = P.paired;
-        auto pb = [bits](uint32_t l) -> uint64_t { return bits == 8u ? l : (l >> 2) + ((l & 3u) != 0u); };
-        for (uint64_t i = lo; i < hi; ++i) {
-            const po::Cand c = load_rec(P.cur, i);
-            n += rows_of_rec(c, paired);
-            if (c.a < n_reads && c.b < n_reads) {   // (write_rows' counters, kernels.hip.h)
-                const uint32_t la = P.len[c.a], lb = P.len[c.b];
-                se += 2 * pb((c.type & 1u) ? la - c.p : lb);
-                if (c.type & 1u) {
-                    const uint64_t k = (paired && c.a != (c.b ^ 1u)) ? 2 : 1;
-                    sl += k * (la - c.p);
-                    sb += k * 2 * pb(la - c.p);
-                }
-                if (c.type & 2u) {
-                    const uint64_t k = paired ? 2 : 1;
-                    sl += k * lb;
-                    sb += k * 2 * pb(lb);
-                }
-            }
-        }
+        uint64_t n = 0;
+        const uint32_t paired = P.paired;
+        for (uint64_t i = lo; i < hi; ++i) n += rows_of_rec(load_rec(P.cur, i), paired);
         P.chunk_off[c + 1] = n;
-        P.sum_l.fetch_add(sl, std::memory_order_relaxed);
-        P.sum_b.fetch_add(sb, std::memory_order_relaxed);
-        P.sum_e.fetch_add(se, std::memory_order_relaxed);
         P.done_count.fetch_add(1, std::memory_order_release);
     }
     if (lead) {

@@ -59,8 +59,9 @@ def main():
                 times[s].append(step()[0])
     for s in args.settings:
         t = sorted(times[s])
-        print("%-70s median %.3f  min %.3f  p25 %.3f  p75 %.3f  (%d steps)" % (s or "(defaults)", statistics.median(t), t[0], t[len(t) // 4],
-                                                                               t[3 * len(t) // 4], len(t)), flush=True)
+        print("%-70s median %.3f  min %.3f  p25 %.3f  p75 %.3f  p95 %.3f  max %.3f  mean %.3f  (%d steps)"
+              % (s or "(defaults)", statistics.median(t), t[0], t[len(t) // 4], t[3 * len(t) // 4], t[min(len(t) - 1, len(t) * 95 // 100)], t[-1],
+                 sum(t) / len(t), len(t)), flush=True)
     ov.close()
 
 
