@@ -52,6 +52,25 @@ def test_streamed_step_matches_the_goldens(cuts, index, monkeypatch):
     assert (n_wide >= 6) == (index == "wide")
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_two_stream_pieces_give_the_same_rows(mode, monkeypatch):
+    """PHASM_TWO_STREAM: the counting pass of piece k + 1 beside the second half of piece k -- 1: on a stream of its own,
+    2: on the stream that writes the reverse complements, held back until piece k's verify kernel starts.
+    Switches, not the default; the rows must not know.  Three calls: the third runs on predicted candidate counts."""
+    monkeypatch.setenv("PHASM_STREAM", "1")
+    monkeypatch.setenv("PHASM_STREAM_CUTS", "200,400,600,800")
+    monkeypatch.setenv("PHASM_TWO_STREAM", mode)
+    monkeypatch.setenv("PHASM_VERIFY_ORDER", "1")
+    for name in ("ladder_cfg2_mini", "cfg2_1k", "ladder_varlen"):
+        _, seqs, m, want = gu.ladder_case(name)
+        for got, st in streamed_rows(seqs, m, calls=3):
+            assert st["streamed"] == 1
+            ck.assert_same_rows(got, want, seqs, m, "%s, two-stream mode %s" % (name, mode))
+    for name, seqs, m, want in gu.repeats_cases():
+        for got, st in streamed_rows(seqs, m, calls=2):
+            ck.assert_same_rows(got, want, seqs, m, "%s, two-stream mode %s" % (name, mode))
+
+
 def _nested_reads(seed, n_reads, genome_len, lo, hi):
     """reads of very different lengths from a short genome: many reads lie inside longer ones (containments), in
     both index directions; every read is followed by its reverse complement"""
